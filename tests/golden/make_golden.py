@@ -1,0 +1,533 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE's own functions.
+
+Runs ONLY in the build container (it needs /root/reference, which never travels to the
+GPU box).  It imports the reference's hot-path modules, drives them on explicit seeded
+inputs and writes inputs + expected outputs as small .npz / .json DATA files.  No
+reference source text is copied: only numbers and strings produced by running it.
+
+How the reference is made importable here:
+  * utils/gaussian_smoothing.py, utils/helpers.py, utils/shared_state.py, config.py import
+    as-is.
+  * utils/ptp_utils.py and pipeline_guided_attention.py import third-party packages that
+    are not installed (cv2, IPython, diffusers 0.12.1, pyrallis) purely for names that the
+    hot-path functions never call; empty placeholder modules satisfy those import
+    statements.  None of the arithmetic that is pinned below goes through a placeholder.
+  * the reference pins tensors with `.cuda()`; on this CPU-only box that call is made the
+    identity for the duration of this script.
+
+Usage:  python tests/golden/make_golden.py        (rewrites tests/golden/*.npz, *.json)
+"""
+import json
+import logging
+import math
+import os
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+sys.path.insert(0, str(OUT))
+import hashrand  # noqa: E402  (inputs rebuilt bit-for-bit by the tests instead of being stored)
+
+
+# ----------------------------------------------------------------------------- import recipe
+class _Placeholder(types.ModuleType):
+    """Module whose every attribute is an empty class (satisfies `from x import Y`)."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        cls = type(name, (), {})
+        setattr(self, name, cls)
+        return cls
+
+
+def import_reference():
+    if not REF.exists():
+        raise SystemExit("reference checkout not present; fixtures can only be regenerated in the build container")
+    sys.path.insert(0, str(REF))
+    names = [
+        "cv2", "IPython", "IPython.display", "pyrallis",
+        "diffusers", "diffusers.configuration_utils", "diffusers.models",
+        "diffusers.models.unet_2d_condition", "diffusers.models.cross_attention",
+        "diffusers.schedulers", "diffusers.utils", "diffusers.pipelines",
+        "diffusers.pipelines.pipeline_utils", "diffusers.pipelines.stable_diffusion",
+        "diffusers.pipelines.stable_diffusion.safety_checker",
+    ]
+    for n in names:
+        sys.modules[n] = _Placeholder(n)
+        if "." in n:  # `from pkg import sub` must resolve to the sub-module placeholder
+            parent, leaf = n.rsplit(".", 1)
+            setattr(sys.modules[parent], leaf, sys.modules[n])
+    sys.modules["diffusers.utils"].logging = types.SimpleNamespace(get_logger=logging.getLogger)
+    sys.modules["pyrallis"].wrap = lambda *a, **k: (lambda f: f)
+    import transformers
+    if not hasattr(transformers, "CLIPFeatureExtractor"):
+        transformers.CLIPFeatureExtractor = type("CLIPFeatureExtractor", (), {})
+    # neutralise device pinning (CPU-only box)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    cwd = os.getcwd()
+    os.chdir("/tmp")  # RunConfig.__post_init__ creates ./outputs
+    try:
+        import config as ref_config
+        import utils.shared_state as state
+        import utils.helpers as helpers
+        import utils.gaussian_smoothing as gs
+        import utils.ptp_utils as ptp
+        import pipeline_guided_attention as pga
+    finally:
+        os.chdir(cwd)
+    return ref_config, state, helpers, gs, ptp, pga
+
+
+ref_config, state, helpers, gs, ptp, pga = import_reference()
+
+BASE_PROMPT = "a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55]"
+
+
+class WordTokenizer:
+    """Whitespace tokenizer with CLIP's framing (BOS=49406, EOS=49407); for the prompts
+    used here every word is one CLIP token, so indices match the real tokenizer."""
+
+    def __init__(self):
+        self.vocab = {}
+        self.model_max_length = 77
+
+    def _id(self, w):
+        return self.vocab.setdefault(w, 1000 + len(self.vocab))
+
+    def __call__(self, text, **kw):
+        return {"input_ids": [49406] + [self._id(w) for w in text.split()] + [49407]}
+
+    def decode(self, tid):
+        for w, i in self.vocab.items():
+            if i == tid:
+                return w
+        return {49406: "<|startoftext|>", 49407: "<|endoftext|>"}.get(tid, "?")
+
+
+class Harness(pga.GuidedAttention):
+    def __init__(self):
+        self.tokenizer = WordTokenizer()
+        self.prompt = None
+
+    def save_viridis(self, tensor1, tag):  # PNG side effect of the reference: dropped
+        pass
+
+
+def fresh_config(meta_prompt, **over):
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        cfg = ref_config.RunConfig(meta_prompt=meta_prompt)
+    finally:
+        os.chdir(cwd)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def setup_prompt(h, meta_prompt, hyper=None, **cfg_over):
+    """Mirror of run.py:parseMetaPrompt driven with the word tokenizer."""
+    cfg = fresh_config(meta_prompt, **cfg_over)
+    state.config = cfg
+    state.curHyperParams = dict(state.hyperParameterOverrides)
+    if hyper:
+        state.curHyperParams.update(hyper)
+    state.cur_time_step_iter = 0
+    state.sub_iteration = 0
+    cfg.prompt, cfg.meta_info, cfg.custom_loss = helpers.parse_prompt(cfg.meta_prompt)
+    tokenized = h.tokenizer(cfg.prompt)["input_ids"]
+    token_dict = {}
+    for item in cfg.meta_info:
+        toks = h.tokenizer(item[0])["input_ids"][1:-1]
+        n = len(toks)
+        idx = None
+        for i in range(0, len(tokenized) - n):
+            if tokenized[i:i + n] == toks:
+                idx = list(range(i, i + n))
+                break
+        for i in idx:
+            token_dict[i] = {"word": h.tokenizer.decode(tokenized[i]), "loss_type": item[1],
+                             "loss": item[2], "subprompt": item[0]}
+    cfg.token_dict = token_dict
+    if not cfg.custom_loss:
+        del cfg.custom_loss  # the reference's hasattr() probe must see "no custom loss"
+    h.prompt = cfg.prompt
+    return cfg
+
+
+def ser_meta(meta_info):
+    out = []
+    for tok, typ, val in meta_info:
+        if typ == helpers.AnnotationType.BOX:
+            v = [val.x, val.y, val.width, val.height, val.size]
+        elif typ == helpers.AnnotationType.COOR:
+            v = list(val)
+        else:
+            v = None
+        out.append([tok, typ.name, v])
+    return out
+
+
+def f32(t):
+    if isinstance(t, (int, float)):
+        return np.float32(t)
+    return t.detach().to(torch.float32).cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- G1
+def g1_gaussian():
+    out = {}
+    for k, s in [(3, 0.5), (3, 1.0), (5, 1.0), (5, 0.75)]:
+        m = gs.GaussianSmoothing(channels=1, kernel_size=k, sigma=s, dim=2)
+        out[f"k{k}_s{s}"] = f32(m.weight[0, 0])
+    # forward on a reflect-padded random image (the call pattern of pipeline:252-254)
+    g = torch.Generator().manual_seed(11)
+    img = torch.rand(16, 16, generator=g)
+    m = gs.GaussianSmoothing(channels=1, kernel_size=3, sigma=0.5, dim=2)
+    inp = torch.nn.functional.pad(img[None, None], (1, 1, 1, 1), mode="reflect")
+    out["fwd_in"] = f32(img)
+    out["fwd_out"] = f32(m(inp)[0, 0])
+    np.savez(OUT / "g1_gaussian.npz", **out)
+
+
+# ----------------------------------------------------------------------------- G2
+class _DummyCustom:
+    def subprompts_of_interest(self, args):
+        return [a.strip() for a in args.strip("()").split(",")]
+
+
+def g2_parse():
+    prompts = [
+        BASE_PROMPT,
+        "a [rat:.2,.4] and a [fox:.6,.5]",
+        "a [robot:.6,.3,.4,.55] and a [vase:0,.3,.4,.55] and the [moon:.35,.05,.35,.35]",
+        "a photo of a [cat:0.1,0.2,0.3,0.4] sitting on grass",
+        "[dog: .5 , .5] running",
+        "plain prompt with no annotations",
+        "a [cat:.2,.5] and a [vase:.7,.5] [CustomLoss:toLeftOf (cat, vase)]",
+        "  leading spaces and a [red ball:.1,.1,.2,.2]",
+    ]
+    cases = []
+    for p in prompts:
+        cfg = fresh_config(p)
+        cfg.registered_loss_functions = {"toLeftOf": _DummyCustom()}
+        state.config = cfg
+        prompt, meta, custom = helpers.parse_prompt(p)
+        cases.append({"meta_prompt": p, "prompt": prompt, "meta_info": ser_meta(meta),
+                      "custom_losses": {k: v[1] for k, v in custom.items()}})
+    (OUT / "g2_parse_prompt.json").write_text(json.dumps(cases, indent=1))
+
+
+# ----------------------------------------------------------------------------- G3
+def g3_masks():
+    rects = [(.6, .3, .4, .55), (.2, .3, .4, .55), (0., 0., .5, .5), (.25, .25, .5, .5),
+             (.35, .05, .35, .35), (0., .3, .4, .55), (.7, .7, .5, .5), (.4, .4, .01, .01)]
+    cases = []
+    arrs = {}
+    n = 0
+    for res in (16, 24, 32):
+        for shrink in (0.0, 0.15, 0.0625):
+            state.curHyperParams = dict(state.hyperParameterOverrides, shrink_factor=shrink)
+            for r in rects:
+                rect = helpers.Rect(r[0], r[1], r[2], r[3], 1).of_size(float(res))
+                mask = np.zeros((res, res), np.uint8)
+                for ii in range(res):
+                    for jj in range(res):
+                        mask[ii, jj] = 1 if helpers.inside_box(jj, ii, rect) else 0
+                arrs[f"mask{n}"] = mask
+                cases.append({"id": n, "res": res, "shrink": shrink, "rect": list(r),
+                              "scaled": [rect.x, rect.y, rect.width, rect.height],
+                              "count": int(mask.sum()), "center": list(helpers.Rect(*r, 1).center())})
+                n += 1
+    np.savez_compressed(OUT / "g3_inside_box.npz", **arrs)
+    (OUT / "g3_inside_box.json").write_text(json.dumps(cases))
+
+
+# ----------------------------------------------------------------------------- G4
+def make_maps(kind, seed, res=16, ntok=77):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "flat":
+        A = torch.softmax(torch.randn(res, res, ntok, generator=g), -1)
+    elif kind == "sharp":
+        A = torch.softmax(3.0 * torch.randn(res, res, ntok, generator=g), -1)
+    elif kind == "onehot":
+        logits = torch.randn(res, res, ntok, generator=g)
+        hot = torch.randint(0, ntok, (res, res), generator=g)
+        logits.scatter_(-1, hot[..., None], 14.0)
+        A = torch.softmax(logits, -1)
+    elif kind == "bos":  # realistic: BOS takes most of the mass, text tokens ~1e-2, pads ~1e-3
+        logits = torch.randn(res, res, ntok, generator=g)
+        logits[..., 0] += 6.0
+        logits[..., 1:8] += 2.0
+        # a blob of attention for token 2 and token 6 so the centroid terms are not degenerate
+        yy, xx = torch.meshgrid(torch.arange(res), torch.arange(res), indexing="ij")
+        logits[..., 2] += 2.5 * torch.exp(-((yy - 4.0) ** 2 + (xx - 11.0) ** 2) / 8.0)
+        logits[..., 6] += 2.5 * torch.exp(-((yy - 10.0) ** 2 + (xx - 3.0) ** 2) / 8.0)
+        A = torch.softmax(logits, -1)
+    else:
+        raise ValueError(kind)
+    return A.to(torch.float32)
+
+
+def run_loss_case(h, A0, smooth, sigma, ksize, normalize_eot):
+    A_leaf = A0.clone().requires_grad_(True)
+    maps = A_leaf * 1.0  # the reference multiplies a view of the maps in place: needs a non-leaf
+    d = h._compute_max_attention_per_index(maps, smooth_attentions=smooth, sigma=sigma,
+                                           kernel_size=ksize, normalize_eot=normalize_eot)
+    loss, losses, unscaled = pga.GuidedAttention._compute_loss(d)
+    total, per_sub = pga.GuidedAttention.group_losses_by_sumprompt(losses)
+    _, per_sub_unscaled = pga.GuidedAttention.group_losses_by_sumprompt(unscaled)
+    grad = torch.autograd.grad(loss.requires_grad_(True), [A_leaf], allow_unused=True)[0]
+    if grad is None:
+        grad = torch.zeros_like(A_leaf)
+    T = len(d["max_loss"])
+
+    def lst(x):
+        return np.array([float(v) for v in x], np.float32).reshape(T)
+
+    return {
+        "A": f32(A0), "max": lst(d["max_loss"]), "col": lst(d["col"]), "row": lst(d["row"]),
+        "inside": lst(d["inside_loss"]), "outside": lst(d["outside_loss"]),
+        "loss": np.float32(float(loss)), "tok": np.array([k for k, _ in losses], np.int32),
+        "losses": np.array([float(v) for _, v in losses], np.float32),
+        "unscaled": np.array([float(v) for _, v in unscaled], np.float32),
+        "sub_unscaled": np.array([float(v) for v in per_sub_unscaled.values()], np.float32),
+        "dA": f32(grad),
+    }
+
+
+def g4_loss():
+    h = Harness()
+    specs = [
+        # name, meta prompt, map kind, seed, smooth, avg_within, sd21(normalize_eot), hyper overrides
+        ("base_flat", BASE_PROMPT, "flat", 1, True, False, False, None),
+        ("base_sharp", BASE_PROMPT, "sharp", 2, True, False, False, None),
+        ("base_onehot", BASE_PROMPT, "onehot", 3, True, False, False, None),
+        ("base_bos", BASE_PROMPT, "bos", 4, True, False, False, None),
+        ("base_bos_nosmooth", BASE_PROMPT, "bos", 4, False, False, False, None),
+        ("base_bos_avg", BASE_PROMPT, "bos", 5, True, True, False, None),
+        ("base_bos_eot", BASE_PROMPT, "bos", 6, True, False, True, None),
+        ("coor_bos", "a [rat:.2,.4] and a [fox:.6,.5]", "bos", 7, True, False, False, None),
+        ("mixed_sharp", "a [robot:.6,.3,.4,.55] and a [vase:.2,.45] on the [moon:.35,.05,.35,.35]", "sharp", 8,
+         True, False, False, None),
+        ("hyper_bos", BASE_PROMPT, "bos", 9, True, False, False,
+         {"inside_loss_scale": .5, "outside_loss_scale": .1, "shrink_factor": 0.0, "bb_center_weight": 0.0}),
+        ("hyper2_flat", BASE_PROMPT, "flat", 10, True, True, False,
+         {"inside_loss_scale": 1.0, "outside_loss_scale": .3, "shrink_factor": 0.05, "bb_center_weight": 0.2}),
+        # kernel_size 5 is not runnable in the reference (pad is hard-coded to 1: IndexError at
+        # pipeline_guided_attention.py:267), so only sigma varies here
+        ("s1_bos", BASE_PROMPT, "bos", 12, True, False, False, {"_sigma": 1.0, "_ksize": 3}),
+    ]
+    meta = []
+    arrs = {}
+    for name, mp, kind, seed, smooth, avg, eot, hyper in specs:
+        hyper = dict(hyper or {})
+        sigma = hyper.pop("_sigma", 0.5)
+        ksize = hyper.pop("_ksize", 3)
+        cfg = setup_prompt(h, mp, hyper or None, sub_prompt_avg_within=avg)
+        A0 = make_maps(kind, seed)
+        r = run_loss_case(h, A0, smooth, sigma, ksize, eot)
+        for k, v in r.items():
+            arrs[f"{name}.{k}"] = v
+        td = {}
+        for k, v in cfg.token_dict.items():
+            val = v["loss"]
+            if v["loss_type"] == helpers.AnnotationType.BOX:
+                val = [val.x, val.y, val.width, val.height]
+            else:
+                val = list(val)
+            td[str(k)] = {"word": v["word"], "loss_type": v["loss_type"].name, "loss": val,
+                          "subprompt": v["subprompt"]}
+        meta.append({"name": name, "meta_prompt": mp, "prompt": cfg.prompt, "smooth": smooth, "sigma": sigma,
+                     "kernel_size": ksize, "sub_prompt_avg_within": avg, "normalize_eot": eot,
+                     "n_prompt_tokens": len(h.tokenizer(cfg.prompt)["input_ids"]),
+                     "hyper": dict(state.curHyperParams), "token_dict": td})
+    np.savez_compressed(OUT / "g4_loss.npz", **arrs)
+    (OUT / "g4_loss.json").write_text(json.dumps(meta, indent=1, default=str))
+
+
+# ----------------------------------------------------------------------------- G5
+def g5_threshold():
+    h = Harness()
+    setup_prompt(h, BASE_PROMPT)
+    rows = []
+    loss_sets = {
+        "low": [(2, torch.tensor([0.05])), (5, torch.tensor([0.02])), (6, torch.tensor([0.03]))],
+        "mid": [(2, torch.tensor([0.30])), (5, torch.tensor([0.20])), (6, torch.tensor([0.15]))],
+        "high": [(2, torch.tensor([0.90])), (5, torch.tensor([0.70])), (6, torch.tensor([0.60]))],
+        "edge": [(2, torch.tensor([0.25])), (5, torch.tensor([0.125])), (6, torch.tensor([0.125]))],
+    }
+    thr_sets = {"default": {0: 1.0}, "two": {0: 0.1, 3: 0.8}, "three": {0: 0.05, 10: 0.5, 20: 0.8},
+                "quarter": {0: 0.25}, "empty": {}}
+    for ln, losses in loss_sets.items():
+        for tn, thr in thr_sets.items():
+            for i in (-1, 0, 1, 3, 10, 20):
+                try:
+                    res = bool(h.meets_threshold(i, thr, losses))
+                except Exception as e:  # e.g. i == -1 with an empty dict never indexes: record anyway
+                    res = f"raises:{type(e).__name__}"
+                rows.append({"losses": ln, "thresholds": tn, "i": i, "result": res})
+    doc = {"loss_sets": {k: [[t, float(v)] for t, v in ls] for k, ls in loss_sets.items()},
+           "thr_sets": {k: {str(a): b for a, b in v.items()} for k, v in thr_sets.items()},
+           "token_subprompt": {"2": "robot", "5": "blue vase", "6": "blue vase"}, "rows": rows}
+    (OUT / "g5_meets_threshold.json").write_text(json.dumps(doc))
+
+
+# ----------------------------------------------------------------------------- G6
+class DuckAttention(torch.nn.Module):
+    """Duck-typed stand-in for the attention module the processor is handed (only its
+    linear layers and the head split/merge; the softmax(QK^T)V arithmetic under test is the
+    reference processor's own)."""
+
+    def __init__(self, C, heads, ctx_dim, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.heads = heads
+        self.scale = (C // heads) ** -0.5
+        self.upcast_attention = False
+        self.upcast_softmax = False
+        self.to_q = torch.nn.Linear(C, C, bias=False)
+        self.to_k = torch.nn.Linear(ctx_dim, C, bias=False)
+        self.to_v = torch.nn.Linear(ctx_dim, C, bias=False)
+        self.to_out = torch.nn.ModuleList([torch.nn.Linear(C, C), torch.nn.Dropout(0.0)])
+        with torch.no_grad():
+            for p in self.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * (1.5 / math.sqrt(p.shape[-1])))
+        self.captured = {}
+
+        def keep_q(mod, inp, outp):  # returns None: the output is not replaced
+            outp.retain_grad()
+            self.captured["q"] = outp
+
+        self.to_q.register_forward_hook(keep_q)
+
+    def prepare_attention_mask(self, mask, n):
+        return mask
+
+    def head_to_batch_dim(self, t):
+        b, n, c = t.shape
+        return t.reshape(b, n, self.heads, c // self.heads).permute(0, 2, 1, 3).reshape(b * self.heads, n, c // self.heads)
+
+    def batch_to_head_dim(self, t):
+        bh, n, d = t.shape
+        b = bh // self.heads
+        return t.reshape(b, self.heads, n, d).permute(0, 2, 1, 3).reshape(b, n, d * self.heads)
+
+
+def g6_processor():
+    h = Harness()
+    setup_prompt(h, BASE_PROMPT)
+    specs = [
+        # name, C, heads, N, ctx_len (None = self attention), ctx_dim, batch, place
+        ("cross_d16", 32, 2, 256, 77, 48, 1, "up"),
+        ("cross_d40", 80, 2, 256, 77, 48, 1, "down"),
+        ("cross_d40_b2", 80, 2, 64, 77, 48, 2, "mid"),
+        ("cross_big", 16, 2, 1056, 77, 24, 1, "down"),  # N > 32^2: not stored
+        ("self_d16", 32, 2, 64, None, 32, 1, "mid"),
+        ("self_d40", 80, 2, 256, None, 80, 1, "up"),
+    ]
+    arrs = {}
+    meta = []
+    for si, (name, C, heads, N, ctx_len, ctx_dim, B, place) in enumerate(specs):
+        seed = 600 + 10 * si
+        attn = DuckAttention(C, heads, ctx_dim, seed=0)
+        with torch.no_grad():  # weights from the integer-hash generator: rebuilt by the tests
+            for pi, (pn, p) in enumerate(attn.named_parameters()):
+                w = hashrand.normalish(tuple(p.shape), seed + 1 + pi) * np.float32(1.5 / math.sqrt(p.shape[-1]))
+                p.copy_(torch.from_numpy(w))
+        store = ptp.AttentionStore()
+        store.num_att_layers = 1
+        proc = ptp.AttendExciteCrossAttnProcessor(attnstore=store, place_in_unet=place)
+        x = torch.from_numpy(hashrand.normalish((B, N, C), seed)).requires_grad_(True)
+        ctx = None if ctx_len is None else torch.from_numpy(hashrand.normalish((B, ctx_len, ctx_dim), seed + 7))
+        out = proc(attn, x, encoder_hidden_states=ctx)
+        key = f"{place}_{'cross' if ctx_len is not None else 'self'}"
+        stored = store.attention_store[key]
+        R1 = torch.from_numpy(hashrand.normalish(tuple(out.shape), seed + 8))
+        scal = (out * R1).sum()
+        if stored:
+            P = stored[0]
+            R2 = torch.from_numpy(hashrand.normalish(tuple(P.shape), seed + 9))
+            scal = scal + (P * R2).sum()
+            arrs[f"{name}.P"] = f32(P)
+        scal.backward()
+        arrs[f"{name}.out"] = f32(out)
+        arrs[f"{name}.dx"] = f32(x.grad)
+        arrs[f"{name}.dq"] = f32(attn.captured["q"].grad)
+        meta.append({"name": name, "C": C, "heads": heads, "N": N, "ctx_len": ctx_len, "ctx_dim": ctx_dim,
+                     "batch": B, "place": place, "scale": attn.scale, "stored": bool(stored), "seed": seed,
+                     "param_order": [pn for pn, _ in attn.named_parameters()],
+                     "store_keys": {k: len(v) for k, v in store.attention_store.items()},
+                     "cur_step": store.cur_step, "cur_att_layer": store.cur_att_layer})
+    np.savez_compressed(OUT / "g6_processor.npz", **arrs)
+    (OUT / "g6_processor.json").write_text(json.dumps(meta, indent=1))
+
+
+# ----------------------------------------------------------------------------- G7
+def g7_aggregate():
+    h = Harness()
+    setup_prompt(h, BASE_PROMPT)
+    arrs = {}
+    meta = []
+    for name, B, heads in (("b1", 1, 8), ("b2", 2, 4)):
+        store = ptp.AttentionStore()
+        layout = [("down", True, 1024), ("down", True, 256), ("down", True, 256), ("down", False, 256),
+                  ("mid", True, 64), ("up", True, 256), ("up", True, 256), ("up", True, 256), ("up", True, 1024),
+                  ("up", False, 64), ("down", True, 4096)]
+        store.num_att_layers = len(layout)
+        for li, (place, is_cross, N) in enumerate(layout):
+            K = 77 if is_cross else N
+            # aggregation is linear: positive hash-uniform inputs are as good as real softmax rows
+            P = torch.from_numpy(hashrand.uniform((B * heads, N, K), 700 + 20 * B + li))
+            store(P, is_cross, place)
+        for res, is_cross, where in ((16, True, ("up", "down", "mid")), (16, True, ("up",)), (8, True, ("up", "down", "mid")),
+                                     (32, True, ("down", "up")), (16, False, ("up", "down", "mid"))):
+            A = ptp.aggregate_attention(store, res, where, is_cross, 0)
+            tag = f"{name}.agg_r{res}_{'c' if is_cross else 's'}_{'-'.join(where)}"
+            arrs[tag] = f32(A)
+        meta.append({"name": name, "batch": B, "heads": heads, "seed_base": 700 + 20 * B,
+                     "layout": [[p, c, n] for p, c, n in layout],
+                     "store_keys": {k: len(v) for k, v in store.attention_store.items()}})
+    np.savez_compressed(OUT / "g7_aggregate.npz", **arrs)
+    (OUT / "g7_aggregate.json").write_text(json.dumps(meta, indent=1))
+
+
+# ----------------------------------------------------------------------------- G8
+def g8_update():
+    h = Harness()
+    setup_prompt(h, BASE_PROMPT)
+    g = torch.Generator().manual_seed(88)
+    lat = torch.randn(1, 4, 8, 8, generator=g).requires_grad_(True)
+    w = torch.randn(1, 4, 8, 8, generator=g)
+    loss = (torch.sin(lat) * w).sum().reshape(1) * 0.01
+    step = 20 * math.sqrt(0.75)
+    new = pga.GuidedAttention._update_latent(lat, loss, step)
+    np.savez(OUT / "g8_update_latent.npz", latents=f32(lat), w=f32(w), step=np.float64(step), out=f32(new),
+             grad=f32(torch.autograd.grad(loss, [lat])[0]))
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(1)  # deterministic reductions
+    g1_gaussian()
+    g2_parse()
+    g3_masks()
+    g4_loss()
+    g5_threshold()
+    g6_processor()
+    g7_aggregate()
+    g8_update()
+    for p in sorted(OUT.glob("g*")):
+        print(f"{p.name:32s} {p.stat().st_size:9d} B")
+
+
+if __name__ == "__main__":
+    main()
