@@ -1,0 +1,25 @@
+# Builds libga_hip.so (gfx950 kernels + C ABI) in-tree.  hipcc cross-compiles without a GPU.
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := guided-attention_amd/csrc
+SRCS    := $(wildcard $(CSRC)/*.hip)
+OBJS    := $(SRCS:.hip=.o)
+LIB     := guided-attention_amd/libga_hip.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+
+all: $(LIB) oracle
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/ga_common.h include/ga_hip.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(OBJS) $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,113 @@
+// Shared device helpers for the gfx950 kernels of libga_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ga_hip.h"
+
+namespace ga {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct bf16_t {
+  uint16_t bits;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+  return __builtin_bit_cast(uint16_t, h);
+}
+
+// Per-dtype traits.  `frag` = 4 consecutive k-elements of an MFMA operand held by one lane.
+template <typename T>
+struct Traits;
+
+template <>
+struct Traits<_Float16> {
+  using elem = _Float16;
+  using frag = f16x4;
+  static constexpr int kDtype = GA_F16;
+  __device__ static __forceinline__ float to_f32(elem x) { return (float)x; }
+  __device__ static __forceinline__ elem from_f32(float x) { return (elem)x; }
+  __device__ static __forceinline__ elem zero() { return (elem)0.0f; }
+  // acc += A(16 x 16k) * B(16k x 16); lane (c = lane&15, g = lane>>4) supplies k = 4g..4g+3 of both
+  __device__ static __forceinline__ f32x4 mma16(frag a, frag b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc, 0, 0, 0);
+  }
+};
+
+template <>
+struct Traits<bf16_t> {
+  using elem = bf16_t;
+  struct frag {
+    bf16_t v[4];
+    __device__ __forceinline__ bf16_t& operator[](int i) { return v[i]; }
+    __device__ __forceinline__ const bf16_t& operator[](int i) const { return v[i]; }
+  };
+  static constexpr int kDtype = GA_BF16;
+  __device__ static __forceinline__ float to_f32(elem x) { return bf16_to_f32(x.bits); }
+  __device__ static __forceinline__ elem from_f32(float x) { return elem{f32_to_bf16(x)}; }
+  __device__ static __forceinline__ elem zero() { return elem{0}; }
+  __device__ static __forceinline__ f32x4 mma16(frag a, frag b, f32x4 acc) {
+    s16x4 av = {(short)a.v[0].bits, (short)a.v[1].bits, (short)a.v[2].bits, (short)a.v[3].bits};
+    s16x4 bv = {(short)b.v[0].bits, (short)b.v[1].bits, (short)b.v[2].bits, (short)b.v[3].bits};
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc, 0, 0, 0);
+  }
+};
+
+template <>
+struct Traits<float> {
+  using elem = float;
+  using frag = f32x4;
+  static constexpr int kDtype = GA_F32;
+  __device__ static __forceinline__ float to_f32(elem x) { return x; }
+  __device__ static __forceinline__ elem from_f32(float x) { return x; }
+  __device__ static __forceinline__ elem zero() { return 0.0f; }
+  // exact-f32 MFMA (v_mfma_f32_16x16x4_f32): step j contracts k = {4g + j}, g = 0..3
+  __device__ static __forceinline__ f32x4 mma16(frag a, frag b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+    return acc;
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ typename Traits<T>::frag zero_frag() {
+  typename Traits<T>::frag f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = Traits<T>::zero();
+  return f;
+}
+
+// load 4 consecutive elements (8 B for 16-bit types, 16 B for f32); p must be 8/16-byte aligned
+template <typename T>
+__device__ __forceinline__ typename Traits<T>::frag load_frag(const T* p) {
+  return *reinterpret_cast<const typename Traits<T>::frag*>(p);
+}
+template <typename T>
+__device__ __forceinline__ void store_frag(T* p, typename Traits<T>::frag f) {
+  *reinterpret_cast<typename Traits<T>::frag*>(p) = f;
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+inline int check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? GA_OK : GA_ERR_LAUNCH;
+}
+
+}  // namespace ga

@@ -1,0 +1,408 @@
+// K3+K4: the Gaussian-smoothed bounding-box loss over the aggregated maps A (res, res, Kt), forward
+// and analytic backward.  Replaces the reference's per-pixel Python loops
+// (pipeline_guided_attention.py:201-296,359-451; utils/helpers.py:164-173,215-277;
+// utils/gaussian_smoothing.py:21-71).
+//
+// The whole problem is 16*16*77 floats (79 KB): it is launch-latency bound, not bandwidth bound, so
+// it runs as ONE 256-thread workgroup that keeps every intermediate in LDS, walks the guided tokens
+// sequentially (deterministic reductions, no atomics) and touches HBM once per input element.
+//
+//   S[p][j]  = softmax_j(100 * A[p][first + j]),  j in [0, last-first)
+//   per guided token k:  M = S[:, k] -> M' = reflect-pad Gaussian smoothing -> s = sum M', Pn = M'/s
+//       col = sum (j+.5) Pn, row = sum (i+.5) Pn, inside = 1 - sum_in Pn, outside = sum_out Pn
+//       item = w_in*inside + 3*w_out*outside + w_c*(|col - res*cx| + 4|row - res*cy|)/(res-1)
+//   loss = sum_k weight_k * item_k
+// The reference hard-codes res = 16 ("16", "15."); res and res-1 are used here (identical at 16).
+#include "ga_common.h"
+
+using namespace ga;
+
+namespace {
+
+constexpr int kMaxTok = 32;
+constexpr int kMaxK = 7;
+constexpr int kThreads = 256;
+
+struct LossArgs {
+  const float* A;
+  int res, Kt, first, last, T;
+  int ksize, smooth;
+  float w_in, w_out3, w_c;
+  double shrink;
+  ga_token_t tok[kMaxTok];
+  float gw[kMaxK * kMaxK];
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+// helpers.py:164-173 inside_box at pixel centre (j+.5, i+.5); float64, same operation order as the
+// reference (each product / sum rounded separately: no FMA contraction)
+__device__ __forceinline__ bool inside_box(const ga_token_t& t, int res, double shrink, int i, int j) {
+  const double ratio = (double)res;  // Rect.of_size: float(new_size / size), size = 1
+  const double x = __dmul_rn(t.geom[0], ratio), y = __dmul_rn(t.geom[1], ratio);
+  const double w = __dmul_rn(t.geom[2], ratio), h = __dmul_rn(t.geom[3], ratio);
+  const double ox = __dmul_rn(shrink, w), oy = __dmul_rn(shrink, h);
+  const double cx = (double)j + 0.5, cy = (double)i + 0.5;
+  if (cx >= __dadd_rn(x, ox) && cx <= __dsub_rn(__dadd_rn(x, w), ox))
+    if (cy >= __dadd_rn(y, oy) && cy <= __dsub_rn(__dadd_rn(y, h), oy)) return true;
+  return false;
+}
+
+// block-wide sum of NV values per thread; result valid in every thread.  scratch: [4][NV] floats.
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = wave_reduce_sum(v[k]);
+  __syncthreads();  // scratch may still be read from a previous call
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) scratch[wave * NV + k] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = (scratch[k] + scratch[NV + k]) + (scratch[2 * NV + k] + scratch[3 * NV + k]);
+}
+
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_reduce_max(v);
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+}
+
+// per-pixel softmax statistics of 100*A over the text slice: row max and sum of exponentials
+__device__ __forceinline__ void pixel_softmax_stats(const LossArgs& a, float* mx, float* sm) {
+  const int npix = a.res * a.res;
+  for (int p = threadIdx.x; p < npix; p += kThreads) {
+    const float* row = a.A + (size_t)p * a.Kt;
+    float m = -INFINITY;
+    for (int c = a.first; c < a.last; ++c) m = fmaxf(m, row[c] * 100.0f);
+    float s = 0.f;
+    for (int c = a.first; c < a.last; ++c) s += expf(row[c] * 100.0f - m);
+    mx[p] = m;
+    sm[p] = s;
+  }
+}
+
+struct TokenStats {
+  float s, mxv, col, row, in, out;
+};
+
+// Forward of one token into LDS: M (raw map), Pn (smoothed, normalised).  Returns the reductions.
+__device__ __forceinline__ TokenStats token_forward(const LossArgs& a, const ga_token_t& tk, const float* mx,
+                                                    const float* sm, float* M, float* Pn, float* scratch) {
+  const int res = a.res, npix = res * res;
+  const int colA = a.first + tk.token - 1;  // pipeline:228 "index - 1" into the [first:last) slice
+  for (int p = threadIdx.x; p < npix; p += kThreads) M[p] = expf(a.A[(size_t)p * a.Kt + colA] * 100.0f - mx[p]) / sm[p];
+  __syncthreads();
+  const int pad = a.ksize >> 1;
+  float v2[2] = {0.f, 0.f};
+  float vmax = -INFINITY;
+  for (int p = threadIdx.x; p < npix; p += kThreads) {
+    float acc;
+    if (a.smooth) {
+      const int i = p / res, j = p - i * res;
+      acc = 0.f;
+      for (int u = 0; u < a.ksize; ++u) {
+        const int ii = reflect_idx(i + u - pad, res);
+        for (int v = 0; v < a.ksize; ++v) acc += a.gw[u * a.ksize + v] * M[ii * res + reflect_idx(j + v - pad, res)];
+      }
+    } else {
+      acc = M[p];
+    }
+    Pn[p] = acc;
+    v2[0] += acc;
+    vmax = fmaxf(vmax, acc);
+  }
+  block_sum<2>(v2, scratch);
+  TokenStats st;
+  st.s = v2[0];
+  st.mxv = block_max(vmax, scratch);
+  float v4[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int p = threadIdx.x; p < npix; p += kThreads) {
+    const int i = p / res, j = p - i * res;
+    const float pn = Pn[p] / st.s;
+    Pn[p] = pn;
+    v4[0] += ((float)j + 0.5f) * pn;
+    v4[1] += ((float)i + 0.5f) * pn;
+    if (tk.kind == GA_TOK_BOX) {
+      if (inside_box(tk, res, a.shrink, i, j))
+        v4[2] += pn;
+      else
+        v4[3] += pn;
+    }
+  }
+  block_sum<4>(v4, scratch);
+  st.col = v4[0];
+  st.row = v4[1];
+  st.in = v4[2];
+  st.out = v4[3];
+  return st;
+}
+
+struct TokenLoss {
+  float inside, outside, item, unscaled, dc, dr, w_in, w_out3, w_c;
+};
+
+__device__ __forceinline__ TokenLoss token_loss(const LossArgs& a, const ga_token_t& tk, const TokenStats& st) {
+  TokenLoss r;
+  const float res = (float)a.res;
+  float cx, cy;
+  if (tk.kind == GA_TOK_BOX) {  // helpers.py:26-27 Rect.center in float64, then used against fp32 tensors
+    cx = (float)(tk.geom[0] + tk.geom[2] / 2.0);
+    cy = (float)(tk.geom[1] + tk.geom[3] / 2.0);
+    r.inside = 1.0f - st.in;   // helpers.py:275
+    r.outside = st.out;        // helpers.py:276
+    r.w_in = a.w_in;
+    r.w_out3 = a.w_out3;
+    r.w_c = a.w_c > 0.f ? a.w_c : 0.f;
+  } else {
+    cx = (float)tk.geom[0];
+    cy = (float)tk.geom[1];
+    r.inside = r.outside = 0.f;
+    r.w_in = r.w_out3 = 0.f;
+    r.w_c = 1.0f;
+  }
+  r.dc = st.col - cx * res;
+  r.dr = st.row - cy * res;
+  const float centering = fabsf(r.dc) / (res - 1.0f) + 4.0f * fabsf(r.dr) / (res - 1.0f);  // pipeline:391-395
+  if (tk.kind == GA_TOK_BOX) {
+    r.item = r.w_in * r.inside + r.w_out3 * r.outside + r.w_c * centering;  // pipeline:423-434
+    r.unscaled = r.inside + r.outside;
+  } else {
+    r.item = r.unscaled = centering;  // pipeline:409-414
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(kThreads) void smooth_loss_fwd_kernel(LossArgs a, float* __restrict__ terms,
+                                                                   float* __restrict__ loss) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int npix = a.res * a.res;
+  float* mx = lds;
+  float* sm = mx + npix;
+  float* M = sm + npix;
+  float* Pn = M + npix;
+  float* scratch = Pn + npix;  // 16 floats
+  pixel_softmax_stats(a, mx, sm);
+  __syncthreads();
+  float total = 0.f;
+  for (int t = 0; t < a.T; ++t) {
+    const ga_token_t& tk = a.tok[t];
+    const TokenStats st = token_forward(a, tk, mx, sm, M, Pn, scratch);
+    const TokenLoss tl = token_loss(a, tk, st);
+    total += tk.weight * tl.item;
+    if (threadIdx.x == 0) {
+      float* o = terms + t * GA_TERMS;
+      o[0] = st.mxv;
+      o[1] = st.col;
+      o[2] = st.row;
+      o[3] = tl.inside;
+      o[4] = tl.outside;
+      o[5] = tl.item;
+      o[6] = tl.unscaled;
+      o[7] = st.s;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = total;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, const float* __restrict__ dloss,
+                                                                   float* __restrict__ dA, T* __restrict__ dPb,
+                                                                   float bcast_scale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int res = a.res, npix = res * res;
+  float* mx = lds;
+  float* sm = mx + npix;
+  float* M = sm + npix;
+  float* Pn = M + npix;
+  float* G = Pn + npix;         // dItem/dM' per pixel
+  float* dot = G + npix;        // sum_k dS[p][k] S[p][k]
+  float* scratch = dot + npix;  // 16 floats
+  int* colmap = reinterpret_cast<int*>(scratch + 16);  // [Kt]: guided-token slot of column c, or -1
+  float* dS = reinterpret_cast<float*>(colmap + ((a.Kt + 3) & ~3));  // [T][npix]
+
+  pixel_softmax_stats(a, mx, sm);
+  for (int c = threadIdx.x; c < a.Kt; c += kThreads) colmap[c] = -1;
+  __syncthreads();
+  const int pad = a.ksize >> 1;
+  const float rm1 = (float)res - 1.0f;
+  for (int t = 0; t < a.T; ++t) {
+    const ga_token_t& tk = a.tok[t];
+    const TokenStats st = token_forward(a, tk, mx, sm, M, Pn, scratch);
+    const TokenLoss tl = token_loss(a, tk, st);
+    if (threadIdx.x == 0) colmap[a.first + tk.token - 1] = t;
+    const float sgc = tl.dc > 0.f ? 1.f : (tl.dc < 0.f ? -1.f : 0.f);
+    const float sgr = tl.dr > 0.f ? 1.f : (tl.dr < 0.f ? -1.f : 0.f);
+    float gd[1] = {0.f};
+    for (int p = threadIdx.x; p < npix; p += kThreads) {
+      const int i = p / res, j = p - i * res;
+      float g = tl.w_c * (sgc / rm1 * ((float)j + 0.5f) + 4.0f * sgr / rm1 * ((float)i + 0.5f));
+      if (tk.kind == GA_TOK_BOX) g += inside_box(tk, res, a.shrink, i, j) ? -tl.w_in : tl.w_out3;
+      G[p] = g;
+      gd[0] += g * Pn[p];
+    }
+    block_sum<1>(gd, scratch);
+    for (int p = threadIdx.x; p < npix; p += kThreads) G[p] = (G[p] - gd[0]) / st.s;  // through Pn = M'/sum(M')
+    __syncthreads();
+    // adjoint of reflect-pad + correlation, as a gather (deterministic): dM[a][b] = sum over (i,u),(j,v)
+    // with reflect(i+u-pad) == a and reflect(j+v-pad) == b of gw[u][v] * G[i][j]
+    float* dSt = dS + (size_t)t * npix;
+    for (int p = threadIdx.x; p < npix; p += kThreads) {
+      float acc;
+      if (a.smooth) {
+        const int ai = p / res, bj = p - ai * res;
+        acc = 0.f;
+        for (int i = max(ai - pad, 0); i <= min(ai + pad, res - 1); ++i)
+          for (int u = 0; u < a.ksize; ++u) {
+            if (reflect_idx(i + u - pad, res) != ai) continue;
+            for (int j = max(bj - pad, 0); j <= min(bj + pad, res - 1); ++j)
+              for (int v = 0; v < a.ksize; ++v)
+                if (reflect_idx(j + v - pad, res) == bj) acc += a.gw[u * a.ksize + v] * G[i * res + j];
+          }
+      } else {
+        acc = G[p];
+      }
+      dSt[p] = tk.weight * acc;
+    }
+    __syncthreads();
+  }
+  // softmax backward: dA[p][c] = 100 * S[p][c] * (dS[p][c] - sum_k dS[p][k] S[p][k]) on the text slice
+  for (int p = threadIdx.x; p < npix; p += kThreads) {
+    float d = 0.f;
+    for (int t = 0; t < a.T; ++t) {
+      const int colA = a.first + a.tok[t].token - 1;
+      d += dS[(size_t)t * npix + p] * (expf(a.A[(size_t)p * a.Kt + colA] * 100.0f - mx[p]) / sm[p]);
+    }
+    dot[p] = d;
+  }
+  __syncthreads();
+  const float dl = dloss ? dloss[0] : 1.0f;
+  const int total = npix * a.Kt;
+  for (int e = threadIdx.x; e < total; e += kThreads) {
+    const int p = e / a.Kt, c = e - p * a.Kt;
+    float g = 0.f;
+    if (c >= a.first && c < a.last) {
+      const float S = expf(a.A[e] * 100.0f - mx[p]) / sm[p];
+      const int t = colmap[c];
+      g = dl * 100.0f * S * ((t >= 0 ? dS[(size_t)t * npix + p] : 0.f) - dot[p]);
+    }
+    dA[e] = g;
+    if (dPb) dPb[e] = Traits<T>::from_f32(g * bcast_scale);
+  }
+}
+
+size_t fwd_lds(int npix) { return sizeof(float) * (4 * (size_t)npix + 16); }
+size_t bwd_lds(int npix, int Kt, int T) {
+  return sizeof(float) * (6 * (size_t)npix + 16 + ((Kt + 3) & ~3) + (size_t)T * npix);
+}
+
+int fill_args(LossArgs& a, const float* A, int res, int Kt, int first, int last, const ga_token_t* tokens, int T,
+              const ga_loss_params_t* hp) {
+  if (!A || !tokens || !hp) return GA_ERR_NULL;
+  if (res < 2 || res > 64 || Kt < 2 || T < 1 || T > kMaxTok) return GA_ERR_SHAPE;
+  if (first < 0 || last > Kt || last - first < 1) return GA_ERR_SHAPE;
+  if (hp->smooth && (hp->ksize < 1 || hp->ksize > kMaxK || (hp->ksize & 1) == 0 || hp->ksize / 2 >= res))
+    return GA_ERR_SHAPE;
+  for (int t = 0; t < T; ++t) {
+    const int col = first + tokens[t].token - 1;
+    if (col < first || col >= last) return GA_ERR_SHAPE;
+    if (tokens[t].kind != GA_TOK_BOX && tokens[t].kind != GA_TOK_COOR) return GA_ERR_UNSUPPORTED;
+    a.tok[t] = tokens[t];
+  }
+  a.A = A;
+  a.res = res;
+  a.Kt = Kt;
+  a.first = first;
+  a.last = last;
+  a.T = T;
+  a.ksize = hp->smooth ? hp->ksize : 1;
+  a.smooth = hp->smooth ? 1 : 0;
+  a.w_in = hp->inside_scale;
+  a.w_out3 = hp->outside_scale * 3.0f;
+  a.w_c = hp->center_weight;
+  a.shrink = hp->shrink;
+  if (a.smooth) {
+    int rc = ga_gaussian_weights(hp->ksize, hp->sigma, a.gw);
+    if (rc != GA_OK) return rc;
+  }
+  return GA_OK;
+}
+
+}  // namespace
+
+extern "C" int ga_gaussian_weights(int ksize, float sigma, float* w) {
+  if (!w) return GA_ERR_NULL;
+  if (ksize < 1 || ksize > kMaxK || !(sigma > 0.f)) return GA_ERR_SHAPE;
+  // utils/gaussian_smoothing.py:30-43 in fp32: per dimension 1/(std*sqrt(2*pi)) * exp(-((x-mean)/(2*std))^2),
+  // product over the two dimensions, then divided by the sum
+  float g1[kMaxK];
+  const float mean = (float)((ksize - 1) / 2.0);
+  const float norm = (float)(1.0 / ((double)sigma * 2.5066282746310002));
+  for (int i = 0; i < ksize; ++i) {
+    const float z = ((float)i - mean) / (2.0f * sigma);
+    g1[i] = norm * expf(-(z * z));
+  }
+  float sum = 0.f;
+  for (int i = 0; i < ksize; ++i)
+    for (int j = 0; j < ksize; ++j) {
+      w[i * ksize + j] = g1[i] * g1[j];
+      sum += w[i * ksize + j];
+    }
+  for (int i = 0; i < ksize * ksize; ++i) w[i] /= sum;
+  return GA_OK;
+}
+
+extern "C" int ga_smooth_loss_fwd(const float* A, int res, int Kt, int first, int last, const ga_token_t* tokens, int T,
+                                  const ga_loss_params_t* hp, float* terms, float* loss, ga_stream_t stream) {
+  if (!terms || !loss) return GA_ERR_NULL;
+  LossArgs a;
+  int rc = fill_args(a, A, res, Kt, first, last, tokens, T, hp);
+  if (rc != GA_OK) return rc;
+  const size_t lds = fwd_lds(res * res);
+  if (lds > 150 * 1024) return GA_ERR_SHAPE;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(smooth_loss_fwd_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GA_ERR_LAUNCH;
+  hipLaunchKernelGGL(smooth_loss_fwd_kernel, dim3(1), dim3(kThreads), lds, static_cast<hipStream_t>(stream), a, terms,
+                     loss);
+  return check_launch();
+}
+
+template <typename T>
+static int launch_loss_bwd(const LossArgs& a, const float* dloss, float* dA, void* dPb, float bs, size_t lds,
+                           hipStream_t s) {
+  auto k = smooth_loss_bwd_kernel<T>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GA_ERR_LAUNCH;
+  hipLaunchKernelGGL(k, dim3(1), dim3(kThreads), lds, s, a, dloss, dA, (T*)dPb, bs);
+  return check_launch();
+}
+
+extern "C" int ga_smooth_loss_bwd(const float* A, int res, int Kt, int first, int last, const ga_token_t* tokens, int T,
+                                  const ga_loss_params_t* hp, const float* dloss, float* dA, void* dP_bcast,
+                                  float bcast_scale, int dtype, ga_stream_t stream) {
+  if (!dA) return GA_ERR_NULL;
+  LossArgs a;
+  int rc = fill_args(a, A, res, Kt, first, last, tokens, T, hp);
+  if (rc != GA_OK) return rc;
+  const size_t lds = bwd_lds(res * res, Kt, T);
+  if (lds > 150 * 1024) return GA_ERR_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case GA_F16:
+      return launch_loss_bwd<_Float16>(a, dloss, dA, dP_bcast, bcast_scale, lds, s);
+    case GA_BF16:
+      return launch_loss_bwd<bf16_t>(a, dloss, dA, dP_bcast, bcast_scale, lds, s);
+    case GA_F32:
+      return launch_loss_bwd<float>(a, dloss, dA, dP_bcast, bcast_scale, lds, s);
+    default:
+      return GA_ERR_DTYPE;
+  }
+}

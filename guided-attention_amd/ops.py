@@ -1,0 +1,230 @@
+"""Python-side operators over the C ABI of libga_hip.so: thin argument marshalling plus the
+`torch.autograd.Function` glue that puts the HIP forward/backward kernels into the autograd graph
+the pipeline differentiates (reference: pipeline_guided_attention.py:466 autograd.grad(loss, latents)).
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from ._lib import GaError, check, dtype_code, load, require_cuda, stream_ptr
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+# --------------------------------------------------------------------------------------- K1
+def attn_capture_fwd(q, k, v, heads, scale, want_probs):
+    """q (B,N,C), k/v (B,Kt,C) projections -> (o (B,N,C), probs (B*heads,N,Kt) or None)."""
+    require_cuda(q, k, v)
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    B, N, C = q.shape
+    Kt = k.shape[1]
+    D = C // heads
+    o = torch.empty_like(q)
+    probs = torch.empty((B * heads, N, Kt), dtype=q.dtype, device=q.device) if want_probs else None
+    check(load().ga_attn_capture_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(probs), B, heads, N, Kt, D,
+                                     float(scale), dtype_code(q), stream_ptr()), "ga_attn_capture_fwd")
+    return o, probs
+
+
+def attn_capture_bwd(q, k, v, d_o, d_probs, heads, scale):
+    """-> dq (B,N,C).  d_probs: None, a dense (B*heads,N,Kt) tensor, or an expanded (stride-0 over the
+    head-map axis) view of one (N,Kt) map — passed to the kernel as strides, never materialised."""
+    require_cuda(q, k, v, d_o, d_probs)
+    B, N, C = q.shape
+    Kt = k.shape[1]
+    d_o = d_o.contiguous()
+    sb = sn = 0
+    if d_probs is not None:
+        if d_probs.dtype != q.dtype:
+            d_probs = d_probs.to(q.dtype)
+        if d_probs.stride(2) != 1 or (d_probs.stride(0) != 0 and not d_probs.is_contiguous()):
+            d_probs = d_probs.contiguous()
+        sb, sn = d_probs.stride(0), d_probs.stride(1)
+    dq = torch.empty_like(q)
+    check(load().ga_attn_capture_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(d_o), _ptr(d_probs), sb, sn, _ptr(dq), None, None,
+                                     B, heads, N, Kt, C // heads, float(scale), dtype_code(q), stream_ptr()),
+          "ga_attn_capture_bwd")
+    return dq
+
+
+class AttnCapture(torch.autograd.Function):
+    """softmax(scale q k^T) v with the probabilities as a second, differentiable output."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale, want_probs):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        o, probs = attn_capture_fwd(q, k, v, heads, scale, want_probs)
+        ctx.save_for_backward(q, k, v)
+        ctx.heads, ctx.scale = heads, scale
+        if probs is None:
+            probs = q.new_empty(0)
+            ctx.mark_non_differentiable(probs)
+        return o, probs
+
+    @staticmethod
+    def backward(ctx, d_o, d_probs):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise GaError("gradients w.r.t. the attention context (K/V) are not part of the guided-attention "
+                          "path (only the latents are differentiated); freeze the UNet parameters")
+        q, k, v = ctx.saved_tensors
+        if d_probs is not None and d_probs.numel() == 0:
+            d_probs = None
+        if d_o is None:
+            d_o = torch.zeros_like(q)
+        dq = attn_capture_bwd(q, k, v, d_o, d_probs, ctx.heads, ctx.scale)
+        return dq, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------- K2
+def aggregate_maps(maps):
+    """maps: list of (heads_i, npix, Kt) tensors of one dtype -> A (npix, Kt) f32."""
+    require_cuda(*maps)
+    maps = [m.contiguous() for m in maps]
+    npix, Kt = maps[0].shape[1], maps[0].shape[2]
+    n = len(maps)
+    ptrs = (ctypes.c_void_p * n)(*[m.data_ptr() for m in maps])
+    heads = (ctypes.c_int * n)(*[m.shape[0] for m in maps])
+    A = torch.empty((npix, Kt), dtype=torch.float32, device=maps[0].device)
+    check(load().ga_aggregate_maps(ptrs, heads, n, npix, Kt, _ptr(A), dtype_code(maps[0]), stream_ptr()),
+          "ga_aggregate_maps")
+    return A
+
+
+class AggregateMaps(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *maps):
+        ctx.shapes = [m.shape for m in maps]
+        ctx.dtype = maps[0].dtype
+        return aggregate_maps(list(maps))
+
+    @staticmethod
+    def backward(ctx, dA):
+        total = sum(s[0] for s in ctx.shapes)
+        g = (dA * (1.0 / total)).to(ctx.dtype)
+        # one (npix, Kt) map broadcast over every head-map: handed on as a stride-0 view
+        return tuple(g.unsqueeze(0).expand(s) for s in ctx.shapes)
+
+
+# --------------------------------------------------------------------------------------- K3+K4
+class LossPlan:
+    """Host-side descriptor of the guided tokens and hyper-parameters (what config.token_dict and
+    shared_state.curHyperParams hold in the reference), marshalled once into the C structs."""
+
+    def __init__(self, entries, hyper, smooth=True, sigma=0.5, kernel_size=3, sub_prompt_avg_within=False):
+        """entries: list of dict(index, kind 'BOX'|'COOR', geom, subprompt)."""
+        self.entries = list(entries)
+        T = len(self.entries)
+        if T == 0:
+            raise GaError("no guided tokens")
+        counts = OrderedDict()
+        for e in self.entries:
+            counts[e["subprompt"]] = counts.get(e["subprompt"], 0) + 1
+        self.weights = [1.0 / counts[e["subprompt"]] if sub_prompt_avg_within else 1.0 for e in self.entries]
+        self.tokens = (_lib.ga_token_t * T)()
+        for i, (e, w) in enumerate(zip(self.entries, self.weights)):
+            tk = self.tokens[i]
+            tk.token = int(e["index"])
+            tk.kind = _lib.GA_TOK_BOX if e["kind"] == "BOX" else _lib.GA_TOK_COOR
+            geom = list(e["geom"]) + [0.0] * (4 - len(e["geom"]))
+            for j in range(4):
+                tk.geom[j] = float(geom[j])
+            tk.weight = w
+        if hyper.get("strict", False):
+            raise GaError("strict bounding-box loss is not implemented (off by default in the reference)")
+        self.params = _lib.ga_loss_params_t()
+        self.params.inside_scale = hyper["inside_loss_scale"]
+        self.params.outside_scale = hyper["outside_loss_scale"]
+        self.params.center_weight = hyper.get("bb_center_weight", .05)
+        self.params.sigma = sigma
+        self.params.shrink = hyper["shrink_factor"]
+        self.params.ksize = kernel_size
+        self.params.smooth = 1 if smooth else 0
+        self.T = T
+
+
+def smooth_loss_fwd(A, res, first, last, plan):
+    require_cuda(A)
+    if A.dtype != torch.float32:
+        raise GaError("aggregated maps must be float32")
+    A = A.contiguous()
+    Kt = A.shape[-1]
+    terms = torch.empty((plan.T, _lib.GA_TERMS), dtype=torch.float32, device=A.device)
+    loss = torch.empty((1,), dtype=torch.float32, device=A.device)
+    check(load().ga_smooth_loss_fwd(_ptr(A), res, Kt, first, last, plan.tokens, plan.T, ctypes.byref(plan.params),
+                                    _ptr(terms), _ptr(loss), stream_ptr()), "ga_smooth_loss_fwd")
+    return terms, loss
+
+
+def smooth_loss_bwd(A, res, first, last, plan, dloss=None, bcast_dtype=None, bcast_scale=1.0):
+    require_cuda(A, dloss)
+    A = A.contiguous()
+    Kt = A.shape[-1]
+    dA = torch.empty_like(A)
+    dPb = torch.empty(A.shape, dtype=bcast_dtype, device=A.device) if bcast_dtype is not None else None
+    code = _lib.DTYPE_CODE[bcast_dtype] if bcast_dtype is not None else _lib.GA_F32
+    if dloss is not None:
+        dloss = dloss.to(torch.float32).contiguous()
+    check(load().ga_smooth_loss_bwd(_ptr(A), res, Kt, first, last, plan.tokens, plan.T, ctypes.byref(plan.params),
+                                    _ptr(dloss), _ptr(dA), _ptr(dPb), float(bcast_scale), code, stream_ptr()),
+          "ga_smooth_loss_bwd")
+    return dA, dPb
+
+
+class SmoothLoss(torch.autograd.Function):
+    """A (res*res, Kt) f32 -> (terms (T,8), loss (1,)).  Only `loss` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, A, res, first, last, plan):
+        terms, loss = smooth_loss_fwd(A, res, first, last, plan)
+        ctx.save_for_backward(A)
+        ctx.args = (res, first, last, plan)
+        ctx.mark_non_differentiable(terms)
+        return terms, loss
+
+    @staticmethod
+    def backward(ctx, _dterms, dloss):
+        (A,) = ctx.saved_tensors
+        res, first, last, plan = ctx.args
+        dA, _ = smooth_loss_bwd(A, res, first, last, plan, dloss)
+        return dA, None, None, None, None
+
+
+def gaussian_weights(kernel_size, sigma):
+    w = (ctypes.c_float * (kernel_size * kernel_size))()
+    check(load().ga_gaussian_weights(kernel_size, float(sigma), w), "ga_gaussian_weights")
+    return torch.tensor(list(w), dtype=torch.float32).reshape(kernel_size, kernel_size)
+
+
+# --------------------------------------------------------------------------------------- K5 / K6 / DDIM
+def latent_axpy(latents, grad, step, want_absmean=False):
+    require_cuda(latents, grad)
+    latents, grad = latents.contiguous(), grad.contiguous().to(latents.dtype)
+    out = torch.empty_like(latents)
+    absmean = torch.empty((1,), dtype=torch.float32, device=latents.device) if want_absmean else None
+    check(load().ga_latent_axpy(_ptr(latents), _ptr(grad), float(step), _ptr(out), _ptr(absmean), latents.numel(),
+                                dtype_code(latents), stream_ptr()), "ga_latent_axpy")
+    return out, absmean
+
+
+def latent_axpby(x, y, a, b):
+    require_cuda(x, y)
+    x, y = x.contiguous(), y.contiguous().to(x.dtype)
+    out = torch.empty_like(x)
+    check(load().ga_latent_axpby(_ptr(x), _ptr(y), float(a), float(b), _ptr(out), x.numel(), dtype_code(x),
+                                 stream_ptr()), "ga_latent_axpby")
+    return out
+
+
+def cfg_ddim_step(eps_uncond, eps_text, guidance, x, alpha_t, alpha_prev, want_x0=False):
+    require_cuda(eps_uncond, eps_text, x)
+    eps_uncond, eps_text, x = eps_uncond.contiguous(), eps_text.contiguous(), x.contiguous()
+    prev = torch.empty_like(x)
+    x0 = torch.empty_like(x) if want_x0 else None
+    check(load().ga_cfg_ddim_step(_ptr(eps_uncond), _ptr(eps_text), float(guidance), _ptr(x), float(alpha_t),
+                                  float(alpha_prev), _ptr(prev), _ptr(x0), x.numel(), dtype_code(x), stream_ptr()),
+          "ga_cfg_ddim_step")
+    return prev, x0

@@ -1,0 +1,156 @@
+/* ga_hip.h — C ABI of libga_hip.so: the MI355X (gfx950) kernels behind the guided-attention hot path.
+ *
+ * The reference (jackBonadies/Guided-Attention) is pure Python and has no FFI: the path sits behind
+ * three Python protocols (attention-processor, controller/AttentionStore, pipeline methods).  This
+ * header is the C boundary a maintainer would bind underneath those protocols (ctypes stub in
+ * INTEGRATION.md).  Each entry point names the reference code it replaces (file:line relative to
+ * the reference checkout).
+ *
+ * Conventions (all entry points):
+ *   - return 0 (GA_OK) or a negative ga_status; never throw, never allocate, never synchronise;
+ *   - work is enqueued on `stream` (a hipStream_t; NULL = the default stream);
+ *   - every tensor pointer is a DEVICE pointer to contiguous memory in the stated layout, owned by
+ *     the caller; small descriptor structs (`ga_token_t`, `ga_loss_params_t`, pointer lists) are HOST
+ *     memory and are consumed before the call returns;
+ *   - dtype is a ga_dtype; "T" below means that element type.  Accumulation is always f32.
+ */
+#ifndef GA_HIP_H
+#define GA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GA_VERSION 100 /* 0.1.0 */
+
+typedef void* ga_stream_t; /* hipStream_t */
+
+typedef enum { GA_F16 = 0, GA_BF16 = 1, GA_F32 = 2 } ga_dtype;
+
+typedef enum {
+  GA_OK = 0,
+  GA_ERR_NULL = -1,        /* a required pointer is NULL */
+  GA_ERR_SHAPE = -2,       /* a size is out of the supported range */
+  GA_ERR_DTYPE = -3,       /* unknown dtype */
+  GA_ERR_ALIGN = -4,       /* a pointer is not 16-byte aligned / head_dim not a multiple of 8 */
+  GA_ERR_LAUNCH = -5,      /* hipLaunchKernel reported an error */
+  GA_ERR_UNSUPPORTED = -6  /* valid request this build does not implement */
+} ga_status;
+
+int ga_version(void);
+const char* ga_strerror(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  attention-store capture, forward.
+ * Replaces utils/ptp_utils.py:77-86 (head split, get_attention_scores, store, bmm(P,V), head merge)
+ * and utils/ptp_utils.py:97-146 (scores = scale*Q K^T, softmax over keys, cast back).
+ *
+ *   Q  [B][N][H][D]  T   the to_q projection as it comes out of the linear layer (no head transpose)
+ *   K,V[B][Kt][H][D] T   the to_k / to_v projections of the text (or any) context, Kt <= 128
+ *   O  [B][N][H][D]  T   softmax(scale Q K^T) V, already in "batch_to_head_dim" layout
+ *   P  [B*H][N][Kt]  T   the attention probabilities exactly as the reference hands them to the
+ *                        controller (head-major batch); NULL = do not materialise them
+ * D must be a multiple of 8 and <= 256.
+ */
+int ga_attn_capture_fwd(const void* Q, const void* K, const void* V, void* O, void* P,
+                        int B, int H, int N, int Kt, int D, float scale, int dtype, ga_stream_t stream);
+
+/* K1 backward (the reference relies on torch autograd through baddbmm/softmax/bmm).
+ *   dO [B][N][H][D] T ; dP (optional) direct gradient on P, element (bh, n, k) at
+ *   dP[bh*dP_stride_bh + n*dP_stride_n + k] (strides in elements; dP_stride_bh = 0 broadcasts one
+ *   [N][Kt] map over all B*H head-maps — the shape dLoss/dA takes after aggregate_attention);
+ *   dQ [B][N][H][D] T.   P is recomputed from Q,K (bit-identical to the forward).
+ *   dK/dV (gradients w.r.t. the context projections) are not needed on this path (the text
+ *   embedding carries no gradient: pipeline_guided_attention.py:466) and must be NULL.
+ */
+int ga_attn_capture_bwd(const void* Q, const void* K, const void* V, const void* dO,
+                        const void* dP, int64_t dP_stride_bh, int64_t dP_stride_n,
+                        void* dQ, void* dK, void* dV,
+                        int B, int H, int N, int Kt, int D, float scale, int dtype, ga_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  aggregate_attention (utils/ptp_utils.py:273-289, select = 0): the mean over every head-map of
+ * every stored tensor with npix pixels, summed in list order.
+ *   maps[i]  device pointer to [heads[i]][npix][Kt] T   (host array of n_maps pointers, n_maps <= 32)
+ *   A        [npix][Kt] f32
+ */
+int ga_aggregate_maps(const void* const* maps, const int* heads, int n_maps, int npix, int Kt,
+                      float* A, int dtype, ga_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3+K4  the Gaussian-smoothed box loss.
+ * Replaces pipeline_guided_attention.py:201-296 (_compute_max_attention_per_index),
+ * utils/gaussian_smoothing.py:21-71, utils/helpers.py:164-173,215-277 (inside_box,
+ * calculate_bounding_box_losses, non-strict) and pipeline_guided_attention.py:359-451
+ * (_compute_loss / get_centering_loss / group_losses_by_sumprompt).
+ */
+typedef enum { GA_TOK_COOR = 0, GA_TOK_BOX = 1 } ga_token_kind;
+
+typedef struct {
+  int32_t token;   /* position in the Kt-token prompt (BOS = 0), i.e. a key of config.token_dict */
+  int32_t kind;    /* ga_token_kind */
+  double geom[4];  /* BOX: x, y, width, height; COOR: x, y — fractions of the image (helpers.Rect size 1) */
+  float weight;    /* 1, or 1/len(sub-prompt) when sub_prompt_avg_within */
+  float _pad;
+} ga_token_t;
+
+typedef struct {
+  float inside_scale;   /* curHyperParams["inside_loss_scale"]            */
+  float outside_scale;  /* curHyperParams["outside_loss_scale"] (the x3 of pipeline:427 is applied inside) */
+  float center_weight;  /* curHyperParams.get("bb_center_weight", .05); <= 0 disables the term */
+  float sigma;          /* Gaussian sigma */
+  double shrink;        /* curHyperParams["shrink_factor"] */
+  int32_t ksize;        /* Gaussian kernel size (odd, <= 7; the reference only runs 3) */
+  int32_t smooth;       /* smooth_attentions */
+} ga_loss_params_t;
+
+#define GA_TERMS 8 /* per token: max, col, row, inside, outside, token_loss, unscaled, sum(M) */
+
+/*   A      [res*res][Kt] f32  aggregated maps (row-major pixels, token fastest)
+ *   first,last  text-token slice [first,last) that is re-softmaxed (x100): 1 and Kt-1, or the first
+ *          EOT index for SD-2.1 (pipeline:209-219)
+ *   terms  [T][GA_TERMS] f32, loss [1] f32 (sum over tokens of weight*token_loss)
+ * Limits: res <= 64, T <= 32, T*res*res <= 24576.
+ */
+int ga_smooth_loss_fwd(const float* A, int res, int Kt, int first, int last,
+                       const ga_token_t* tokens, int T, const ga_loss_params_t* hp,
+                       float* terms, float* loss, ga_stream_t stream);
+
+/* Backward of the above w.r.t. A (recomputed from A; nothing is saved by the forward).
+ *   dloss  [1] f32 device scalar multiplying the gradient, or NULL for 1
+ *   dA     [res*res][Kt] f32
+ *   dP_bcast (optional) [res*res][Kt] T = bcast_scale * dA, the map that ga_attn_capture_bwd
+ *          broadcasts over the head-maps (bcast_scale = 1 / number of aggregated head-maps)
+ */
+int ga_smooth_loss_bwd(const float* A, int res, int Kt, int first, int last,
+                       const ga_token_t* tokens, int T, const ga_loss_params_t* hp,
+                       const float* dloss, float* dA, void* dP_bcast, float bcast_scale, int dtype,
+                       ga_stream_t stream);
+
+/* Gaussian weights exactly as utils/gaussian_smoothing.py:21-47 builds them (host helper; w[ksize*ksize]). */
+int ga_gaussian_weights(int ksize, float sigma, float* w);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  latent update (pipeline_guided_attention.py:466-469): out = latents - step * grad, with the
+ * log line's mean(|grad|) (pipeline:467) fused when absmean != NULL ([1] f32).  out may alias latents.
+ */
+int ga_latent_axpy(const void* latents, const void* grad, float step, void* out, float* absmean,
+                   int64_t n, int dtype, ga_stream_t stream);
+
+/* K6  out = a*x + b*y (re-noise back to level t, pipeline_guided_attention.py:1048-1053). */
+int ga_latent_axpby(const void* x, const void* y, float a, float b, void* out, int64_t n, int dtype,
+                    ga_stream_t stream);
+
+/* Classifier-free-guidance combine + DDIM step (eta = 0), pipeline_guided_attention.py:1022-1029:
+ *   eps = eps_uncond + g*(eps_text - eps_uncond); x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t);
+ *   prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps.   x0_out may be NULL.  prev may alias x. */
+int ga_cfg_ddim_step(const void* eps_uncond, const void* eps_text, float guidance, const void* x,
+                     float alpha_t, float alpha_prev, void* prev, void* x0_out, int64_t n, int dtype,
+                     ga_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GA_HIP_H */

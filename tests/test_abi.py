@@ -1,0 +1,77 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/ga_hip.h declares,
+and its host-only entry points behave.  No kernels are launched here."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_npz
+
+HEADER = ROOT / "include" / "ga_hip.h"
+
+
+def declared_functions():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ga_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from guided_attention_amd import _lib
+    if not _lib.LIB_PATH.exists():
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def test_header_and_binding_agree():
+    from guided_attention_amd import _lib
+    assert declared_functions() == sorted(_lib.PROTOTYPES)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_functions()
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_version_and_strerror(lib):
+    m = re.search(r"#define GA_VERSION (\d+)", HEADER.read_text())
+    assert lib.ga_version() == int(m.group(1))
+    assert lib.ga_strerror(0) == b"ok"
+    assert b"NULL" in lib.ga_strerror(-1)
+    assert lib.ga_strerror(-999) == b"unknown status"
+
+
+def test_struct_layout_matches_header():
+    from guided_attention_amd import _lib
+    assert ctypes.sizeof(_lib.ga_token_t) == 48      # 2*int32 + 4*double + 2*float
+    assert ctypes.sizeof(_lib.ga_loss_params_t) == 32
+
+
+def test_gaussian_weights_host_entry(lib):
+    g = load_npz("g1_gaussian.npz")
+    for k, s in [(3, 0.5), (3, 1.0), (5, 1.0), (5, 0.75)]:
+        w = (ctypes.c_float * (k * k))()
+        assert lib.ga_gaussian_weights(k, s, w) == 0
+        np.testing.assert_allclose(np.array(w).reshape(k, k), g[f"k{k}_s{s}"], rtol=0, atol=2e-7)
+    assert lib.ga_gaussian_weights(9, 0.5, (ctypes.c_float * 81)()) == -2
+    assert lib.ga_gaussian_weights(3, 0.5, None) == -1
+
+
+def test_argument_validation_needs_no_gpu(lib):
+    # every entry point validates before touching the device: errors come back as codes
+    assert lib.ga_attn_capture_fwd(None, None, None, None, None, 1, 8, 256, 77, 160, 0.1, 0, None) == -1
+    assert lib.ga_latent_axpy(None, None, 1.0, None, None, 16, 0, None) == -1
+
+
+def test_product_refuses_cpu_tensors():
+    import torch
+    from guided_attention_amd import ops
+    with pytest.raises(ops.GaError):
+        ops.latent_axpy(torch.zeros(4), torch.zeros(4), 1.0)
+    with pytest.raises(ops.GaError):
+        ops.aggregate_maps([torch.zeros(2, 4, 4)])

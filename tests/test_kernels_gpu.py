@@ -1,0 +1,346 @@
+"""Parity of the HIP kernels (through the C ABI of libga_hip.so) with the CPU oracle and with the
+fixtures produced by the reference.  Needs an MI355X: run with `pytest -m gpu`.
+
+Tolerances (stated, per dtype): f32 kernels use exact-f32 MFMA / f32 VALU and are held to ~1e-5
+relative; f16 / bf16 kernels round their MFMA operands and outputs to 11 / 8 significant bits and are
+held to 2e-3 / 1.6e-2 of the tensor's max magnitude.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import hashrand
+from conftest import load_json, load_npz
+from oracle import attention as oattn
+from oracle import loss as oloss
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+TOL = {"f32": 2e-5, "f16": 2e-3, "bf16": 1.6e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from guided_attention_amd import ops as _ops
+    _ops.load()
+    return _ops
+
+
+def dev(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+def to_bh(t, H):  # (B,N,H*D) -> (B*H,N,D) float64 numpy (oracle layout)
+    B, N, C = t.shape
+    return t.double().cpu().reshape(B, N, H, C // H).permute(0, 2, 1, 3).reshape(B * H, N, C // H).numpy()
+
+
+def from_bh(a, B, H):  # (B*H,N,D) -> (B,N,H*D)
+    BH, N, D = a.shape
+    return a.reshape(B, H, N, D).transpose(0, 2, 1, 3).reshape(B, N, H * D)
+
+
+def close(got, ref, tol, what=""):
+    got = got.double().cpu().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(got - ref).max()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol:.1e} * {scale:.3e}"
+
+
+SHAPES = [  # B, H, N, Kt, D
+    (1, 8, 4096, 77, 40), (1, 8, 1024, 77, 80), (1, 8, 256, 77, 160), (1, 8, 64, 77, 160),  # SD-1.x layers
+    (2, 8, 256, 77, 160), (2, 8, 1024, 77, 80),                                              # CFG batch
+    (1, 5, 576, 77, 64), (1, 20, 144, 77, 64),                                               # SD-2.1 768^2 shapes
+    (1, 2, 50, 77, 16), (1, 3, 17, 5, 8), (1, 1, 16, 1, 8), (1, 2, 100, 80, 24),              # ragged / tiny
+    (1, 2, 64, 81, 32), (1, 2, 96, 128, 48),                                                  # 8-key-tile path
+]
+
+
+def make_qkv(B, H, N, Kt, D, dtype, seed, spread=1.0):
+    q = dev(hashrand.normalish((B, N, H * D), seed) * spread, dtype)
+    k = dev(hashrand.normalish((B, Kt, H * D), seed + 1) * spread, dtype)
+    v = dev(hashrand.normalish((B, Kt, H * D), seed + 2), dtype)
+    return q, k, v
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_attn_capture_fwd(ops, shape, dt):
+    B, H, N, Kt, D = shape
+    q, k, v = make_qkv(B, H, N, Kt, D, DT[dt], 100 + N + D)
+    scale = D ** -0.5
+    o, p = ops.attn_capture_fwd(q, k, v, H, scale, True)
+    o2, none = ops.attn_capture_fwd(q, k, v, H, scale, False)
+    assert none is None and torch.equal(o, o2)  # capture does not change O
+    Pref, Oref = oattn.capture_fwd_numpy(to_bh(q, H), to_bh(k, H), to_bh(v, H), scale)
+    assert p.shape == (B * H, N, Kt)
+    close(p, Pref, TOL[dt], "P")
+    close(o, from_bh(Oref, B, H), TOL[dt], "O")
+    rows = p.float().sum(-1)
+    assert (rows - 1).abs().max().item() < {"f32": 1e-5, "f16": 4e-3, "bf16": 3e-2}[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("mode", ["none", "dense", "bcast"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_attn_capture_bwd(ops, shape, mode, dt):
+    B, H, N, Kt, D = shape
+    q, k, v = make_qkv(B, H, N, Kt, D, DT[dt], 200 + N + D)
+    d_o = dev(hashrand.normalish((B, N, H * D), 300 + N), DT[dt])
+    scale = D ** -0.5
+    dp = dp_np = None
+    if mode == "dense":
+        dp = dev(hashrand.normalish((B * H, N, Kt), 400 + N), DT[dt])
+        dp_np = dp.double().cpu().numpy()
+    elif mode == "bcast":  # the shape of dLoss/dA: one (N,Kt) map shared by all head-maps, small values
+        m = dev(hashrand.normalish((N, Kt), 500 + N) * 3e-3, DT[dt])
+        dp = m.unsqueeze(0).expand(B * H, N, Kt)
+        dp_np = np.broadcast_to(m.double().cpu().numpy(), (B * H, N, Kt))
+    dq = ops.attn_capture_bwd(q, k, v, d_o, dp, H, scale)
+    dQ, _, _ = oattn.capture_bwd_numpy(to_bh(q, H), to_bh(k, H), to_bh(v, H), scale, to_bh(d_o, H), dp_np)
+    close(dq, from_bh(dQ, B, H), TOL[dt] * 2, "dQ")
+
+
+def test_attn_bwd_tiny_gradients_fp16(ops):
+    """The loss reaches Q through dS ~ 1e-5..1e-7: below fp16's normal range.  The per-row power-of-two
+    rescale must keep them (relative error vs fp64 stays at operand-rounding level)."""
+    B, H, N, Kt, D = 1, 8, 256, 77, 160
+    q, k, v = make_qkv(B, H, N, Kt, D, torch.float16, 901)
+    d_o = torch.zeros_like(q)
+    m = dev(hashrand.normalish((N, Kt), 902) * 1e-4, torch.float16)
+    dq = ops.attn_capture_bwd(q, k, v, d_o, m.unsqueeze(0).expand(B * H, N, Kt), H, D ** -0.5)
+    dQ, _, _ = oattn.capture_bwd_numpy(to_bh(q, H), to_bh(k, H), to_bh(v, H), D ** -0.5, to_bh(d_o, H),
+                                       np.broadcast_to(m.double().cpu().numpy(), (B * H, N, Kt)))
+    ref = from_bh(dQ, B, H)
+    assert np.abs(ref).max() < 1e-4
+    close(dq, ref, 6e-3, "dQ tiny")
+
+
+def test_attn_bwd_linear_in_upstream(ops):
+    """Size-independent property at the full SD-1.x size: the backward is linear in (dO, dP)."""
+    B, H, N, Kt, D = 1, 8, 4096, 77, 40
+    q, k, v = make_qkv(B, H, N, Kt, D, torch.float32, 77)
+    a = dev(hashrand.normalish((B, N, H * D), 78), torch.float32)
+    b = dev(hashrand.normalish((B, N, H * D), 79), torch.float32)
+    pa = dev(hashrand.normalish((B * H, N, Kt), 80), torch.float32)
+    pb = dev(hashrand.normalish((B * H, N, Kt), 81), torch.float32)
+    s = D ** -0.5
+    lhs = ops.attn_capture_bwd(q, k, v, 2 * a - 3 * b, 2 * pa - 3 * pb, H, s)
+    rhs = 2 * ops.attn_capture_bwd(q, k, v, a, pa, H, s) - 3 * ops.attn_capture_bwd(q, k, v, b, pb, H, s)
+    close(lhs, rhs.double().cpu().numpy(), 1e-4, "linearity")
+
+
+def test_attn_autograd_function(ops):
+    """AttnCapture inside torch autograd == torch's own autograd through baddbmm/softmax/bmm (fp32 on GPU)."""
+    B, H, N, Kt, D = 2, 4, 64, 77, 40
+    q, k, v = make_qkv(B, H, N, Kt, D, torch.float32, 55)
+    w1 = dev(hashrand.normalish((B, N, H * D), 56), torch.float32)
+    w2 = dev(hashrand.normalish((B * H, N, Kt), 57), torch.float32)
+    qa = q.clone().requires_grad_(True)
+    o, p = ops.AttnCapture.apply(qa, k, v, H, D ** -0.5, True)
+    ((o * w1).sum() + (p * w2).sum()).backward()
+    qb = q.clone().requires_grad_(True)
+    qh, kh, vh = (oattn.head_split(t, H) for t in (qb, k, v))
+    pr = torch.softmax(torch.bmm(qh, kh.transpose(1, 2)) * D ** -0.5, -1)
+    orf = oattn.head_merge(torch.bmm(pr, vh), H)
+    ((orf * w1).sum() + (pr * w2).sum()).backward()
+    close(o, orf.detach().double().cpu().numpy(), 2e-5, "O")
+    close(qa.grad, qb.grad.double().cpu().numpy(), 5e-5, "dq")
+
+
+def test_attn_errors(ops):
+    q, k, v = make_qkv(1, 2, 16, 77, 16, torch.float16, 1)
+    with pytest.raises(ops.GaError):
+        ops.attn_capture_fwd(q.cpu(), k.cpu(), v.cpu(), 2, 0.25, True)  # no CPU fallback
+    with pytest.raises(ops.GaError):
+        ops.attn_capture_fwd(q, make_qkv(1, 2, 16, 200, 16, torch.float16, 2)[1], v, 2, 0.25, True)  # Kt > 128
+    with pytest.raises(ops.GaError):
+        ops.attn_capture_fwd(q.to(torch.float64), k.to(torch.float64), v.to(torch.float64), 2, 0.25, False)
+    kk = k.clone().requires_grad_(True)
+    o, _ = ops.AttnCapture.apply(q.clone().requires_grad_(True), kk, v, 2, 0.25, False)
+    with pytest.raises(ops.GaError):
+        o.sum().backward()  # context gradients are outside the path: loud, not silent zeros
+
+
+# ------------------------------------------------------------------------------------- processor vs reference (G6)
+G6 = [m for m in load_json("g6_processor.json") if m["ctx_len"] is not None]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("meta", G6, ids=lambda m: m["name"])
+def test_capture_against_reference_fixture(ops, meta, dt):
+    """The reference processor's own P / dq (tests/golden/g6) reproduced by the HIP kernels."""
+    g = load_npz("g6_processor.npz")
+    n, H, seed = meta["name"], meta["heads"], meta["seed"]
+    B, N, C = meta["batch"], meta["N"], meta["C"]
+    shapes = {"to_q.weight": (C, C), "to_k.weight": (C, meta["ctx_dim"]), "to_v.weight": (C, meta["ctx_dim"]),
+              "to_out.0.weight": (C, C), "to_out.0.bias": (C,)}
+    w = {}
+    for pi, pn in enumerate(meta["param_order"]):
+        w[pn] = torch.from_numpy(hashrand.normalish(shapes[pn], seed + 1 + pi) * np.float32(1.5 / math.sqrt(shapes[pn][-1])))
+    x = torch.from_numpy(hashrand.normalish((B, N, C), seed))
+    ctx = torch.from_numpy(hashrand.normalish((B, meta["ctx_len"], meta["ctx_dim"]), seed + 7))
+    q = dev((x @ w["to_q.weight"].T).numpy(), DT[dt])
+    k = dev((ctx @ w["to_k.weight"].T).numpy(), DT[dt])
+    v = dev((ctx @ w["to_v.weight"].T).numpy(), DT[dt])
+    o, p = ops.attn_capture_fwd(q, k, v, H, meta["scale"], True)
+    tol = TOL[dt] * (1 if dt == "f32" else 2)
+    if meta["stored"]:
+        close(p, g[f"{n}.P"], tol, "P vs reference")
+    out = o.float().cpu() @ w["to_out.0.weight"].T + w["to_out.0.bias"]
+    close(out, g[f"{n}.out"], tol * 2, "processor output vs reference")
+    R1 = torch.from_numpy(hashrand.normalish(tuple(out.shape), seed + 8))
+    d_o = dev((R1 @ w["to_out.0.weight"]).numpy(), DT[dt])
+    dp = dev(hashrand.normalish((B * H, N, meta["ctx_len"]), seed + 9), DT[dt]) if meta["stored"] else None
+    dq = ops.attn_capture_bwd(q, k, v, d_o, dp, H, meta["scale"])
+    close(dq, g[f"{n}.dq"], tol * 3, "dq vs reference")
+
+
+# ------------------------------------------------------------------------------------- aggregate (G7)
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("meta", load_json("g7_aggregate.json"), ids=lambda m: m["name"])
+def test_aggregate_against_reference_fixture(ops, meta, dt):
+    g = load_npz("g7_aggregate.npz")
+    store = {}
+    for li, (place, is_cross, N) in enumerate(meta["layout"]):
+        if N > 1024:
+            continue
+        K = 77 if is_cross else N
+        P = dev(hashrand.uniform((meta["batch"] * meta["heads"], N, K), meta["seed_base"] + li), DT[dt])
+        store.setdefault(f"{place}_{'cross' if is_cross else 'self'}", []).append(P)
+    for key in g.files:
+        name, tag = key.split(".")
+        if name != meta["name"]:
+            continue
+        _, r, cs, where = tag.split("_")
+        res = int(r[1:])
+        maps = [m for loc in where.split("-") for m in store.get(f"{loc}_{'cross' if cs == 'c' else 'self'}", [])
+                if m.shape[1] == res * res]
+        A = ops.aggregate_maps(maps)
+        ref = g[key].reshape(res * res, -1)
+        if dt == "f32":
+            close(A, ref, 2e-6, key)
+        else:  # inputs were rounded to 16 bits before the (exact f32) mean
+            ref16 = sum(m.float().sum(0) for m in maps) / sum(m.shape[0] for m in maps)
+            close(A, ref16.double().cpu().numpy(), 2e-6, key)
+            close(A, ref, TOL[dt], key)
+
+
+def test_aggregate_backward_is_broadcast(ops):
+    maps = [dev(hashrand.uniform((8, 256, 77), 9 + i), torch.float16).requires_grad_(True) for i in range(5)]
+    A = ops.AggregateMaps.apply(*maps)
+    w = dev(hashrand.normalish((256, 77), 3), torch.float32)
+    (A * w).sum().backward()
+    for m in maps:
+        close(m.grad, np.broadcast_to((w / 40).half().double().cpu().numpy(), (8, 256, 77)), 1e-6, "dP")
+
+
+# ------------------------------------------------------------------------------------- loss (G4)
+G4 = load_json("g4_loss.json")
+
+
+def plan_from_meta(ops, meta):
+    ents = [{"index": int(k), "kind": v["loss_type"], "geom": tuple(v["loss"]), "subprompt": v["subprompt"]}
+            for k, v in meta["token_dict"].items()]
+    return ops.LossPlan(ents, meta["hyper"], smooth=meta["smooth"], sigma=meta["sigma"],
+                        kernel_size=meta["kernel_size"], sub_prompt_avg_within=meta["sub_prompt_avg_within"])
+
+
+@pytest.mark.parametrize("meta", G4, ids=lambda m: m["name"])
+def test_smooth_loss_against_reference_fixture(ops, meta):
+    g = load_npz("g4_loss.npz")
+    n = meta["name"]
+    plan = plan_from_meta(ops, meta)
+    A = dev(g[f"{n}.A"].reshape(256, 77), torch.float32)
+    first, last = oloss.text_slice(77, meta["normalize_eot"], meta["n_prompt_tokens"])
+    terms, loss = ops.smooth_loss_fwd(A, 16, first, last, plan)
+    t = terms.cpu().numpy()
+    tol = dict(rtol=3e-5, atol=3e-6)
+    for col, key in enumerate(("max", "col", "row", "inside", "outside", "losses", "unscaled")):
+        np.testing.assert_allclose(t[:, col], g[f"{n}.{key}"], err_msg=key, **tol)
+    np.testing.assert_allclose(loss.item(), g[f"{n}.loss"], **tol)
+    dA, dPb = ops.smooth_loss_bwd(A, 16, first, last, plan, None, torch.float16, 1.0 / 40)
+    ref = g[f"{n}.dA"].reshape(256, 77)
+    close(dA, ref, 3e-5, "dA vs reference autograd")
+    close(dPb, ref / 40, 1.5e-3, "broadcast map")
+    # autograd wrapper, with an upstream factor
+    Aa = A.clone().requires_grad_(True)
+    _, l2 = ops.SmoothLoss.apply(Aa, 16, first, last, plan)
+    (l2 * 2.5).sum().backward()
+    close(Aa.grad, 2.5 * ref, 3e-5, "autograd dA")
+
+
+@pytest.mark.parametrize("res", [16, 24, 32, 64])
+@pytest.mark.parametrize("smooth,ksize", [(True, 3), (True, 5), (False, 3)])
+def test_smooth_loss_other_resolutions(ops, res, smooth, ksize):
+    """768^2 / 1024^2 configurations (res 24 / 32) and beyond: no reference fixture exists (the reference
+    hard-codes 16), so parity is against the oracle's closed form."""
+    A = torch.softmax(torch.from_numpy(hashrand.normalish((res, res, 77), 40 + res)) * 2, -1)
+    ents = [{"index": 2, "kind": "BOX", "geom": (.6, .3, .4, .55), "subprompt": "robot"},
+            {"index": 5, "kind": "BOX", "geom": (.2, .3, .4, .55), "subprompt": "blue vase"},
+            {"index": 6, "kind": "COOR", "geom": (.3, .7), "subprompt": "blue vase"}]
+    oplan = oloss.TokenPlan(ents)
+    terms_ref, dA_ref = oloss.loss_and_grad_numpy(A.numpy(), oplan, smooth=smooth, sigma=0.5, kernel_size=ksize)
+    plan = ops.LossPlan(ents, oloss.DEFAULT_HYPER, smooth=smooth, sigma=0.5, kernel_size=ksize)
+    Ad = A.reshape(res * res, 77).cuda()
+    terms, loss = ops.smooth_loss_fwd(Ad, res, 1, 76, plan)
+    np.testing.assert_allclose(loss.item(), terms_ref["loss"], rtol=5e-5)
+    np.testing.assert_allclose(terms[:, 5].cpu().numpy(), terms_ref["token_loss"], rtol=5e-5, atol=1e-6)
+    dA, _ = ops.smooth_loss_bwd(Ad, res, 1, 76, plan)
+    close(dA, dA_ref.reshape(res * res, 77), 5e-5, "dA")
+
+
+def test_gaussian_weights_host(ops):
+    g = load_npz("g1_gaussian.npz")
+    for k, s in [(3, 0.5), (3, 1.0), (5, 1.0), (5, 0.75)]:
+        np.testing.assert_allclose(ops.gaussian_weights(k, s).numpy(), g[f"k{k}_s{s}"], rtol=0, atol=2e-7)
+
+
+def test_loss_errors(ops):
+    A = torch.rand(256, 77, device="cuda")
+    ents = [{"index": 2, "kind": "BOX", "geom": (.6, .3, .4, .55), "subprompt": "robot"}]
+    plan = ops.LossPlan(ents, oloss.DEFAULT_HYPER)
+    with pytest.raises(ops.GaError):
+        ops.smooth_loss_fwd(A, 16, 1, 2, plan)  # guided token outside the text slice
+    with pytest.raises(ops.GaError):
+        ops.smooth_loss_fwd(A.half(), 16, 1, 76, plan)
+    with pytest.raises(ops.GaError):
+        ops.LossPlan(ents, dict(oloss.DEFAULT_HYPER, strict=True))
+    with pytest.raises(ops.GaError):
+        ops.LossPlan([], oloss.DEFAULT_HYPER)
+
+
+# ------------------------------------------------------------------------------------- latent ops (G8)
+def test_latent_axpy_against_reference_fixture(ops):
+    g = load_npz("g8_update_latent.npz")
+    lat, grad = dev(g["latents"], torch.float32), dev(g["grad"], torch.float32)
+    out, am = ops.latent_axpy(lat, grad, float(g["step"]), True)
+    close(out, g["out"], 1e-6, "latents")
+    np.testing.assert_allclose(am.item(), np.abs(g["grad"]).mean(), rtol=1e-5)
+    out2, none = ops.latent_axpy(lat, grad, float(g["step"]), False)
+    assert none is None and torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("n", [1, 1000, 16384, 4 * 128 * 128 + 3])
+def test_latent_ops(ops, dt, n):
+    x = dev(hashrand.normalish((n,), 1), DT[dt])
+    y = dev(hashrand.normalish((n,), 2), DT[dt])
+    z = dev(hashrand.normalish((n,), 3), DT[dt])
+    xs, ys, zs = (t.double().cpu().numpy() for t in (x, y, z))
+    out, am = ops.latent_axpy(x, y, 17.3, True)
+    close(out, xs - 17.3 * ys, TOL[dt], "axpy")
+    np.testing.assert_allclose(am.item(), np.abs(ys).mean(), rtol=1e-4)
+    close(ops.latent_axpby(x, y, 0.8, 0.6), 0.8 * xs + 0.6 * ys, TOL[dt], "axpby")
+    a_t, a_p, gs = 0.35, 0.52, 7.5
+    prev, x0 = ops.cfg_ddim_step(x, y, gs, z, a_t, a_p, True)
+    eps = xs + gs * (ys - xs)
+    x0r = (zs - math.sqrt(1 - a_t) * eps) / math.sqrt(a_t)
+    close(x0, x0r, TOL[dt], "x0")
+    close(prev, math.sqrt(a_p) * x0r + math.sqrt(1 - a_p) * eps, TOL[dt], "prev")
