@@ -16,7 +16,19 @@ __global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ x, con
     out[i] = Traits<T>::from_f32(a * Traits<T>::to_f32(x[i]) + b * Traits<T>::to_f32(y[i]));
 }
 
-// single workgroup: also reduces sum|grad| deterministically
+template <typename T>
+__device__ __forceinline__ T axpy_elem(T x, float step, float g) {
+  return Traits<T>::from_f32(Traits<T>::to_f32(x) - step * g);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void axpy_kernel(const T* __restrict__ x, const T* __restrict__ g, float step,
+                                                   T* __restrict__ out, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i] = axpy_elem<T>(x[i], step, Traits<T>::to_f32(g[i]));
+}
+
+// single workgroup: also reduces sum|grad| deterministically (same element formula as axpy_kernel)
 template <typename T>
 __global__ __launch_bounds__(1024) void axpy_absmean_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                             float step, T* __restrict__ out,
@@ -26,7 +38,7 @@ __global__ __launch_bounds__(1024) void axpy_absmean_kernel(const T* __restrict_
   for (long long i = threadIdx.x; i < n; i += 1024) {
     const float gv = Traits<T>::to_f32(g[i]);
     acc += fabsf(gv);
-    out[i] = Traits<T>::from_f32(Traits<T>::to_f32(x[i]) - step * gv);
+    out[i] = axpy_elem<T>(x[i], step, gv);
   }
   acc = wave_reduce_sum(acc);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
@@ -60,8 +72,7 @@ int do_axpy(const void* x, const void* g, float step, void* out, float* absmean,
     hipLaunchKernelGGL(axpy_absmean_kernel<T>, dim3(1), dim3(1024), 0, s, (const T*)x, (const T*)g, step, (T*)out,
                        absmean, n);
   else
-    hipLaunchKernelGGL(axpby_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)g, 1.0f, -step,
-                       (T*)out, n);
+    hipLaunchKernelGGL(axpy_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)g, step, (T*)out, n);
   return check_launch();
 }
 

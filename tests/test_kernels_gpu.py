@@ -46,7 +46,7 @@ def from_bh(a, B, H):  # (B*H,N,D) -> (B,N,H*D)
 
 
 def close(got, ref, tol, what=""):
-    got = got.double().cpu().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    got = got.detach().double().cpu().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     scale = max(np.abs(ref).max(), 1e-30)
     err = np.abs(got - ref).max()
