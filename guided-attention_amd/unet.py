@@ -1,0 +1,416 @@
+"""Host-side UNet2DCondition for SD-1.x / SD-2.x shapes in plain PyTorch-ROCm (conv / GEMM / norm
+on MIOpen, rocBLAS, hipBLASLt).  The reference delegates this to diffusers 0.12.1
+(`UNet2DConditionModel`, called from pipeline_guided_attention.py:583-743), which is not vendored in
+the reference checkout and not installed here; the topology and parameter names follow the published
+diffusers layout so that a local `diffusion_pytorch_model.safetensors` loads by name.
+
+Every attention layer dispatches to an *attention processor* with the reference's protocol
+(utils/ptp_utils.py:66): proc(attn, hidden_states, encoder_hidden_states=None, attention_mask=None).
+The default processor is the HIP one (no CPU fallback).
+"""
+import math
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+@dataclass
+class UNetConfig:
+    sample_size: int = 64
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    down_block_types: Tuple[str, ...] = ("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D",
+                                         "DownBlock2D")
+    up_block_types: Tuple[str, ...] = ("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D")
+    layers_per_block: int = 2
+    attention_head_dim: Union[int, Tuple[int, ...]] = 8  # diffusers naming: this is the number of heads
+    cross_attention_dim: int = 768
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    use_linear_projection: bool = False
+    center_input_sample: bool = False
+
+    @classmethod
+    def sd15(cls):
+        return cls()
+
+    @classmethod
+    def sd21(cls, sample_size=96):
+        return cls(sample_size=sample_size, attention_head_dim=(5, 10, 20, 20), cross_attention_dim=1024,
+                   use_linear_projection=True)
+
+    @classmethod
+    def tiny(cls, sample_size=64, cross_attention_dim=64):
+        """Full SD-1.x topology (4 resolutions, 16 cross + 16 self attention layers) at 1/10 width, for tests."""
+        return cls(sample_size=sample_size, block_out_channels=(32, 64, 128, 128), attention_head_dim=2,
+                   cross_attention_dim=cross_attention_dim)
+
+    def get(self, key, default=None):
+        return getattr(self, key, default)
+
+
+class Attention(nn.Module):
+    """The module an attention processor is handed (diffusers 0.12.1 `CrossAttention` surface)."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.upcast_attention = False
+        self.upcast_softmax = False
+        self.is_cross = cross_attention_dim is not None
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(cross_attention_dim or query_dim, inner, bias=False)
+        self.to_v = nn.Linear(cross_attention_dim or query_dim, inner, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(0.0)])
+        self.processor = None  # None -> the HIP default, resolved lazily
+
+    def set_processor(self, processor):
+        self.processor = processor
+
+    def prepare_attention_mask(self, attention_mask, target_length):
+        return attention_mask
+
+    def head_to_batch_dim(self, t):
+        b, n, c = t.shape
+        return t.reshape(b, n, self.heads, c // self.heads).permute(0, 2, 1, 3).reshape(b * self.heads, n, c // self.heads)
+
+    def batch_to_head_dim(self, t):
+        bh, n, d = t.shape
+        return t.reshape(bh // self.heads, self.heads, n, d).permute(0, 2, 1, 3).reshape(bh // self.heads, n, d * self.heads)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None):
+        proc = self.processor
+        if proc is None:
+            from .utils.ptp_utils import default_processor
+            proc = self.processor = default_processor()
+        return proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        h, gate = self.proj(x).chunk(2, dim=-1)
+        return h * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
+
+    def forward(self, x):
+        for m in self.net:
+            x = m(x)
+        return x
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, dim_head, cross_attention_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, None, heads, dim_head)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, cross_attention_dim, heads, dim_head)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, context):
+        x = self.attn1(self.norm1(x)) + x
+        x = self.attn2(self.norm2(x), encoder_hidden_states=context) + x
+        return self.ff(self.norm3(x)) + x
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, heads, dim_head, in_channels, cross_attention_dim, groups, use_linear_projection):
+        super().__init__()
+        inner = heads * dim_head
+        self.use_linear_projection = use_linear_projection
+        self.norm = nn.GroupNorm(groups, in_channels, eps=1e-6)
+        if use_linear_projection:
+            self.proj_in = nn.Linear(in_channels, inner)
+            self.proj_out = nn.Linear(inner, in_channels)
+        else:
+            self.proj_in = nn.Conv2d(in_channels, inner, 1)
+            self.proj_out = nn.Conv2d(inner, in_channels, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
+
+    def forward(self, x, context):
+        b, c, h, w = x.shape
+        res = x
+        x = self.norm(x)
+        if self.use_linear_projection:
+            x = self.proj_in(x.permute(0, 2, 3, 1).reshape(b, h * w, c))
+        else:
+            x = self.proj_in(x).permute(0, 2, 3, 1).reshape(b, h * w, -1)
+        for blk in self.transformer_blocks:
+            x = blk(x, context)
+        if self.use_linear_projection:
+            x = self.proj_out(x).reshape(b, h, w, c).permute(0, 3, 1, 2)
+        else:
+            x = self.proj_out(x.reshape(b, h, w, -1).permute(0, 3, 1, 2))
+        return x + res
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, in_channels, out_channels, temb_channels, groups, eps):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
+
+    def forward(self, x, temb_act):
+        """temb_act = SiLU(time embedding), computed once per UNet forward."""
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = h + self.time_emb_proj(temb_act)[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        if self.conv_shortcut is not None:
+            x = self.conv_shortcut(x)
+        return x + h
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=1)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+
+    def forward(self, x, output_size=None):
+        if output_size is None:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        else:
+            x = F.interpolate(x, size=output_size, mode="nearest")
+        return self.conv(x)
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cfg, in_c, out_c, temb_c, heads, add_downsample, has_attn):
+        super().__init__()
+        self.has_cross_attention = has_attn
+        self.resnets = nn.ModuleList([ResnetBlock2D(in_c if i == 0 else out_c, out_c, temb_c, cfg.norm_num_groups,
+                                                    cfg.norm_eps) for i in range(cfg.layers_per_block)])
+        if has_attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(heads, out_c // heads, out_c, cfg.cross_attention_dim,
+                                                                cfg.norm_num_groups, cfg.use_linear_projection)
+                                             for _ in range(cfg.layers_per_block)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_c)]) if add_downsample else None
+
+    def forward(self, x, temb_act, context):
+        outs = []
+        for i, resnet in enumerate(self.resnets):
+            x = resnet(x, temb_act)
+            if self.has_cross_attention:
+                x = self.attentions[i](x, context)
+            outs.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+            outs.append(x)
+        return x, outs
+
+
+class MidBlock(nn.Module):
+    def __init__(self, cfg, channels, temb_c, heads):
+        super().__init__()
+        self.has_cross_attention = True
+        self.resnets = nn.ModuleList([ResnetBlock2D(channels, channels, temb_c, cfg.norm_num_groups, cfg.norm_eps)
+                                      for _ in range(2)])
+        self.attentions = nn.ModuleList([Transformer2DModel(heads, channels // heads, channels, cfg.cross_attention_dim,
+                                                            cfg.norm_num_groups, cfg.use_linear_projection)])
+
+    def forward(self, x, temb_act, context):
+        x = self.resnets[0](x, temb_act)
+        x = self.attentions[0](x, context)
+        return self.resnets[1](x, temb_act)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cfg, in_c, out_c, prev_c, temb_c, heads, add_upsample, has_attn):
+        super().__init__()
+        self.has_cross_attention = has_attn
+        n = cfg.layers_per_block + 1
+        resnets = []
+        for i in range(n):
+            skip_c = in_c if i == n - 1 else out_c
+            res_in = prev_c if i == 0 else out_c
+            resnets.append(ResnetBlock2D(res_in + skip_c, out_c, temb_c, cfg.norm_num_groups, cfg.norm_eps))
+        self.resnets = nn.ModuleList(resnets)
+        if has_attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(heads, out_c // heads, out_c, cfg.cross_attention_dim,
+                                                                cfg.norm_num_groups, cfg.use_linear_projection)
+                                             for _ in range(n)])
+        self.upsamplers = nn.ModuleList([Upsample2D(out_c)]) if add_upsample else None
+
+    def forward(self, x, skips, temb_act, context, upsample_size=None, n_layers=None):
+        """`skips` is consumed from its end.  n_layers < len(resnets) stops early (truncated guidance
+        forward) and returns before the upsampler."""
+        for i, resnet in enumerate(self.resnets):
+            if n_layers is not None and i >= n_layers:
+                return x
+            x = resnet(torch.cat([x, skips.pop()], dim=1), temb_act)
+            if self.has_cross_attention:
+                x = self.attentions[i](x, context)
+        if n_layers is None and self.upsamplers is not None:
+            x = self.upsamplers[0](x, upsample_size)
+        return x
+
+
+def timestep_embedding(timesteps, dim):
+    """diffusers `Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)`: [cos | sin], f32."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=timesteps.device) / half
+    emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_c, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_c, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+@dataclass
+class UNetOutput:
+    sample: Optional[torch.Tensor]
+
+
+class UNet2DConditionModel(nn.Module):
+    def __init__(self, config: Optional[UNetConfig] = None):
+        super().__init__()
+        cfg = self.config = config or UNetConfig()
+        ch = cfg.block_out_channels
+        heads = cfg.attention_head_dim if isinstance(cfg.attention_head_dim, (tuple, list)) else (cfg.attention_head_dim,) * len(ch)
+        temb_c = ch[0] * 4
+        self.in_channels = cfg.in_channels
+        self.conv_in = nn.Conv2d(cfg.in_channels, ch[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(ch[0], temb_c)
+        self.down_blocks = nn.ModuleList()
+        out_c = ch[0]
+        for i, kind in enumerate(cfg.down_block_types):
+            in_c, out_c = out_c, ch[i]
+            self.down_blocks.append(DownBlock(cfg, in_c, out_c, temb_c, heads[i], i != len(ch) - 1,
+                                              kind == "CrossAttnDownBlock2D"))
+        self.mid_block = MidBlock(cfg, ch[-1], temb_c, heads[-1])
+        self.up_blocks = nn.ModuleList()
+        rev, rev_heads = list(reversed(ch)), list(reversed(heads))
+        out_c = rev[0]
+        for i, kind in enumerate(cfg.up_block_types):
+            prev_c, out_c = out_c, rev[i]
+            in_c = rev[min(i + 1, len(ch) - 1)]
+            self.up_blocks.append(UpBlock(cfg, in_c, out_c, prev_c, temb_c, rev_heads[i], i != len(ch) - 1,
+                                          kind == "CrossAttnUpBlock2D"))
+        self.num_upsamplers = len(ch) - 1
+        self.conv_norm_out = nn.GroupNorm(cfg.norm_num_groups, ch[0], eps=cfg.norm_eps)
+        self.conv_out = nn.Conv2d(ch[0], cfg.out_channels, 3, padding=1)
+
+    # ---- attention-processor registry (diffusers protocol used by utils/ptp_utils.py:149-175)
+    def _attention_modules(self):
+        for name, mod in self.named_modules():
+            if isinstance(mod, Attention):
+                yield name, mod
+
+    @property
+    def attn_processors(self):
+        return {f"{name}.processor": mod.processor for name, mod in self._attention_modules()}
+
+    def set_attn_processor(self, processor):
+        mods = dict(self._attention_modules())
+        if isinstance(processor, dict):
+            if len(processor) != len(mods):
+                raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} does "
+                                 f"not match the number of attention layers: {len(mods)}.")
+            for name, mod in mods.items():
+                mod.set_processor(processor[f"{name}.processor"])
+        else:
+            for mod in mods.values():
+                mod.set_processor(processor)
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
+                cross_attention_kwargs=None, return_dict=True, stop_after_up_block=None):
+        """stop_after_up_block = (i, n): run up_blocks[:i] fully and only the first n layers of up_blocks[i],
+        then return sample=None — everything after the last attention map the loss consumes is skipped."""
+        cfg = self.config
+        up_factor = 2 ** self.num_upsamplers
+        forward_upsample_size = any(s % up_factor != 0 for s in sample.shape[-2:])
+        if cfg.center_input_sample:
+            sample = 2 * sample - 1.0
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep], dtype=torch.int64 if isinstance(timestep, int) else torch.float64,
+                                    device=sample.device)
+        elif timestep.dim() == 0:
+            timestep = timestep[None].to(sample.device)
+        timestep = timestep.expand(sample.shape[0])
+        t_emb = timestep_embedding(timestep, cfg.block_out_channels[0]).to(self.dtype)
+        temb_act = F.silu(self.time_embedding(t_emb))
+
+        x = self.conv_in(sample)
+        skips = [x]
+        for blk in self.down_blocks:
+            x, outs = blk(x, temb_act, encoder_hidden_states)
+            skips.extend(outs)
+        x = self.mid_block(x, temb_act, encoder_hidden_states)
+        for i, blk in enumerate(self.up_blocks):
+            n_res = len(blk.resnets)
+            upsample_size = None
+            if i != len(self.up_blocks) - 1 and forward_upsample_size:
+                upsample_size = skips[-n_res - 1].shape[2:]
+            if stop_after_up_block is not None and i == stop_after_up_block[0]:
+                blk(x, skips, temb_act, encoder_hidden_states, upsample_size, n_layers=stop_after_up_block[1])
+                return UNetOutput(sample=None) if return_dict else (None,)
+            x = blk(x, skips, temb_act, encoder_hidden_states, upsample_size)
+        x = self.conv_out(F.silu(self.conv_norm_out(x)))
+        return UNetOutput(sample=x) if return_dict else (x,)
+
+    # ---- weights
+    def init_weights_(self, seed=0):
+        """Seeded random init for runs without a checkpoint (there is no network here): PyTorch's default
+        layer init drawn from one CPU generator, so every rank/device builds identical weights."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith("bias"):
+                    p.zero_()
+                elif p.dim() == 1:
+                    p.fill_(1.0)
+                else:
+                    fan_in = p[0].numel()
+                    bound = math.sqrt(3.0 / fan_in)  # unit-gain uniform: activations keep O(1) scale in fp16
+                    p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * bound)
+        return self
+
+    def load_diffusers_state(self, state):
+        missing, unexpected = self.load_state_dict(state, strict=False)
+        if missing or unexpected:
+            raise RuntimeError(f"UNet checkpoint mismatch: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+        return self

@@ -1,0 +1,186 @@
+"""Host-side helpers with the reference's names and behaviour (utils/helpers.py): the meta-prompt
+grammar, `Rect`, the bounding-box geometry and the in-memory log.  Only what the guided-attention
+path and its callers use is provided; plotting / annotation / latent statistics are out of scope.
+
+Meta-prompt grammar (reference utils/helpers.py:59-114):
+    plain words | [phrase:x,y] (COOR) | [phrase:x,y,w,h] (BOX) | [CustomLoss:name (args)] (last item)
+Quirks of the reference that are kept on purpose (pinned by tests/golden/g2_parse_prompt.json):
+a single trailing word after the last annotation is dropped, and plain words keep their trailing
+space until the next word is appended.
+"""
+import os
+from enum import Enum
+
+import torch
+
+from . import shared_state as state
+
+
+class AnnotationType(Enum):
+    COOR = 0
+    BOX = 1
+    KEYWORD = 2
+
+
+class Rect:
+    """Axis-aligned box; `size` is the side of the square it is expressed in (1 = fractions)."""
+
+    def __init__(self, x, y, width, height, size):
+        self.x, self.y, self.width, self.height, self.size = x, y, width, height, size
+
+    def right(self):
+        return self.x + self.width
+
+    def bottom(self):
+        return self.y + self.height
+
+    def center(self):
+        return ((self.x + self.width / 2.0), (self.y + self.height / 2.0))
+
+    def of_size(self, new_size):
+        ratio = float(new_size / self.size)
+        return Rect(self.x * ratio, self.y * ratio, self.width * ratio, self.height * ratio, new_size)
+
+    def as_tuple(self):
+        return (self.x, self.y, self.width, self.height)
+
+    def __repr__(self):
+        return f"Rect({self.x}, {self.y}, {self.width}, {self.height}, size={self.size})"
+
+
+def add_word(prompt, token):
+    if prompt == "" or prompt.endswith(" "):
+        return prompt + token
+    return prompt + " " + token
+
+
+def _closing_bracket(text):
+    """Index in `text` of the ']' that closes text[0] == '[' (nesting aware).  Like the reference's
+    findMatchingBracket (helpers.py:41-56) the scan starts two characters in, and a missing bracket
+    yields 0."""
+    depth = 0
+    for i in range(2, len(text)):
+        if text[i] == "[":
+            depth += 1
+        elif text[i] == "]":
+            if depth == 0:
+                return i
+            depth -= 1
+    return 0
+
+
+def _annotation(text, bracket, meta_info, custom_losses):
+    """Consume one `[...]` item at the head of `text`; returns (word to add or None, rest)."""
+    close = _closing_bracket(text)
+    colon = text.index(":")
+    phrase = text[bracket + 1:colon].strip(" ")
+    numbers = text[colon + 1:close].strip(" ").split(",")
+    word = phrase
+    if phrase == "CustomLoss":
+        spec = text[colon + 1:]
+        gap = spec.index(" ")
+        name, args = spec[:gap], spec[gap + 1:-1]
+        fn = state.config.registered_loss_functions[name]
+        custom_losses[name] = (fn, args)
+        for sub in fn.subprompts_of_interest(args):
+            meta_info.append((sub, AnnotationType.KEYWORD, None))
+        word = None
+    elif len(numbers) == 2:
+        meta_info.append((phrase, AnnotationType.COOR, (float(numbers[0]), float(numbers[1]))))
+    elif len(numbers) == 4:
+        x, y, w, h = (float(n) for n in numbers)
+        meta_info.append((phrase, AnnotationType.BOX, Rect(x, y, w, h, 1)))
+    return word, text[close + 1:]
+
+
+def parse_prompt(meta_prompt):
+    """-> (prompt, meta_info [(phrase, AnnotationType, Rect | (x, y) | None)], custom_losses)."""
+    prompt, meta_info, custom_losses = "", [], {}
+    text = meta_prompt
+    while True:
+        text = text.lstrip(" ")
+        space, bracket = text.find(" "), text.find("[")
+        if space < 0 and bracket < 0:
+            return prompt, meta_info, custom_losses
+        if bracket < 0:
+            return add_word(prompt, text), meta_info, custom_losses
+        if space < 0 or bracket < space:
+            word, text = _annotation(text, bracket, meta_info, custom_losses)
+            if word is not None:
+                prompt = add_word(prompt, word)
+        else:
+            prompt = add_word(prompt, text[:space + 1])
+            text = text[space:]
+
+
+def get_meta_prompt_clean():
+    s = state.config.meta_prompt
+    for ch in "[]:.":
+        s = s.replace(ch, "_")
+    return s[0:5] if state.config.interactive else s
+
+
+def get_inner_folder_name():
+    return get_meta_prompt_clean()
+
+
+# ---- bounding-box geometry (reference helpers.py:155-173): pixel centres, closed interval, box shrunk
+sample_center = True
+
+
+def inside_box(cur_x, cur_y, rect):
+    if sample_center:
+        cur_x += 0.5
+        cur_y += 0.5
+    off_x = state.curHyperParams["shrink_factor"] * rect.width
+    off_y = state.curHyperParams["shrink_factor"] * rect.height
+    if cur_x >= (rect.x + off_x) and cur_x <= (rect.x + rect.width - off_x):
+        if cur_y >= (rect.y + off_y) and cur_y <= (rect.y + rect.height - off_y):
+            return True
+    return False
+
+
+def inside_mask(rect, res):
+    """(res, res) bool tensor of `inside_box` for a Rect already scaled with of_size(res)."""
+    return torch.tensor([[inside_box(jj, ii, rect) for jj in range(res)] for ii in range(res)], dtype=torch.bool)
+
+
+def calculate_bounding_box_losses(r, imageSoftmax):
+    """Non-strict form of reference helpers.py:215-277: (1 - mass inside, mass outside) of the
+    sum-normalised map.  Stand-alone operator; the hot path computes the same two numbers inside
+    ga_smooth_loss_fwd."""
+    if state.curHyperParams["strict"]:
+        raise NotImplementedError("strict bounding-box loss is off by default in the reference and not provided")
+    res = imageSoftmax.shape[0]
+    mask = inside_mask(r, res).to(imageSoftmax.device)
+    zero = imageSoftmax.new_zeros(())
+    inside = torch.where(mask, imageSoftmax, zero).sum().reshape(1)
+    outside = torch.where(mask, zero, imageSoftmax).sum().reshape(1)
+    return (1. - inside, outside)
+
+
+def dictToString(d):
+    if type(d) is dict:
+        return "".join("_" + str(k) + "_" + dictToString(v) for k, v in d.items() if k != "meta_prompt")
+    return str(d)
+
+
+# ---- in-memory log (reference helpers.py:292-307); kept off the timed path by the pipeline's `log_level`
+lines = []
+
+
+def log(text, also_print=False):
+    lines.append(text + os.linesep)
+    if also_print:
+        print(text)
+
+
+def log_clear():
+    global lines
+    lines = []
+
+
+def log_save(filename):
+    with open(filename, "w") as fp:
+        fp.writelines(lines)
+    log_clear()

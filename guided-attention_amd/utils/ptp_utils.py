@@ -1,0 +1,243 @@
+"""Attention hook layer with the reference's interface (utils/ptp_utils.py:59-289): the attention
+processor that computes softmax(scale Q K^T) and hands it to the controller, the controller /
+AttentionStore classes, `register_attention_control` and `aggregate_attention`.
+
+What differs underneath: the probabilities are produced by the HIP capture kernel
+(`ga_attn_capture_fwd`: QK^T on MFMA, row softmax in registers, P written once, PV fused) directly
+from / into the projection layout, and the store can be told to materialise only the maps the loss
+consumes.  Capture policies (`AttentionStore(capture=...)`):
+  "loss-only"  (default)  keep P only for cross-attention layers with attention_res^2 pixels — the
+               five 16x16 maps `aggregate_attention(res=16, is_cross=True)` reads;
+  "reference"  keep every P with at most 32^2 pixels, cross and self, as the reference does (:228).
+Layers whose P is not kept still tick the controller (the layer counter drives between_steps), with a
+`ProbsNotCaptured` placeholder carrying only the shape.
+"""
+import abc
+from typing import List
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from .._lib import GaError
+from . import shared_state as state
+
+MAX_CAPTURE_KEYS = 128  # ga_attn_capture_* keep the whole key axis on chip up to this length
+
+
+class ProbsNotCaptured:
+    """Shape-only stand-in for a probability tensor that was deliberately not materialised."""
+
+    def __init__(self, shape, dtype, device):
+        self.shape, self.dtype, self.device = torch.Size(shape), dtype, device
+
+
+def _tiled_attention(q, k, v, heads, scale):
+    """softmax(scale q k^T) v for long key sequences (self-attention), probabilities never materialised.
+    q,k,v: (B, N, heads*d) projections -> (B, N, heads*d)."""
+    B, N, C = q.shape
+    d = C // heads
+    qh, kh, vh = (t.view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    o = F.scaled_dot_product_attention(qh, kh, vh, scale=scale)
+    return o.transpose(1, 2).reshape(B, N, C)
+
+
+def _materialised_attention(q, k, v, heads, scale):
+    """Reference-capture mode for key sequences too long for the capture kernel (self-attention with
+    N <= 32^2): P is materialised in the reference's (B*heads, N, Kt) layout."""
+    B, N, C = q.shape
+    d = C // heads
+
+    def split(t):
+        return t.view(B, -1, heads, d).transpose(1, 2).reshape(B * heads, -1, d)
+
+    probs = torch.softmax(torch.bmm(split(q), split(k).transpose(1, 2)) * scale, dim=-1)
+    o = torch.bmm(probs, split(v)).view(B, heads, N, d).transpose(1, 2).reshape(B, N, C)
+    return o, probs
+
+
+class AttendExciteCrossAttnProcessor:
+    """proc(attn, hidden_states, encoder_hidden_states=None, attention_mask=None) -> hidden_states"""
+
+    def __init__(self, attnstore, place_in_unet):
+        self.attnstore = attnstore
+        self.place_in_unet = place_in_unet
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None):
+        if attention_mask is not None:
+            raise GaError("attention masks are not part of the guided-attention path")
+        if state.curHyperParams is not None and state.curHyperParams.get("paint_with_words_stop", 0):
+            raise NotImplementedError("paint-with-words (off by default in the reference) is not provided")
+        is_cross = encoder_hidden_states is not None
+        context = encoder_hidden_states if is_cross else hidden_states
+        query = attn.to_q(hidden_states)
+        key = attn.to_k(context)
+        value = attn.to_v(context)
+        n_pix, n_keys = query.shape[1], key.shape[1]
+        store = self.attnstore
+        want = store is not None and store.wants_probs(is_cross, n_pix)
+        probs = None
+        if n_keys <= MAX_CAPTURE_KEYS:
+            out, probs = ops.AttnCapture.apply(query, key, value, attn.heads, attn.scale, want)
+            if not want:
+                probs = None
+        elif want:
+            out, probs = _materialised_attention(query, key, value, attn.heads, attn.scale)
+        else:
+            if not query.is_cuda:
+                raise GaError("attention runs on the GPU only; there is no CPU fallback")
+            out = _tiled_attention(query, key, value, attn.heads, attn.scale)
+        if store is not None:
+            if probs is None:
+                probs = ProbsNotCaptured((query.shape[0] * attn.heads, n_pix, n_keys), query.dtype, query.device)
+            store(probs, is_cross, self.place_in_unet)
+        out = attn.to_out[0](out)
+        return attn.to_out[1](out)
+
+
+def default_processor():
+    """What an attention layer uses when no controller is registered: the HIP kernels, no capture."""
+    return AttendExciteCrossAttnProcessor(attnstore=None, place_in_unet=None)
+
+
+def register_attention_control(model, controller):
+    attn_procs = {}
+    count = 0
+    for name in model.unet.attn_processors.keys():
+        if name.startswith("mid_block"):
+            place = "mid"
+        elif name.startswith("up_blocks"):
+            place = "up"
+        elif name.startswith("down_blocks"):
+            place = "down"
+        else:
+            continue
+        count += 1
+        attn_procs[name] = AttendExciteCrossAttnProcessor(attnstore=controller, place_in_unet=place)
+    model.unet.set_attn_processor(attn_procs)
+    controller.num_att_layers = count
+
+
+class AttentionControl(abc.ABC):
+    def __init__(self):
+        self.cur_step = 0
+        self.num_att_layers = -1
+        self.cur_att_layer = 0
+
+    def step_callback(self, x_t):
+        return x_t
+
+    def between_steps(self):
+        return
+
+    @property
+    def num_uncond_att_layers(self):
+        return 0
+
+    def wants_probs(self, is_cross: bool, n_pixels: int) -> bool:
+        return True
+
+    @abc.abstractmethod
+    def forward(self, attn, is_cross: bool, place_in_unet: str):
+        raise NotImplementedError
+
+    def __call__(self, attn, is_cross: bool, place_in_unet: str):
+        if self.cur_att_layer >= self.num_uncond_att_layers:
+            self.forward(attn, is_cross, place_in_unet)
+        self.cur_att_layer += 1
+        if self.cur_att_layer == self.num_att_layers + self.num_uncond_att_layers:
+            self.cur_att_layer = 0
+            self.cur_step += 1
+            self.between_steps()
+
+    def reset(self):
+        self.cur_step = 0
+        self.cur_att_layer = 0
+
+
+class EmptyControl(AttentionControl):
+    def wants_probs(self, is_cross, n_pixels):
+        return False
+
+    def forward(self, attn, is_cross: bool, place_in_unet: str):
+        return attn
+
+
+class AttentionStore(AttentionControl):
+    @staticmethod
+    def get_empty_store():
+        return {"down_cross": [], "mid_cross": [], "up_cross": [],
+                "down_self": [], "mid_self": [], "up_self": []}
+
+    def __init__(self, save_global_store=False, capture="loss-only", attention_res=16):
+        super().__init__()
+        if capture not in ("loss-only", "reference"):
+            raise ValueError(f"capture must be 'loss-only' or 'reference', got {capture!r}")
+        self.save_global_store = save_global_store
+        self.capture = capture
+        self.attention_res = attention_res
+        self.step_store = self.get_empty_store()
+        self.attention_store = {}
+        self.global_store = {}
+        self.curr_step_index = 0
+
+    def _save_all(self):
+        return bool(getattr(state.config, "save_individual_CA_maps", False))
+
+    def wants_probs(self, is_cross, n_pixels):
+        if self.capture == "reference" or self.save_global_store:
+            return self._save_all() or n_pixels <= 32 ** 2
+        return is_cross and n_pixels == self.attention_res ** 2
+
+    def forward(self, attn, is_cross: bool, place_in_unet: str):
+        if isinstance(attn, ProbsNotCaptured):
+            return attn
+        key = f"{place_in_unet}_{'cross' if is_cross else 'self'}"
+        if self._save_all() or attn.shape[1] <= 32 ** 2:  # avoid memory overhead (reference :228)
+            self.step_store[key].append(attn)
+        return attn
+
+    def between_steps(self):
+        self.attention_store = self.step_store
+        if self.save_global_store:
+            with torch.no_grad():
+                if len(self.global_store) == 0:
+                    self.global_store = self.step_store
+                else:
+                    for key in self.global_store:
+                        for i in range(len(self.global_store[key])):
+                            self.global_store[key][i] += self.step_store[key][i].detach()
+        self.step_store = self.get_empty_store()
+
+    def get_average_attention(self):
+        return self.attention_store
+
+    def get_average_global_attention(self):
+        return {key: [item / self.cur_step for item in self.global_store[key]] for key in self.attention_store}
+
+    def reset(self):
+        super().reset()
+        self.step_store = self.get_empty_store()
+        self.attention_store = {}
+        self.global_store = {}
+
+
+def aggregate_attention(attention_store: AttentionStore, res: int, from_where: List[str], is_cross: bool,
+                        select: int) -> torch.Tensor:
+    """Mean over the heads of every stored map with res^2 pixels, in `from_where` order
+    (reference :273-289).  Runs `ga_aggregate_maps`; returns float32 (res, res, n_keys) and stays
+    differentiable w.r.t. the stored probabilities."""
+    maps = []
+    attention_maps = attention_store.get_average_attention()
+    num_pixels = res ** 2
+    for location in from_where:
+        for item in attention_maps[f"{location}_{'cross' if is_cross else 'self'}"]:
+            if item.shape[1] == num_pixels:
+                maps.append(item)
+    if not maps:
+        raise RuntimeError(f"no stored attention map has {res}x{res} pixels: nothing to aggregate "
+                           "(reference: torch.cat of an empty list)")
+    if select != 0:
+        raise IndexError(f"index {select} is out of bounds for dimension 0 with size 1")
+    out = ops.AggregateMaps.apply(*maps)
+    return out.view(res, res, out.shape[-1])

@@ -513,6 +513,170 @@ def g8_update():
     np.savez(OUT / "g8_update_latent.npz", latents=f32(lat), w=f32(w), step=np.float64(step), out=f32(new),
              grad=f32(torch.autograd.grad(loss, [lat])[0]))
 
+# ----------------------------------------------------------------------------- G9 loop-level trace
+def hash_init_(module, seed):
+    """Deterministic, platform-independent weights (tests rebuild them bit-for-bit)."""
+    with torch.no_grad():
+        for pi, (name, p) in enumerate(module.named_parameters()):
+            if name.endswith("bias"):
+                p.zero_()
+            elif p.dim() == 1:
+                p.fill_(1.0)
+            else:
+                fan_in = p[0].numel()
+                u = hashrand.uniform(tuple(p.shape), seed + pi) * np.float32(2.0) - np.float32(1.0)
+                p.copy_(torch.from_numpy(u * np.float32(math.sqrt(3.0 / fan_in))))
+    return module
+
+
+class _UNetShim:
+    """Plain callable around the build's UNet module (the reference assigns `unet.__dict__['forward']`,
+    :854, which must stay inert here) with the attributes register_attention_control / __call__ read."""
+
+    def __init__(self, real):
+        self.real = real
+        self.config = types.SimpleNamespace(sample_size=real.config.sample_size,
+                                            cross_attention_dim=real.config.cross_attention_dim,
+                                            block_out_channels=list(real.config.block_out_channels))
+        self.in_channels = real.in_channels
+        self.calls = []
+
+    @property
+    def attn_processors(self):
+        return self.real.attn_processors
+
+    def set_attn_processor(self, procs):
+        self.real.set_attn_processor(procs)
+
+    def zero_grad(self):
+        pass
+
+    def __call__(self, sample, t, encoder_hidden_states=None, cross_attention_kwargs=None):
+        self.calls.append((int(sample.shape[0]), bool(torch.is_grad_enabled() and sample.requires_grad)))
+        return self.real(sample, int(t), encoder_hidden_states=encoder_hidden_states)
+
+
+def g9_loop():
+    sys.path.insert(0, str(OUT.parent.parent))
+    from guided_attention_amd.scheduler import DDIMScheduler
+    from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig
+    import contextlib
+
+    pga.DDIMScheduler = DDIMScheduler  # "the build's DDIM" (diffusers is not installed)
+    real_generator, real_randn = torch.Generator, torch.randn
+    torch.Generator = lambda device=None: real_generator("cpu")            # reference hard-codes 'cuda' (:921)
+    torch.randn = lambda *a, **k: real_randn(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+
+    class LoopHarness(Harness):
+        vae_scale_factor = 8
+        _execution_device = torch.device("cpu")
+
+        def __init__(self, unet, embeds):
+            super().__init__()
+            self.unet = unet
+            self.scheduler = DDIMScheduler()
+            self.embeds = embeds
+            tok_outer = self.tokenizer
+
+            class Tok:  # padded-tensor front of the word tokenizer
+                model_max_length = 77
+
+                def __call__(self_, text, padding=None, max_length=None, truncation=None, return_tensors=None):
+                    if return_tensors is None:
+                        return tok_outer(text)
+                    texts = [text] if isinstance(text, str) else text
+                    return types.SimpleNamespace(input_ids=torch.zeros(len(texts), 77, dtype=torch.long) +
+                                                 (0 if texts[0] else 1))
+
+                def decode(self_, tid):
+                    return tok_outer.decode(tid)
+
+                def batch_decode(self_, ids):
+                    return []
+
+            self.tokenizer = Tok()
+
+            class Enc:
+                config = types.SimpleNamespace()
+                dtype = torch.float32
+
+                def __call__(self_, ids, attention_mask=None):  # ids all-ones marks the empty (negative) prompt
+                    return (embeds[0:1] if int(ids[0, 0]) == 1 else embeds[1:2],)
+
+            self.text_encoder = Enc()
+
+        def check_inputs(self, *a, **k):
+            pass
+
+        def prepare_latents(self, bs, ch, height, width, dtype, device, generator, latents=None):
+            return latents
+
+        def prepare_extra_step_kwargs(self, generator, eta):
+            return {}
+
+        def progress_bar(self, total=None):
+            return contextlib.nullcontext(types.SimpleNamespace(update=lambda: None))
+
+        def save_image(self, latent, tag):
+            pass
+
+        def decode_latents(self, latents):
+            self.final_latents = latents.detach().clone()
+            return np.zeros((1, 8, 8, 3), np.float32)
+
+        def numpy_to_pil(self, image):
+            return [image]
+
+    cases = [
+        # name, steps, call thresholds, only_update_on_threshold_steps, max_iter_to_alter, hyper, scale_factor
+        ("default_like", 6, {0: 1.0}, True, 25, {"recurse_steps": 3, "recurse_until": 14}, 20),
+        ("every_step", 6, {0: 9.0, 2: 1.7}, False, 4, {"recurse_steps": 2, "recurse_until": 1}, 20),
+        ("no_recurse_thr2", 5, {0: 2.5, 1: 0.5}, True, 25, {"recurse_steps": 1}, 10),
+    ]
+    arrs, meta = {}, []
+    for ci, (name, steps, thr, only_thr, max_alter, hyper, sf) in enumerate(cases):
+        cfgu = UNetConfig.tiny(sample_size=32, cross_attention_dim=48)
+        real = hash_init_(UNet2DConditionModel(cfgu), 9000 + 1000 * ci).float()
+        for p in real.parameters():
+            p.requires_grad_(False)
+        shim = _UNetShim(real)
+        embeds = torch.from_numpy(hashrand.normalish((2, 77, 48), 9100 + ci))
+        h = LoopHarness(shim, embeds)
+        cfg = setup_prompt(h, BASE_PROMPT, hyper, only_update_on_threshold_steps=only_thr)
+        cfg.thresholds = dict(thr)  # run.py:overrideConfig: config.thresholds := hyper-param thresholds
+        state.curHyperParams["thresholds"] = dict(thr)
+        state.cur_seed = 7
+        helpers.log_clear()
+        controller = ptp.AttentionStore()
+        ptp.register_attention_control(h, controller)
+        lat0 = torch.from_numpy(hashrand.normalish((1, 4, 32, 32), 9200 + ci))
+        gen = real_generator("cpu").manual_seed(1234 + ci)
+        out = h(prompt=cfg.prompt, attention_store=controller, attention_res=16, guidance_scale=7.5, generator=gen,
+                num_inference_steps=steps, max_iter_to_alter=max_alter, run_standard_sd=False, thresholds=cfg.thresholds,
+                scale_factor=sf, scale_range=(1.0, 0.5), smooth_attentions=True, sigma=0.5, kernel_size=3, sd_2_1=False,
+                latents=lat0.clone(), return_dict=False)
+        log = "".join(helpers.lines)
+        n_b1 = sum(1 for b, g in shim.calls if b == 1)
+        n_b2 = sum(1 for b, g in shim.calls if b == 2)
+        n_bwd = log.count("gradient size average")
+        losses = [float(l.split("Loss:")[1]) for l in log.splitlines() if l.startswith("Iteration") and "Loss:" in l]
+        import re
+        fin = [float(re.search(r"tensor\(\[([^\]]+)\]", l).group(1)) for l in log.splitlines()
+               if "Finished with loss of" in l]
+        arrs[f"{name}.final_latents"] = f32(h.final_latents)
+        arrs[f"{name}.iter_losses"] = np.array(losses, np.float32)
+        arrs[f"{name}.refine_final_losses"] = np.array(fin, np.float32)
+        meta.append({"name": name, "steps": steps, "thresholds": {str(k): v for k, v in thr.items()},
+                     "only_update_on_threshold_steps": only_thr, "max_iter_to_alter": max_alter, "hyper": hyper,
+                     "scale_factor": sf, "unet_seed": 9000 + 1000 * ci, "embed_seed": 9100 + ci,
+                     "latent_seed": 9200 + ci, "renoise_seed": 1234 + ci, "fwd_b1": n_b1, "fwd_b2": n_b2, "bwd": n_bwd,
+                     "subiterations": log.count("subiteration:"), "call_sequence": "".join(str(b) for b, g in shim.calls),
+                     "final_abs_mean": float(h.final_latents.abs().mean())})
+        print(name, meta[-1]["fwd_b1"], meta[-1]["bwd"], meta[-1]["fwd_b2"], meta[-1]["final_abs_mean"], losses[:4], fin)
+    torch.Generator, torch.randn = real_generator, real_randn
+    np.savez_compressed(OUT / "g9_loop.npz", **arrs)
+    (OUT / "g9_loop.json").write_text(json.dumps(meta, indent=1))
+
 
 def main():
     torch.manual_seed(0)
@@ -525,6 +689,7 @@ def main():
     g6_processor()
     g7_aggregate()
     g8_update()
+    g9_loop()
     for p in sorted(OUT.glob("g*")):
         print(f"{p.name:32s} {p.stat().st_size:9d} B")
 
