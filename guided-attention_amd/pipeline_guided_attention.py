@@ -314,8 +314,11 @@ class GuidedAttention:
 
     def _guidance_forward(self, latents, t, cond):
         self.unet_calls["fwd_b1_grad"] += 1
-        if self.guidance_forward == "truncated":
-            return self.unet(latents, t, encoder_hidden_states=cond, stop_after_up_block=self._truncate_at).sample
+        if self.guidance_forward == "truncated" and self._truncate_at is not None:
+            out = self.unet(latents, t, encoder_hidden_states=cond, stop_after_up_block=self._truncate_at).sample
+            if hasattr(self._attention_store, "flush"):
+                self._attention_store.flush()
+            return out
         return self.unet(latents, t, encoder_hidden_states=cond).sample
 
     def _perform_iterative_refinement_step(self, latents, loss, threshold, text_embeddings, text_input,
@@ -398,7 +401,7 @@ class GuidedAttention:
         self.scheduler.set_timesteps(num_inference_steps, device="cpu")
         timesteps = self.scheduler.timesteps
         acp = self.scheduler.alphas_cumprod
-        state.sigmas = np.array(((1 - acp) / acp) ** 0.5)
+        state.sigmas = (((1 - acp) / acp) ** 0.5).numpy()
         state.timesteps = timesteps
         latents = self.prepare_latents(1, self.unet.in_channels, height, width, prompt_embeds.dtype, device, generator,
                                        latents)
@@ -417,6 +420,7 @@ class GuidedAttention:
         if hasattr(attention_store, "attention_res"):
             attention_store.attention_res = attention_res
         self.unet_calls = {"fwd_b1_grad": 0, "bwd": 0, "fwd_b2": 0, "loss_evals": 0}
+        self._attention_store = attention_store
         self._deferred_log = []
         self._truncate_at = self._truncation_point(attention_res, height, width)
         cond = prompt_embeds[1:2] if do_cfg else prompt_embeds[0:1]

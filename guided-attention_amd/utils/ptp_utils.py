@@ -77,7 +77,9 @@ class AttendExciteCrossAttnProcessor:
         store = self.attnstore
         want = store is not None and store.wants_probs(is_cross, n_pix)
         probs = None
-        if n_keys <= MAX_CAPTURE_KEYS:
+        ctx_needs_grad = torch.is_grad_enabled() and (key.requires_grad or value.requires_grad)
+        if n_keys <= MAX_CAPTURE_KEYS and not ctx_needs_grad:
+            # the capture kernels: whole key axis on chip; context (text) carries no gradient
             out, probs = ops.AttnCapture.apply(query, key, value, attn.heads, attn.scale, want)
             if not want:
                 probs = None
@@ -153,6 +155,14 @@ class AttentionControl(abc.ABC):
     def reset(self):
         self.cur_step = 0
         self.cur_att_layer = 0
+
+    def flush(self):
+        """Close a forward that stopped before its last attention layer (truncated guidance forward): publish
+        what was captured exactly as the layer counter would have after the final layer."""
+        if self.cur_att_layer != 0:
+            self.cur_att_layer = 0
+            self.cur_step += 1
+            self.between_steps()
 
 
 class EmptyControl(AttentionControl):
