@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py — guided images/sec of the guided-attention hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one guided image: the full 50-step DDIM guided sampling of the SD-1.x UNet at 512^2
+(latent 64^2), prompt 'a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55]', guidance 7.5, the
+reference's shipped hyper-parameters (thresholds {0:1.0}, recurse_steps 3, max 10 refinement
+iterations), fp16, timed from after prompt encoding to the final latents (the VAE
+decode is outside the metric).  Synthetic inputs: seeded random-init UNet weights (no checkpoint
+offline), synthetic prompt embeddings, host-generated initial latents and re-noise tensors.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+META_PROMPT = "a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55]"
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed guided images per GPU")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="default", choices=["default", "every-step"])
+    ap.add_argument("--model", default=os.environ.get("GA_BENCH_MODEL", "sd15"), choices=["sd15", "tiny"])
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--guidance-forward", default="full", choices=["full", "truncated"])
+    ap.add_argument("--skip-unused-guidance", action="store_true")
+    return ap.parse_args()
+
+
+def build_pipeline(args, device, rank, world):
+    from guided_attention_amd import parallel
+    from guided_attention_amd.pipeline_guided_attention import GuidedAttention
+    from guided_attention_amd.text import SyntheticTextEncoder, WordTokenizer
+    from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig
+    cfg = UNetConfig.sd15() if args.model == "sd15" else UNetConfig.tiny(64, 768)
+    with torch.device(device):
+        unet = UNet2DConditionModel(cfg)
+    unet = unet.half()
+    if rank == 0:
+        unet.init_weights_(seed=0)       # seeded random weights of the SD-1.x architecture
+    t0 = time.perf_counter()
+    n_msgs = parallel.broadcast_module_(unet)  # RCCL over xGMI: the only start-up collective
+    torch.cuda.synchronize()
+    bcast_s = time.perf_counter() - t0
+    pipe = GuidedAttention(unet, None, None, SyntheticTextEncoder(cfg.cross_attention_dim), WordTokenizer())
+    pipe.to(device, torch.float16)
+    pipe.guidance_forward = args.guidance_forward
+    pipe.skip_unused_guidance = args.skip_unused_guidance
+    return pipe, cfg, {"messages": n_msgs, "seconds": bcast_s}
+
+
+def make_run(args, pipe, cfg, device):
+    from guided_attention_amd import run
+    from guided_attention_amd.config import RunConfig
+    from guided_attention_amd.utils import helpers, ptp_utils, shared_state as state
+    rc = RunConfig(meta_prompt=META_PROMPT, output_path="/tmp/ga_bench_out", half_precision=True,
+                   n_inference_steps=args.ddim_steps)
+    if args.workload == "every-step":
+        rc.only_update_on_threshold_steps = False
+        rc.max_iter_to_alter = 25
+    rc.stable = pipe
+    state.curHyperParams = state.get_hyperparam_states()[0]
+    run.overrideConfig(rc)        # thresholds := {0: 1.0}, as the reference does at run time
+    run.parseMetaPrompt(rc)
+    g = torch.Generator("cpu").manual_seed(1234)
+    embeds = torch.randn(2, 77, cfg.cross_attention_dim, generator=g).to(device, torch.float16)
+    lat_side = cfg.sample_size
+
+    def one_image(seed):
+        gs = torch.Generator("cpu").manual_seed(seed)
+        latents = torch.randn(1, 4, lat_side, lat_side, generator=gs)
+        noise = [torch.randn(1, 4, lat_side, lat_side, generator=gs) for _ in range(2 * args.ddim_steps)]
+        helpers.log_clear()
+        state.cur_seed = seed
+        controller = ptp_utils.AttentionStore()
+        ptp_utils.register_attention_control(pipe, controller)
+        return pipe(prompt=None, prompt_embeds=embeds[1:2], negative_prompt_embeds=embeds[0:1],
+                    attention_store=controller, attention_res=rc.attention_res, guidance_scale=rc.guidance_scale,
+                    num_inference_steps=rc.n_inference_steps, max_iter_to_alter=rc.max_iter_to_alter,
+                    thresholds=rc.thresholds, scale_factor=rc.scale_factor, scale_range=rc.scale_range,
+                    smooth_attentions=rc.smooth_attentions, sigma=rc.sigma, kernel_size=rc.kernel_size,
+                    latents=latents, renoise_noise=noise, output_type="latent")
+
+    return one_image, rc, embeds
+
+
+def roofline_entry(timings, B_target=2):
+    """Dominant hand-written kernel = the cross-attention capture forward at the 64x64 layers
+    (N = 4096, d = 40, h = 8, 77 keys): algorithmic bytes per launch = Q + O (2*B*N*C each, fp16) + K,V
+    (2 * 2*B*77*C); P is not written at this resolution (loss-only capture).  DESIGN.md section 5."""
+    best = None
+    for key, ms in timings.items():
+        if key[0] != "attn_capture_fwd":
+            continue
+        _, B, H, N, Kt, D, want, _dt = key
+        total = sum(ms)
+        if best is None or total > best[0]:
+            best = (total, key, ms)
+    if best is None:
+        return None
+    _, (_, B, H, N, Kt, D, want, dt), ms = best
+    C, esz = H * D, 2
+    bytes_alg = esz * (2 * B * N * C + 2 * B * Kt * C + (B * H * N * Kt if want else 0))
+    avg_ms = sum(ms) / len(ms)
+    achieved = bytes_alg / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": f"attn_capture_fwd B{B} H{H} N{N} Kt{Kt} D{D} {'+P' if want else 'noP'}",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None, "algorithmic_bytes": bytes_alg, "avg_launch_us": round(avg_ms * 1e3, 2),
+            "launches": len(ms)}
+
+
+def cpu_baseline(args, cfg, calls, rc):
+    """The oracle (CPU fp32 restatement, oracle/pipeline.py) on the host cores: one guidance evaluation
+    (forward with autograd + loss), one backward to the latents and one CFG forward of the SAME UNet
+    shape, extrapolated with the GPU run's per-image call counts."""
+    import copy
+    from oracle import loss as oloss
+    from oracle.pipeline import GuidedSampler
+    from guided_attention_amd.unet import UNet2DConditionModel
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    unet = UNet2DConditionModel(cfg).init_weights_(seed=0).float()
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    entries = [{"index": 2, "kind": "BOX", "geom": (.6, .3, .4, .55), "subprompt": "robot"},
+               {"index": 5, "kind": "BOX", "geom": (.2, .3, .4, .55), "subprompt": "blue vase"},
+               {"index": 6, "kind": "BOX", "geom": (.2, .3, .4, .55), "subprompt": "blue vase"}]
+    s = GuidedSampler(unet, oloss.TokenPlan(entries), thresholds={0: 1.0}, steps=args.ddim_steps)
+    g = torch.Generator("cpu").manual_seed(1234)
+    embeds = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
+    lat = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator("cpu").manual_seed(0))
+    t0 = time.perf_counter()
+    with torch.enable_grad():
+        lat_g, r, _ = s._evaluate(lat, 981, embeds[1:2])
+    t1 = time.perf_counter()
+    with torch.enable_grad():
+        s._update(lat_g, r["loss"], 20.0)
+    t2 = time.perf_counter()
+    with torch.no_grad():
+        unet(torch.cat([lat] * 2), 981, encoder_hidden_states=embeds)
+    t3 = time.perf_counter()
+    per = {"fwd_b1_grad": t1 - t0, "bwd": t2 - t1, "fwd_b2": t3 - t2}
+    sec_per_image = sum(per[k] * calls[k] for k in per)
+    return {"value": 1.0 / sec_per_image, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "1x guidance forward+loss (autograd), 1x backward to latents, 1x CFG forward (B=2) of the same "
+                      f"{args.model} UNet in fp32 on the host, extrapolated with the GPU run's per-image call counts "
+                      f"{ {k: calls[k] for k in per} }",
+            "seconds_per_kind": {k: round(v, 3) for k, v in per.items()}, "seconds_per_image": round(sec_per_image, 1)}
+
+
+def main():
+    args = parse()
+    from guided_attention_amd import ops, parallel
+    rank, world, local = parallel.init_distributed()
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the guided-attention path has no CPU fallback")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    ops.load()
+    pipe, cfg, bcast = build_pipeline(args, device, rank, world)
+    one_image, rc, _ = make_run(args, pipe, cfg, device)
+    import torch.distributed as dist
+
+    seed_of = lambda j: rank + world * j   # seeds striped by rank (weak scaling: K images per GPU)
+    for j in range(args.warmup):
+        one_image(1000 + seed_of(j))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.start_timing()
+    t0 = time.perf_counter()
+    calls = None
+    finals = []
+    for j in range(args.steps):
+        out = one_image(seed_of(j))
+        finals.append(out.latents)
+        calls = out.unet_calls
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timings = ops.stop_timing()
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    gathered = parallel.gather_tensors(finals)  # the end-of-run gather of the final latents (32 KB each)
+    ok = all(torch.isfinite(f).all().item() for f in finals)
+    if rank == 0:
+        n_images = args.steps * world
+        roof = roofline_entry(timings)
+        flops_per_fwd = 0.803e12 if args.model == "sd15" else None
+        line = {
+            "metric": "guided images/sec (50-step SD-1.5 512^2)", "value": n_images / elapsed, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"W-{args.workload}: SD-1.x UNet 512^2 (latent 64^2), {args.ddim_steps} DDIM steps, "
+                                   f"meta_prompt '{META_PROMPT}', guidance 7.5, thresholds {rc.thresholds}, 1 seed per step",
+                       "parallelism": f"seed-parallel x{world}", "guidance_forward": args.guidance_forward,
+                       "skip_unused_guidance": args.skip_unused_guidance, "model": args.model,
+                       "weights": "seeded random init (no checkpoint offline)"},
+            "unet_calls_per_image": calls, "finite": ok,
+            "weight_broadcast": bcast,
+        }
+        if flops_per_fwd:
+            tf = flops_per_fwd * (calls["fwd_b1_grad"] + 2 * calls["fwd_b2"] + calls["bwd"]) / 1e12
+            line["end_to_end"] = {"tflop_per_image": round(tf, 1),
+                                  "achieved_tflops_per_gpu": round(tf * args.steps / elapsed, 1),
+                                  "frac_of_2.5PF_dense_fp16": round(tf * args.steps / elapsed / 2500.0, 4)}
+        line["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, cfg, calls, rc)
+            line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,39 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+# Optional per-launch timing (bench.py): HIP events recorded on the launch stream around a kernel.
+_TIMING = None
+
+
+def start_timing():
+    global _TIMING
+    _TIMING = {}
+
+
+def stop_timing():
+    """-> {key: [milliseconds per launch]}; synchronises once, at the end."""
+    global _TIMING
+    rec, _TIMING = _TIMING, None
+    torch.cuda.synchronize()
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in (rec or {}).items()}
+
+
+class _timed:
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _TIMING is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _TIMING.setdefault(self.key, []).append((self.e0, e1))
+
+
 # --------------------------------------------------------------------------------------- K1
 def attn_capture_fwd(q, k, v, heads, scale, want_probs):
     """q (B,N,C), k/v (B,Kt,C) projections -> (o (B,N,C), probs (B*heads,N,Kt) or None)."""
@@ -25,8 +58,9 @@ def attn_capture_fwd(q, k, v, heads, scale, want_probs):
     D = C // heads
     o = torch.empty_like(q)
     probs = torch.empty((B * heads, N, Kt), dtype=q.dtype, device=q.device) if want_probs else None
-    check(load().ga_attn_capture_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(probs), B, heads, N, Kt, D,
-                                     float(scale), dtype_code(q), stream_ptr()), "ga_attn_capture_fwd")
+    with _timed(("attn_capture_fwd", B, heads, N, Kt, D, bool(want_probs), str(q.dtype))):
+        check(load().ga_attn_capture_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(probs), B, heads, N, Kt, D,
+                                         float(scale), dtype_code(q), stream_ptr()), "ga_attn_capture_fwd")
     return o, probs
 
 
@@ -45,9 +79,10 @@ def attn_capture_bwd(q, k, v, d_o, d_probs, heads, scale):
             d_probs = d_probs.contiguous()
         sb, sn = d_probs.stride(0), d_probs.stride(1)
     dq = torch.empty_like(q)
-    check(load().ga_attn_capture_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(d_o), _ptr(d_probs), sb, sn, _ptr(dq), None, None,
-                                     B, heads, N, Kt, C // heads, float(scale), dtype_code(q), stream_ptr()),
-          "ga_attn_capture_bwd")
+    with _timed(("attn_capture_bwd", B, heads, N, Kt, C // heads, d_probs is not None, str(q.dtype))):
+        check(load().ga_attn_capture_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(d_o), _ptr(d_probs), sb, sn, _ptr(dq), None,
+                                         None, B, heads, N, Kt, C // heads, float(scale), dtype_code(q), stream_ptr()),
+              "ga_attn_capture_bwd")
     return dq
 
 
