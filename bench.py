@@ -99,29 +99,56 @@ def make_run(args, pipe, cfg, device):
     return one_image, rc, embeds
 
 
-def roofline_entry(timings, B_target=2):
-    """Dominant hand-written kernel = the cross-attention capture forward at the 64x64 layers
-    (N = 4096, d = 40, h = 8, 77 keys): algorithmic bytes per launch = Q + O (2*B*N*C each, fp16) + K,V
-    (2 * 2*B*77*C); P is not written at this resolution (loss-only capture).  DESIGN.md section 5."""
-    best = None
-    for key, ms in timings.items():
-        if key[0] != "attn_capture_fwd":
-            continue
-        _, B, H, N, Kt, D, want, _dt = key
-        total = sum(ms)
-        if best is None or total > best[0]:
-            best = (total, key, ms)
-    if best is None:
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host and oversubscribes a container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def capture_bytes(key):
+    """Algorithmic HBM bytes of one capture-kernel launch: forward = Q + O + K + V
+    (+ P when it is stored); backward = Q + dO + dQ + K + V (+ the broadcast dP map)."""
+    kind, B, H, N, Kt, D, flag, dt = key
+    esz = 4 if dt == "torch.float32" else 2
+    C = H * D
+    kv = 2 * B * Kt * C
+    if kind == "attn_capture_fwd":
+        return esz * (2 * B * N * C + kv + (B * H * N * Kt if flag else 0))
+    return esz * (3 * B * N * C + kv + (N * Kt if flag else 0))
+
+
+def roofline_entry(census, ops):
+    """Dominant hand-written kernel: the capture kernel (forward or backward symbol) with the largest total time
+    over the timed region.  achieved = sum of algorithmic bytes over its launches / sum of their durations, each
+    shape's duration measured by a back-to-back replay between two HIP events on the launch stream; the same
+    weighted mean is what `rocprofv3 --kernel-trace --stats` reports as the symbol's AverageNs."""
+    per_kind = {}
+    for key, count in census.items():
+        us = ops.replay_launch_us(key)
+        d = per_kind.setdefault(key[0], {"time_us": 0.0, "bytes": 0, "launches": 0, "shapes": []})
+        d["time_us"] += us * count
+        d["bytes"] += capture_bytes(key) * count
+        d["launches"] += count
+        d["shapes"].append({"B": key[1], "N": key[3], "D": key[5], "flag": key[6], "launches": count,
+                            "launch_us": round(us, 2), "GBps": round(capture_bytes(key) / us / 1e3, 1)})
+    if not per_kind:
         return None
-    _, (_, B, H, N, Kt, D, want, dt), ms = best
-    C, esz = H * D, 2
-    bytes_alg = esz * (2 * B * N * C + 2 * B * Kt * C + (B * H * N * Kt if want else 0))
-    avg_ms = sum(ms) / len(ms)
-    achieved = bytes_alg / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": f"attn_capture_fwd B{B} H{H} N{N} Kt{Kt} D{D} {'+P' if want else 'noP'}",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "algorithmic_bytes": bytes_alg, "avg_launch_us": round(avg_ms * 1e3, 2),
-            "launches": len(ms)}
+    kind, d = max(per_kind.items(), key=lambda kv: kv[1]["time_us"])
+    achieved = d["bytes"] / d["time_us"] / 1e3
+    return {"bound": "hbm", "kernel": kind, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "avg_launch_us": round(d["time_us"] / d["launches"], 2), "launches": d["launches"],
+            "algorithmic_bytes_per_launch": d["bytes"] // d["launches"],
+            "shapes": sorted(d["shapes"], key=lambda x: -x["launches"] * x["launch_us"])[:6],
+            "other_kernels": {k: {"avg_launch_us": round(v["time_us"] / v["launches"], 2),
+                                  "GBps": round(v["bytes"] / v["time_us"] / 1e3, 1)} for k, v in per_kind.items() if k != kind}}
 
 
 def cpu_baseline(args, cfg, calls, rc):
@@ -132,7 +159,7 @@ def cpu_baseline(args, cfg, calls, rc):
     from oracle import loss as oloss
     from oracle.pipeline import GuidedSampler
     from guided_attention_amd.unet import UNet2DConditionModel
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     unet = UNet2DConditionModel(cfg).init_weights_(seed=0).float()
     for p in unet.parameters():
@@ -185,7 +212,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.start_timing()
+    ops.start_census()
     t0 = time.perf_counter()
     calls = None
     finals = []
@@ -197,7 +224,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    timings = ops.stop_timing()
+    census = ops.stop_census()
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -206,7 +233,7 @@ def main():
     ok = all(torch.isfinite(f).all().item() for f in finals)
     if rank == 0:
         n_images = args.steps * world
-        roof = roofline_entry(timings)
+        roof = roofline_entry(census, ops)
         flops_per_fwd = 0.803e12 if args.model == "sd15" else None
         line = {
             "metric": "guided images/sec (50-step SD-1.5 512^2)", "value": n_images / elapsed, "unit": "images/s",

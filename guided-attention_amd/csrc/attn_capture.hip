@@ -26,47 +26,98 @@ __host__ __device__ constexpr int round16(int x) { return (x + 15) & ~15; }
 
 template <typename T, int NT>
 struct Lds {
-  static constexpr int KP = NT * 16;  // padded key count
-  static constexpr int VS = KP + 4;   // row stride of a transposed [D][key] image
-  __host__ __device__ static int ks(int DP) { return DP + 4; }  // row stride of a [key][D] image
+  static constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte vector
+  static constexpr int KP = NT * 16;          // padded key count
+  // Row strides are padded by one 16-byte vector: every row stays 16-byte aligned for the staging stores,
+  // and the MFMA fragment reads (8 B per lane, 16 rows x 4 k-groups) fall on 64 distinct banks.
+  static constexpr int VS = KP + VEC;                             // transposed [D][key] image
+  __host__ __device__ static int ks(int DP) { return DP + VEC; }  // row-major [key][D] image
+  // The transposed image is written with 2-byte stores by lanes that hold consecutive 16-byte pieces of ONE key
+  // row, i.e. image rows VEC apart: with a plain stride those all fall on two banks (20-way conflict, ~5 us per
+  // workgroup at D = 160).  Row r is therefore shifted by 4 elements per VEC rows, which walks the banks.
+  static constexpr int ROT = 4;
+  __host__ __device__ static int tr(int r) { return r * VS + ROT * (r / VEC); }
+  __host__ __device__ static int tr_size(int DP) { return DP * VS + ROT * (DP / VEC); }
 };
 
-// Stage rows [key][D] of one (batch, head) from the [B][Kt][H][D] projection into LDS, as a row-major
-// image (stride DP+4) and/or a transposed image (stride KP+4); padding keys / columns are zero-filled.
+// Stage one (batch, head) slice [key][D] of a [B][Kt][H][D] projection into LDS as a row-major image and/or a
+// transposed image; padding keys / columns are zero-filled.  All global loads of a pass are issued before the
+// first LDS store (one L2 round trip per pass instead of one per vector); up to two sources share a pass.
 template <typename T, int NT, int NTHREADS>
-__device__ __forceinline__ void stage_kv(const T* __restrict__ src, int H, int Kt, int D, int DP, T* rowmaj,
-                                         T* transposed) {
-  using Tr = Traits<T>;
+__device__ __forceinline__ void stage_kv2(const T* __restrict__ srcA, T* rowA, T* trA, const T* __restrict__ srcB,
+                                          T* rowB, T* trB, int H, int Kt, int D, int DP) {
+  constexpr int VEC = Lds<T, NT>::VEC;
   constexpr int KP = Lds<T, NT>::KP;
-  constexpr int VS = Lds<T, NT>::VS;
+  constexpr int UNROLL = 4;
   const int KS = Lds<T, NT>::ks(DP);
-  const int chunks = DP >> 2;
-  for (int idx = threadIdx.x; idx < KP * chunks; idx += NTHREADS) {
-    const int key = idx / chunks;
-    const int d = (idx - key * chunks) << 2;
-    typename Tr::frag f = zero_frag<T>();
-    if (key < Kt && d < D) f = load_frag<T>(src + (size_t)key * H * D + d);
-    if (rowmaj) store_frag<T>(rowmaj + key * KS + d, f);
-    if (transposed) {
+  const int vpr = DP / VEC;  // vectors per row
+  const int total = KP * vpr;
+  for (int base = 0; base < total; base += NTHREADS * UNROLL) {
+    uint4 a[UNROLL], b[UNROLL];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) transposed[(d + i) * VS + key] = f[i];
+    for (int u = 0; u < UNROLL; ++u) {
+      const int idx = base + u * NTHREADS + threadIdx.x;
+      const int key = idx / vpr;
+      const int d = (idx - key * vpr) * VEC;
+      const bool live = idx < total && key < Kt && d < D;
+      a[u] = uint4{0, 0, 0, 0};
+      b[u] = uint4{0, 0, 0, 0};
+      if (live) {
+        const size_t off = (size_t)key * H * D + d;
+        a[u] = *reinterpret_cast<const uint4*>(srcA + off);
+        if (srcB) b[u] = *reinterpret_cast<const uint4*>(srcB + off);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int idx = base + u * NTHREADS + threadIdx.x;
+      if (idx >= total) continue;
+      const int key = idx / vpr;
+      const int d = (idx - key * vpr) * VEC;
+      if (rowA) *reinterpret_cast<uint4*>(rowA + key * KS + d) = a[u];
+      if (rowB) *reinterpret_cast<uint4*>(rowB + key * KS + d) = b[u];
+      const T* ea = reinterpret_cast<const T*>(&a[u]);
+      const T* eb = reinterpret_cast<const T*>(&b[u]);
+      if (trA) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) trA[Lds<T, NT>::tr(d + i) + key] = ea[i];
+      }
+      if (trB) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) trB[Lds<T, NT>::tr(d + i) + key] = eb[i];
+      }
     }
   }
 }
 
+// NK = number of 16-wide chunks of the (padded) head dimension, a template parameter so that the per-lane
+// fragment arrays are exactly sized and statically indexed (NK = 3 / 5 / 10 for SD-1.x, 4 for SD-2.x / SDXL).
+
+// This lane's operand fragments of one activation row X[q][:] (Q or dO), all loads issued together so that
+// they overlap the K/V staging instead of forming one global round trip per 16-wide chunk.
+template <typename T, int NK>
+__device__ __forceinline__ void load_row_frags(const T* __restrict__ xrow, bool ok, int D, int g,
+                                               typename Traits<T>::frag (&x)[NK]) {
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc) {
+    const int d = (kc << 4) + (g << 2);
+    x[kc] = zero_frag<T>();
+    if (ok && d < D) x[kc] = load_frag<T>(xrow + d);
+  }
+}
+
 // S^T tiles: acc[t][r] = sum_d Kimg[16t + 4g + r][d] * X[q][d]   (X = Q or dO row of this lane's query)
-template <typename T, int NT>
-__device__ __forceinline__ void qk_tiles(const T* __restrict__ xrow, bool ok, const T* kimg, int KS, int D, int DP,
-                                         int c, int g, f32x4 (&acc)[NT]) {
+template <typename T, int NT, int NK>
+__device__ __forceinline__ void qk_tiles(const typename Traits<T>::frag (&x)[NK], const T* kimg, int KS, int c, int g,
+                                         f32x4 (&acc)[NT]) {
   using Tr = Traits<T>;
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int kc = 0; kc < (DP >> 4); ++kc) {
-    const int d = (kc << 4) + (g << 2);
-    typename Tr::frag b = zero_frag<T>();
-    if (ok && d < D) b = load_frag<T>(xrow + d);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = Tr::mma16(load_frag<T>(kimg + (t * 16 + c) * KS + d), b, acc[t]);
+  for (int kc = 0; kc < NK; ++kc) {
+    const int d = (kc << 4) + (g << 2);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = Tr::mma16(load_frag<T>(kimg + (t * 16 + c) * KS + d), x[kc], acc[t]);
   }
 }
 
@@ -100,33 +151,33 @@ __device__ __forceinline__ void softmax_keys(f32x4 (&acc)[NT], int Kt, int g, fl
     for (int r = 0; r < 4; ++r) acc[t][r] *= inv;
 }
 
-template <typename T, int NT, int WAVES>
+template <typename T, int NT, int WAVES, int NK>
 __global__ __launch_bounds__(WAVES * 64) void attn_capture_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                                       const T* __restrict__ V, T* __restrict__ O,
                                                                       T* __restrict__ P, int H, int N, int Kt, int D,
                                                                       int DP, float scale) {
   using Tr = Traits<T>;
   constexpr int KP = Lds<T, NT>::KP;
-  constexpr int VS = Lds<T, NT>::VS;
   constexpr int ROWS = WAVES * 16;
   const int KS = Lds<T, NT>::ks(DP);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Ks = reinterpret_cast<T*>(smem);  // [KP][KS]
   T* Vt = Ks + KP * KS;                // [DP][VS]
-  T* Pst = Vt + DP * VS;               // [ROWS][Kt] (only when P != nullptr)
+  T* Pst = Vt + Lds<T, NT>::tr_size(DP);  // [ROWS][Kt] (only when P != nullptr)
 
   const int b = blockIdx.z, head = blockIdx.y, q_wg = blockIdx.x * ROWS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t kv_off = ((size_t)b * Kt * H + head) * D;
-  stage_kv<T, NT, WAVES * 64>(K + kv_off, H, Kt, D, DP, Ks, nullptr);
-  stage_kv<T, NT, WAVES * 64>(V + kv_off, H, Kt, D, DP, nullptr, Vt);
-  __syncthreads();
-
   const int q = q_wg + wave * 16 + c;
   const bool ok = q < N;
   const size_t row_off = (((size_t)b * N + (ok ? q : 0)) * H + head) * D;
+  typename Tr::frag xq[NK];
+  load_row_frags<T, NK>(Q + row_off, ok, D, g, xq);  // in flight while K/V are staged
+  stage_kv2<T, NT, WAVES * 64>(K + kv_off, Ks, nullptr, V + kv_off, nullptr, Vt, H, Kt, D, DP);
+  __syncthreads();
+
   f32x4 acc[NT];
-  qk_tiles<T, NT>(Q + row_off, ok, Ks, KS, D, DP, c, g, acc);
+  qk_tiles<T, NT, NK>(xq, Ks, KS, c, g, acc);
   softmax_keys<NT>(acc, Kt, g, scale);
 
   typename Tr::frag pf[NT];  // P^T as the B operand of O^T = V^T P^T (and the value stored in P)
@@ -147,10 +198,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_fwd_kernel(const T* _
   }
 
   T* orow = O + row_off;
-  for (int dt = 0; dt < (DP >> 4); ++dt) {
+  for (int dt = 0; dt < NK; ++dt) {
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NT; ++t) o = Tr::mma16(load_frag<T>(Vt + (dt * 16 + c) * VS + t * 16 + 4 * g), pf[t], o);
+    for (int t = 0; t < NT; ++t) o = Tr::mma16(load_frag<T>(Vt + Lds<T, NT>::tr(dt * 16 + c) + t * 16 + 4 * g), pf[t], o);
     const int d = (dt << 4) + (g << 2);  // o[r] = O[q][d + r]
     if (ok && d < D) {
       typename Tr::frag of;
@@ -178,14 +229,13 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_fwd_kernel(const T* _
   }
 }
 
-template <typename T, int NT, int WAVES>
+template <typename T, int NT, int WAVES, int NK>
 __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
     const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ V, const T* __restrict__ dO,
     const T* __restrict__ dP, long long dP_sb, long long dP_sn, T* __restrict__ dQ, int H, int N, int Kt, int D, int DP,
     float scale) {
   using Tr = Traits<T>;
   constexpr int KP = Lds<T, NT>::KP;
-  constexpr int VS = Lds<T, NT>::VS;
   constexpr int ROWS = WAVES * 16;
   const int KS = Lds<T, NT>::ks(DP);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -196,17 +246,19 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
   const int b = blockIdx.z, head = blockIdx.y, q_wg = blockIdx.x * ROWS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t kv_off = ((size_t)b * Kt * H + head) * D;
-  stage_kv<T, NT, WAVES * 64>(K + kv_off, H, Kt, D, DP, Ks, Ktr);
-  stage_kv<T, NT, WAVES * 64>(V + kv_off, H, Kt, D, DP, Vs, nullptr);
-  __syncthreads();
-
   const int q = q_wg + wave * 16 + c;
   const bool ok = q < N;
   const size_t row_off = (((size_t)b * N + (ok ? q : 0)) * H + head) * D;
+  typename Tr::frag xq[NK], xdo[NK];
+  load_row_frags<T, NK>(Q + row_off, ok, D, g, xq);
+  load_row_frags<T, NK>(dO + row_off, ok, D, g, xdo);
+  stage_kv2<T, NT, WAVES * 64>(K + kv_off, Ks, Ktr, V + kv_off, Vs, nullptr, H, Kt, D, DP);
+  __syncthreads();
+
   f32x4 p[NT], dp[NT];
-  qk_tiles<T, NT>(Q + row_off, ok, Ks, KS, D, DP, c, g, p);
-  softmax_keys<NT>(p, Kt, g, scale);                          // identical instruction sequence to the forward
-  qk_tiles<T, NT>(dO + row_off, ok, Vs, KS, D, DP, c, g, dp);  // dP^T[key][q] = sum_d V[key][d] dO[q][d]
+  qk_tiles<T, NT, NK>(xq, Ks, KS, c, g, p);
+  softmax_keys<NT>(p, Kt, g, scale);           // identical instruction sequence to the forward
+  qk_tiles<T, NT, NK>(xdo, Vs, KS, c, g, dp);  // dP^T[key][q] = sum_d V[key][d] dO[q][d]
 
   if (dP != nullptr && ok) {
     const T* src = dP + (long long)(b * H + head) * dP_sb + (long long)q * dP_sn;
@@ -258,10 +310,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
     for (int r = 0; r < 4; ++r) dsf[t][r] = Tr::from_f32(p[t][r]);
 
   T* orow = dQ + row_off;
-  for (int dt = 0; dt < (DP >> 4); ++dt) {
+  for (int dt = 0; dt < NK; ++dt) {
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NT; ++t) o = Tr::mma16(load_frag<T>(Ktr + (dt * 16 + c) * VS + t * 16 + 4 * g), dsf[t], o);
+    for (int t = 0; t < NT; ++t) o = Tr::mma16(load_frag<T>(Ktr + Lds<T, NT>::tr(dt * 16 + c) + t * 16 + 4 * g), dsf[t], o);
     const int d = (dt << 4) + (g << 2);
     if (ok && d < D) {
       typename Tr::frag of;
@@ -274,12 +326,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
 
 template <typename T, int NT>
 size_t fwd_lds_bytes(int DP, int Kt, int waves, bool withP) {
-  return sizeof(T) * ((size_t)Lds<T, NT>::KP * Lds<T, NT>::ks(DP) + (size_t)DP * Lds<T, NT>::VS +
+  return sizeof(T) * ((size_t)Lds<T, NT>::KP * Lds<T, NT>::ks(DP) + (size_t)Lds<T, NT>::tr_size(DP) +
                       (withP ? (size_t)waves * 16 * Kt : 0));
 }
 template <typename T, int NT>
 size_t bwd_lds_bytes(int DP) {
-  return sizeof(T) * (2 * (size_t)Lds<T, NT>::KP * Lds<T, NT>::ks(DP) + (size_t)DP * Lds<T, NT>::VS);
+  return sizeof(T) * (2 * (size_t)Lds<T, NT>::KP * Lds<T, NT>::ks(DP) + (size_t)Lds<T, NT>::tr_size(DP));
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -292,56 +344,76 @@ int set_dyn_lds(KernelT kernel, size_t bytes) {
   return e == hipSuccess ? GA_OK : GA_ERR_LAUNCH;
 }
 
-int pick_waves(int B, int H, int N) {
-  // a launch wants >= 256 workgroups (one per CU); 4-wave groups amortise the K/V staging
-  const long long wg4 = (long long)((N + 63) / 64) * H * B;
-  return wg4 >= 256 ? 4 : 1;
+// Dispatch on NK = ceil(D / 16): exact instantiations for the head sizes of SD-1.x (40, 80, 160), SD-2.x / SDXL
+// (64) and small test sizes; anything else runs the next larger instantiation with zero-padded chunks.
+template <typename T, int NT, int NK>
+int launch_fwd_nk(const void* Q, const void* K, const void* V, void* O, void* P, int B, int H, int N, int Kt, int D,
+                  float scale, hipStream_t s) {
+  const int DP = NK * 16;
+  const size_t lds = fwd_lds_bytes<T, NT>(DP, Kt, 4, P != nullptr);
+  if (lds > kLdsLimit) return GA_ERR_SHAPE;
+  dim3 grid((N + 63) / 64, H, B);
+  auto k = attn_capture_fwd_kernel<T, NT, 4, NK>;
+  int rc = set_dyn_lds(k, lds);
+  if (rc != GA_OK) return rc;
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)Q, (const T*)K, (const T*)V, (T*)O, (T*)P, H, N, Kt, D, DP,
+                     scale);
+  return check_launch();
 }
+
+template <typename T, int NT, int NK>
+int launch_bwd_nk(const void* Q, const void* K, const void* V, const void* dO, const void* dP, int64_t sb, int64_t sn,
+                  void* dQ, int B, int H, int N, int Kt, int D, float scale, hipStream_t s) {
+  const int DP = NK * 16;
+  const size_t lds = bwd_lds_bytes<T, NT>(DP);
+  if (lds > kLdsLimit) return GA_ERR_SHAPE;
+  dim3 grid((N + 63) / 64, H, B);
+  auto k = attn_capture_bwd_kernel<T, NT, 4, NK>;
+  int rc = set_dyn_lds(k, lds);
+  if (rc != GA_OK) return rc;
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)Q, (const T*)K, (const T*)V, (const T*)dO, (const T*)dP,
+                     (long long)sb, (long long)sn, (T*)dQ, H, N, Kt, D, DP, scale);
+  return check_launch();
+}
+
+#define GA_NK_DISPATCH_COARSE(CALL)          \
+  do {                                       \
+    const int nk = (D + 15) / 16;            \
+    if (nk <= 2) return CALL(2);             \
+    if (nk <= 4) return CALL(4);             \
+    if (nk <= 8) return CALL(8);             \
+    return CALL(16);                         \
+  } while (0)
+
+#define GA_NK_DISPATCH(CALL)                 \
+  do {                                       \
+    const int nk = (D + 15) / 16;            \
+    if (nk <= 1) return CALL(1);             \
+    if (nk == 2) return CALL(2);             \
+    if (nk == 3) return CALL(3);             \
+    if (nk == 4) return CALL(4);             \
+    if (nk == 5) return CALL(5);             \
+    if (nk <= 8) return CALL(8);             \
+    if (nk <= 10) return CALL(10);           \
+    return CALL(16);                         \
+  } while (0)
 
 template <typename T, int NT>
 int launch_fwd(const void* Q, const void* K, const void* V, void* O, void* P, int B, int H, int N, int Kt, int D,
                float scale, hipStream_t s) {
-  const int DP = round16(D);
-  const int waves = pick_waves(B, H, N);
-  const size_t lds = fwd_lds_bytes<T, NT>(DP, Kt, waves, P != nullptr);
-  if (lds > kLdsLimit) return GA_ERR_SHAPE;
-  dim3 grid((N + waves * 16 - 1) / (waves * 16), H, B);
-  int rc;
-  if (waves == 4) {
-    auto k = attn_capture_fwd_kernel<T, NT, 4>;
-    if ((rc = set_dyn_lds(k, lds)) != GA_OK) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)Q, (const T*)K, (const T*)V, (T*)O, (T*)P, H, N, Kt, D, DP,
-                       scale);
-  } else {
-    auto k = attn_capture_fwd_kernel<T, NT, 1>;
-    if ((rc = set_dyn_lds(k, lds)) != GA_OK) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(64), lds, s, (const T*)Q, (const T*)K, (const T*)V, (T*)O, (T*)P, H, N, Kt, D, DP,
-                       scale);
-  }
-  return check_launch();
+#define GA_CALL(NKV) launch_fwd_nk<T, NT, NKV>(Q, K, V, O, P, B, H, N, Kt, D, scale, s)
+  if (NT != 5) GA_NK_DISPATCH_COARSE(GA_CALL);  // 81..128 keys: fewer instantiations
+  GA_NK_DISPATCH(GA_CALL);
+#undef GA_CALL
 }
 
 template <typename T, int NT>
 int launch_bwd(const void* Q, const void* K, const void* V, const void* dO, const void* dP, int64_t sb, int64_t sn,
                void* dQ, int B, int H, int N, int Kt, int D, float scale, hipStream_t s) {
-  const int DP = round16(D);
-  const int waves = pick_waves(B, H, N);
-  const size_t lds = bwd_lds_bytes<T, NT>(DP);
-  if (lds > kLdsLimit) return GA_ERR_SHAPE;
-  dim3 grid((N + waves * 16 - 1) / (waves * 16), H, B);
-  int rc;
-  if (waves == 4) {
-    auto k = attn_capture_bwd_kernel<T, NT, 4>;
-    if ((rc = set_dyn_lds(k, lds)) != GA_OK) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)Q, (const T*)K, (const T*)V, (const T*)dO, (const T*)dP,
-                       (long long)sb, (long long)sn, (T*)dQ, H, N, Kt, D, DP, scale);
-  } else {
-    auto k = attn_capture_bwd_kernel<T, NT, 1>;
-    if ((rc = set_dyn_lds(k, lds)) != GA_OK) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(64), lds, s, (const T*)Q, (const T*)K, (const T*)V, (const T*)dO, (const T*)dP,
-                       (long long)sb, (long long)sn, (T*)dQ, H, N, Kt, D, DP, scale);
-  }
-  return check_launch();
+#define GA_CALL(NKV) launch_bwd_nk<T, NT, NKV>(Q, K, V, dO, dP, sb, sn, dQ, B, H, N, Kt, D, scale, s)
+  if (NT != 5) GA_NK_DISPATCH_COARSE(GA_CALL);
+  GA_NK_DISPATCH(GA_CALL);
+#undef GA_CALL
 }
 
 int check_common(int B, int H, int N, int Kt, int D) {

@@ -15,37 +15,73 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-# Optional per-launch timing (bench.py): HIP events recorded on the launch stream around a kernel.
-_TIMING = None
+# Optional launch census (bench.py): which shapes each capture kernel was launched with, and how often.
+# Per-launch HIP events are useless while the host is the bottleneck (the event pair brackets host gaps),
+# so bench.py replays each recorded shape back-to-back between two events instead (replay_launch_us).
+_CENSUS = None
 
 
-def start_timing():
-    global _TIMING
-    _TIMING = {}
+def start_census():
+    global _CENSUS
+    _CENSUS = {}
 
 
-def stop_timing():
-    """-> {key: [milliseconds per launch]}; synchronises once, at the end."""
-    global _TIMING
-    rec, _TIMING = _TIMING, None
-    torch.cuda.synchronize()
-    return {k: [a.elapsed_time(b) for a, b in v] for k, v in (rec or {}).items()}
+def stop_census():
+    global _CENSUS
+    rec, _CENSUS = _CENSUS, None
+    return rec or {}
 
 
-class _timed:
-    def __init__(self, key):
-        self.key = key
+def _count(key):
+    if _CENSUS is not None:
+        _CENSUS[key] = _CENSUS.get(key, 0) + 1
 
-    def __enter__(self):
-        if _TIMING is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
 
-    def __exit__(self, *exc):
-        if _TIMING is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            _TIMING.setdefault(self.key, []).append((self.e0, e1))
+def replay_launch_us(key, iters=200):
+    """Average duration (us) of one launch of a recorded capture-kernel shape, inputs resident in HBM:
+    `iters` launches captured into one hipGraph (no host in the loop: a Python-driven loop is launch-bound at
+    ~10 us per call and hides the kernel time), replayed between two HIP events on the launch stream."""
+    kind, B, H, N, Kt, D, flag, dt = key
+    dtype = {"torch.float16": torch.float16, "torch.bfloat16": torch.bfloat16, "torch.float32": torch.float32}[dt]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    q = torch.randn(B, N, H * D, device=dev, dtype=dtype)
+    k = torch.randn(B, Kt, H * D, device=dev, dtype=dtype)
+    v = torch.randn(B, Kt, H * D, device=dev, dtype=dtype)
+    out = torch.empty_like(q)
+    code, scale = dtype_code(q), D ** -0.5
+    lib = load()
+    if kind == "attn_capture_fwd":
+        probs = torch.empty(B * H, N, Kt, device=dev, dtype=dtype) if flag else None
+
+        def fn():
+            check(lib.ga_attn_capture_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(probs), B, H, N, Kt, D, scale,
+                                          code, stream_ptr()), "replay fwd")
+    else:
+        d_o = torch.randn_like(q)
+        dp = torch.randn(N, Kt, device=dev, dtype=dtype) * 1e-3 if flag else None
+
+        def fn():
+            check(lib.ga_attn_capture_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(d_o), _ptr(dp), 0, Kt, _ptr(out), None, None,
+                                          B, H, N, Kt, D, scale, code, stream_ptr()), "replay bwd")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(iters):
+                fn()
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        side.synchronize()
+        e0.record(side)
+        graph.replay()
+        e1.record(side)
+        side.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
+    return e0.elapsed_time(e1) * 1e3 / iters
 
 
 # --------------------------------------------------------------------------------------- K1
@@ -58,9 +94,9 @@ def attn_capture_fwd(q, k, v, heads, scale, want_probs):
     D = C // heads
     o = torch.empty_like(q)
     probs = torch.empty((B * heads, N, Kt), dtype=q.dtype, device=q.device) if want_probs else None
-    with _timed(("attn_capture_fwd", B, heads, N, Kt, D, bool(want_probs), str(q.dtype))):
-        check(load().ga_attn_capture_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(probs), B, heads, N, Kt, D,
-                                         float(scale), dtype_code(q), stream_ptr()), "ga_attn_capture_fwd")
+    _count(("attn_capture_fwd", B, heads, N, Kt, D, bool(want_probs), str(q.dtype)))
+    check(load().ga_attn_capture_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(probs), B, heads, N, Kt, D,
+                                     float(scale), dtype_code(q), stream_ptr()), "ga_attn_capture_fwd")
     return o, probs
 
 
@@ -79,10 +115,10 @@ def attn_capture_bwd(q, k, v, d_o, d_probs, heads, scale):
             d_probs = d_probs.contiguous()
         sb, sn = d_probs.stride(0), d_probs.stride(1)
     dq = torch.empty_like(q)
-    with _timed(("attn_capture_bwd", B, heads, N, Kt, C // heads, d_probs is not None, str(q.dtype))):
-        check(load().ga_attn_capture_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(d_o), _ptr(d_probs), sb, sn, _ptr(dq), None,
-                                         None, B, heads, N, Kt, C // heads, float(scale), dtype_code(q), stream_ptr()),
-              "ga_attn_capture_bwd")
+    _count(("attn_capture_bwd", B, heads, N, Kt, C // heads, d_probs is not None, str(q.dtype)))
+    check(load().ga_attn_capture_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(d_o), _ptr(d_probs), sb, sn, _ptr(dq), None, None,
+                                     B, heads, N, Kt, C // heads, float(scale), dtype_code(q), stream_ptr()),
+          "ga_attn_capture_bwd")
     return dq
 
 
