@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--guidance-forward", default="full", choices=["full", "truncated"])
     ap.add_argument("--skip-unused-guidance", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying hipGraphs")
     return ap.parse_args()
 
 
@@ -61,6 +62,7 @@ def build_pipeline(args, device, rank, world):
     pipe.to(device, torch.float16)
     pipe.guidance_forward = args.guidance_forward
     pipe.skip_unused_guidance = args.skip_unused_guidance
+    pipe.use_graphs = not args.eager
     return pipe, cfg, {"messages": n_msgs, "seconds": bcast_s}
 
 
@@ -243,6 +245,7 @@ def main():
                                    f"meta_prompt '{META_PROMPT}', guidance 7.5, thresholds {rc.thresholds}, 1 seed per step",
                        "parallelism": f"seed-parallel x{world}", "guidance_forward": args.guidance_forward,
                        "skip_unused_guidance": args.skip_unused_guidance, "model": args.model,
+                       "launch": "eager" if args.eager else "hipGraph replay of the UNet passes (captured in warm-up)",
                        "weights": "seeded random init (no checkpoint offline)"},
             "unet_calls_per_image": calls, "finite": ok,
             "weight_broadcast": bcast,

@@ -14,6 +14,9 @@
 // Q, dO are read straight from the projection layout [B][N][H][D] (no head transpose copies) and
 // O, dQ are written back in it; P leaves through an LDS staging tile as 16-byte coalesced stores.
 // The kernels are HBM/L2-bound (about 26 FLOP/B), so MFMA shape efficiency is not the concern.
+#include <mutex>
+#include <unordered_map>
+
 #include "ga_common.h"
 
 using namespace ga;
@@ -336,12 +339,21 @@ size_t bwd_lds_bytes(int DP) {
 
 constexpr size_t kLdsLimit = 160 * 1024;
 
+// Raise a kernel's dynamic-LDS limit above the 64 KB default; remembered per kernel so that the runtime call
+// happens on the first (eager, warm-up) launch only and never inside a stream capture.
 template <typename KernelT>
 int set_dyn_lds(KernelT kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return GA_OK;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  return e == hipSuccess ? GA_OK : GA_ERR_LAUNCH;
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> granted;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = granted.find(fn);
+  if (it != granted.end() && it->second >= bytes) return GA_OK;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return GA_ERR_LAUNCH;
+  granted[fn] = bytes;
+  return GA_OK;
 }
 
 // Dispatch on NK = ceil(D / 16): exact instantiations for the head sizes of SD-1.x (40, 80, 160), SD-2.x / SDXL

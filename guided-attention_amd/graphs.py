@@ -1,0 +1,118 @@
+"""hipGraph capture of the UNet passes of the guided-attention loop.
+
+A batch-1 UNet pass is ~1000 kernel launches of 5-15 us each; issued eagerly the host is the
+bottleneck.  The three passes of the loop are therefore captured ONCE per (shapes, prompt plan) into
+HIP graphs and replayed:
+    g_eval : latents -> UNet forward with the capture kernels -> aggregate -> smoothed box loss   (autograd on)
+    g_grad : autograd backward of that loss to the latents (replays against g_eval's saved activations)
+    g_cfg  : the no-grad CFG forward on [latents, latents]
+Host control flow (thresholds, refinement, recurse) stays in Python between replays; scalars that change
+per step (timestep) live in static device tensors, per-step kernel scalars (step size, alphas) stay in
+the eager one-launch kernels around the graphs.  The kernels inside the graphs are exactly the eager
+ones (same C-ABI calls on the capture stream).
+"""
+import torch
+
+from . import ops
+from .utils.ptp_utils import aggregate_attention
+
+
+class GraphRunner:
+    @classmethod
+    def for_run(cls, pipe, store, prompt_embeds, latents, attention_res, smooth, sigma, ksize, normalize_eot):
+        plan = pipe._loss_plan(smooth, sigma, ksize)
+        key = (tuple(latents.shape), latents.dtype, tuple(prompt_embeds.shape), pipe._plan_key, attention_res,
+               pipe.guidance_forward, normalize_eot, str(pipe.prompt) if normalize_eot else None,
+               getattr(store, "capture", None))
+        runner = pipe._graph_cache.get(key)
+        if runner is None:
+            pipe._graph_cache.clear()  # one live configuration: the pools hold every activation of both passes
+            runner = cls(pipe, store, prompt_embeds, latents, attention_res, smooth, sigma, ksize, normalize_eot)
+            pipe._graph_cache[key] = runner
+        runner.embeds.copy_(prompt_embeds)
+        return runner
+
+    def __init__(self, pipe, store, prompt_embeds, latents, attention_res, smooth, sigma, ksize, normalize_eot):
+        self.pipe = pipe
+        dev = latents.device
+        self.t_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.embeds = prompt_embeds.detach().clone()
+        self.lat_g = torch.zeros_like(latents).requires_grad_(True)
+        self.lat2 = torch.zeros((2,) + tuple(latents.shape[1:]), dtype=latents.dtype, device=dev)
+        self.loss_args = (smooth, sigma, ksize, normalize_eot)
+        self.res = attention_res
+        self._capture(store)
+
+    # -- bodies (run eagerly for warm-up, then once more under capture)
+    def _eval_body(self, store):
+        pipe = self.pipe
+        with torch.enable_grad():
+            pipe._guidance_forward(self.lat_g, self.t_dev, self.embeds[1:2])
+            A = aggregate_attention(store, self.res, ("up", "down", "mid"), True, 0)
+            parts = pipe._loss_device(A, *self.loss_args)
+        return parts, store.attention_store
+
+    def _grad_body(self, loss):
+        with torch.enable_grad():
+            return torch.autograd.grad(loss, [self.lat_g], retain_graph=True)[0]
+
+    def _cfg_body(self, store):
+        with torch.no_grad():
+            out = self.pipe.unet(self.lat2, self.t_dev, encoder_hidden_states=self.embeds).sample
+        return out, store.attention_store
+
+    def _capture(self, store):
+        calls = dict(self.pipe.unet_calls)
+        self.t_dev.fill_(981)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up: library algorithm selection and workspace allocation happen here
+                parts, _ = self._eval_body(store)
+                self._grad_body(parts[1])
+                self._cfg_body(store)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g_eval = torch.cuda.CUDAGraph()
+        with ops.census_scope() as c_eval, torch.cuda.graph(self.g_eval):
+            self.parts, self.store_eval = self._eval_body(store)
+        self.loss = self.parts[1]
+        self.g_grad = torch.cuda.CUDAGraph()
+        with ops.census_scope() as c_grad, torch.cuda.graph(self.g_grad, pool=self.g_eval.pool()):
+            self.grad = self._grad_body(self.loss)
+        self.g_cfg = torch.cuda.CUDAGraph()
+        with ops.census_scope() as c_cfg, torch.cuda.graph(self.g_cfg, pool=self.g_eval.pool()):
+            self.noise, self.store_cfg = self._cfg_body(store)
+        self.launches = {"eval": c_eval.launches, "grad": c_grad.launches, "cfg": c_cfg.launches}
+        torch.cuda.synchronize()
+        self.pipe.unet_calls.update(calls)  # capture / warm-up passes are not image work
+
+    # -- replays
+    def _publish(self, store, snapshot):
+        if store is not None and hasattr(store, "attention_store"):
+            store.attention_store = snapshot  # "the maps of the most recent forward", as after an eager pass
+            store.cur_step += 1
+
+    def evaluate(self, latents, t, store):
+        self.t_dev.fill_(int(t))
+        with torch.no_grad():
+            self.lat_g.copy_(latents)
+        self.g_eval.replay()
+        ops.add_census(self.launches["eval"])
+        self._publish(store, self.store_eval)
+        return self.lat_g, self.parts
+
+    def backward(self):
+        self.g_grad.replay()
+        ops.add_census(self.launches["grad"])
+        return self.grad
+
+    def cfg_forward(self, latents, t, store):
+        self.t_dev.fill_(int(t))
+        self.lat2[0].copy_(latents[0])
+        self.lat2[1].copy_(latents[0])
+        self.g_cfg.replay()
+        ops.add_census(self.launches["cfg"])
+        self._publish(store, self.store_cfg)
+        return self.noise

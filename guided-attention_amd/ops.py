@@ -37,6 +37,26 @@ def _count(key):
         _CENSUS[key] = _CENSUS.get(key, 0) + 1
 
 
+class census_scope:
+    """Collect the launches made inside the block into `.launches` (used while a hipGraph is captured, so that
+    each replay can be accounted with `add_census`)."""
+
+    def __enter__(self):
+        global _CENSUS
+        self._outer, _CENSUS = _CENSUS, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _CENSUS
+        self.launches, _CENSUS = _CENSUS, self._outer
+
+
+def add_census(launches):
+    if _CENSUS is not None:
+        for key, n in launches.items():
+            _CENSUS[key] = _CENSUS.get(key, 0) + n
+
+
 def replay_launch_us(key, iters=200):
     """Average duration (us) of one launch of a recorded capture-kernel shape, inputs resident in HBM:
     `iters` launches captured into one hipGraph (no host in the loop: a Python-driven loop is launch-bound at

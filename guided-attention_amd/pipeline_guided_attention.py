@@ -54,6 +54,11 @@ class GuidedAttention:
         # False keeps the reference's behaviour of evaluating the guidance pass + loss on every step even when
         # no update can follow (steps outside `thresholds` with only_update_on_threshold_steps): log-only work.
         self.skip_unused_guidance = False
+        # True: the two UNet passes are captured once into hipGraphs (guidance forward + loss, its backward, the CFG
+        # forward) and replayed — same kernels, no per-launch host work.  False: eager launches.
+        self.use_graphs = False
+        self._runner = None
+        self._graph_cache = {}
         self.unet_calls = {"fwd_b1_grad": 0, "bwd": 0, "fwd_b2": 0, "loss_evals": 0}
         self._plan_key = None
         self._plan = None
@@ -205,10 +210,8 @@ class GuidedAttention:
             self._plan_key = key
         return self._plan
 
-    def _compute_max_attention_per_index(self, attention_maps, smooth_attentions=False, sigma=0.5, kernel_size=3,
-                                         normalize_eot=False):
-        """attention_maps (res, res, n_tokens) f32 -> losses_dict with the reference's keys (each a list with one
-        entry per guided token) plus the fused results of ga_smooth_loss_fwd."""
+    def _loss_device(self, attention_maps, smooth_attentions, sigma, kernel_size, normalize_eot):
+        """Device half of the loss evaluation (graph-capturable: no host sync): -> (terms, loss, custom, plan)."""
         res, n_tok = attention_maps.shape[0], attention_maps.shape[-1]
         last_idx = n_tok - 1
         if normalize_eot:
@@ -216,22 +219,35 @@ class GuidedAttention:
             last_idx = len(self.tokenizer(prompt)["input_ids"]) - 1
         plan = self._loss_plan(smooth_attentions, sigma, kernel_size)
         terms, loss = ops.SmoothLoss.apply(attention_maps.reshape(res * res, n_tok), res, 1, last_idx, plan)
+        custom = None
+        if hasattr(state.config, "custom_loss") and state.config.custom_loss:
+            text_maps = torch.softmax(attention_maps[:, :, 1:last_idx] * 100, dim=-1)
+            for _name, (fn, args) in state.config.custom_loss.items():
+                v = fn.calc_loss(text_maps, args)
+                custom = v if custom is None else custom + v
+        packed = torch.cat([terms.detach().reshape(-1), loss.detach()])
+        return terms, loss, custom, plan, packed
+
+    def _loss_host(self, terms, loss, custom, plan, packed):
+        """Host half: the one device sync per evaluation (the thresholds need the values), then the reference's
+        `losses_dict` keys (one entry per guided token) plus the fused results."""
         self.unet_calls["loss_evals"] += 1
-        host = torch.cat([terms.detach().reshape(-1), loss.detach()]).cpu()  # the one device sync per evaluation
+        host = packed.cpu()
         host_terms = host[:-1].view(plan.T, -1)
         losses_dict = {k: [terms[t, c] for t in range(plan.T)] for k, c in TERM.items() if c < 5}
         losses_dict["_fused"] = {"loss": loss, "host_terms": host_terms, "host_loss": host[-1:], "plan": plan}
-        if hasattr(state.config, "custom_loss") and state.config.custom_loss:
-            text_maps = torch.softmax(attention_maps[:, :, 1:last_idx] * 100, dim=-1)
-            total = None
-            for _name, (fn, args) in state.config.custom_loss.items():
-                v = fn.calc_loss(text_maps, args)
-                total = v if total is None else total + v
-            losses_dict["custom_loss"] = total
+        if custom is not None:
+            losses_dict["custom_loss"] = custom
         for t, e in enumerate(plan.entries):
             word = state.config.token_dict[e["index"]]["word"]
             helpers.log(f"{word}: weighted center col {host_terms[t, 1].item()} row {host_terms[t, 2].item()}")
         return losses_dict
+
+    def _compute_max_attention_per_index(self, attention_maps, smooth_attentions=False, sigma=0.5, kernel_size=3,
+                                         normalize_eot=False):
+        """attention_maps (res, res, n_tokens) f32 -> losses_dict with the reference's keys plus the fused
+        results of ga_smooth_loss_fwd (reference :201-296)."""
+        return self._loss_host(*self._loss_device(attention_maps, smooth_attentions, sigma, kernel_size, normalize_eot))
 
     def _aggregate_and_get_max_attention_per_token(self, attention_store, attention_res=16, smooth_attentions=False,
                                                    sigma=0.5, kernel_size=3, normalize_eot=False):
@@ -306,7 +322,11 @@ class GuidedAttention:
     def _update_latent(self, latents, loss, step_size):
         """latents - step_size * dLoss/dlatents (reference :456-470): autograd back through the UNet
         (K1 / K3+K4 backward kernels inside), then the fused axpy + mean|grad| kernel."""
-        grad_cond = torch.autograd.grad(loss.requires_grad_(True), [latents], retain_graph=True)[0]
+        runner = self._runner
+        if runner is not None and loss is runner.loss:
+            grad_cond = runner.backward()  # hipGraph replay of the captured backward pass
+        else:
+            grad_cond = torch.autograd.grad(loss.requires_grad_(True), [latents], retain_graph=True)[0]
         self.unet_calls["bwd"] += 1
         new_latents, absmean = ops.latent_axpy(latents.detach(), grad_cond, float(step_size), True)
         self._deferred_log.append(("gradient size average: ", absmean))
@@ -320,6 +340,22 @@ class GuidedAttention:
                 self._attention_store.flush()
             return out
         return self.unet(latents, t, encoder_hidden_states=cond).sample
+
+    def _guidance_eval(self, latents, t, cond, attention_store, attention_res, smooth_attentions, sigma, kernel_size,
+                       normalize_eot):
+        """One guidance evaluation = restart the autograd graph at the latents, UNet forward with capture,
+        aggregate, loss.  -> (latents leaf the loss depends on, losses_dict).  Eager, or one hipGraph replay."""
+        runner = self._runner
+        if runner is not None:
+            self.unet_calls["fwd_b1_grad"] += 1
+            leaf, parts = runner.evaluate(latents, t, attention_store)
+            return leaf, self._loss_host(*parts)
+        latents = latents.clone().detach().requires_grad_(True)
+        self._guidance_forward(latents, t, cond)
+        losses_dict = self._aggregate_and_get_max_attention_per_token(
+            attention_store=attention_store, attention_res=attention_res, smooth_attentions=smooth_attentions,
+            sigma=sigma, kernel_size=kernel_size, normalize_eot=normalize_eot)
+        return latents, losses_dict
 
     def _perform_iterative_refinement_step(self, latents, loss, threshold, text_embeddings, text_input,
                                            attention_store, step_size, t, attention_res=16, smooth_attentions=True,
@@ -338,22 +374,18 @@ class GuidedAttention:
             helpers.log(f"subiteration: {iteration}")
             iteration += 1
             state.sub_iteration = iteration
-            latents = latents.clone().detach().requires_grad_(True)  # restart the graph
-            self._guidance_forward(latents, t, text_embeddings[1].unsqueeze(0))
-            losses_dict = self._aggregate_and_get_max_attention_per_token(
-                attention_store=attention_store, attention_res=attention_res, smooth_attentions=smooth_attentions,
-                sigma=sigma, kernel_size=kernel_size, normalize_eot=normalize_eot)
+            latents, losses_dict = self._guidance_eval(  # restarts the graph at the latents
+                latents, t, text_embeddings[1].unsqueeze(0), attention_store, attention_res, smooth_attentions, sigma,
+                kernel_size, normalize_eot)
             loss, losses, unscaled_losses = self._compute_loss(losses_dict, return_losses=True)
             if losses_dict["_fused"]["host_loss"].item() != 0 or "custom_loss" in losses_dict:
                 latents = self._update_latent(latents, loss, step_size)
             if iteration >= max_refinement_steps:
                 helpers.log(f"\t Exceeded max number of iterations ({max_refinement_steps})! ", self.verbose)
                 break
-        latents = latents.clone().detach().requires_grad_(True)
-        self._guidance_forward(latents, t, text_embeddings[1].unsqueeze(0))
-        max_attention_per_index = self._aggregate_and_get_max_attention_per_token(
-            attention_store=attention_store, attention_res=attention_res, smooth_attentions=smooth_attentions,
-            sigma=sigma, kernel_size=kernel_size, normalize_eot=normalize_eot)
+        latents, max_attention_per_index = self._guidance_eval(
+            latents, t, text_embeddings[1].unsqueeze(0), attention_store, attention_res, smooth_attentions, sigma,
+            kernel_size, normalize_eot)
         loss, losses, unscaled_losses = self._compute_loss(max_attention_per_index, return_losses=True)
         helpers.log(f"\t Finished with loss of: {max_attention_per_index['_fused']['host_loss'].item()} "
                     f"iter: {iteration}", self.verbose)
@@ -425,6 +457,11 @@ class GuidedAttention:
         self._truncate_at = self._truncation_point(attention_res, height, width)
         cond = prompt_embeds[1:2] if do_cfg else prompt_embeds[0:1]
         guided = bool(getattr(state.config, "token_dict", None)) or bool(getattr(state.config, "custom_loss", None))
+        self._runner = None
+        if self.use_graphs and do_cfg and guided and not run_standard_sd:
+            from .graphs import GraphRunner
+            self._runner = GraphRunner.for_run(self, attention_store, prompt_embeds, latents, attention_res,
+                                               smooth_attentions, sigma, kernel_size, sd_2_1)
 
         for i, t in enumerate(timesteps):
             t_int = int(t)
@@ -442,12 +479,9 @@ class GuidedAttention:
                         self._guidance_forward(latents, t_int, cond)
                 elif not (self.skip_unused_guidance and (run_standard_sd or not may_update)):
                     with torch.enable_grad():
-                        latents = latents.clone().detach().requires_grad_(True)
-                        self._guidance_forward(latents, t_int, cond)
-                        max_attention_per_index = self._aggregate_and_get_max_attention_per_token(
-                            attention_store=attention_store, attention_res=attention_res,
-                            smooth_attentions=smooth_attentions, sigma=sigma, kernel_size=kernel_size,
-                            normalize_eot=sd_2_1)
+                        latents, max_attention_per_index = self._guidance_eval(
+                            latents, t_int, cond, attention_store, attention_res, smooth_attentions, sigma,
+                            kernel_size, sd_2_1)
                         if not run_standard_sd:
                             loss, losses, unscaled_losses = self._compute_loss(losses_dict=max_attention_per_index)
                             if not self.meets_threshold(i, thresholds, unscaled_losses):
@@ -477,7 +511,10 @@ class GuidedAttention:
                 model_in = torch.cat([latents] * 2) if do_cfg else latents
                 model_in = self.scheduler.scale_model_input(model_in, t_int)
                 self.unet_calls["fwd_b2"] += 1
-                noise_pred = self.unet(model_in, t_int, encoder_hidden_states=prompt_embeds).sample
+                if self._runner is not None and do_cfg:
+                    noise_pred = self._runner.cfg_forward(latents, t_int, attention_store)
+                else:
+                    noise_pred = self.unet(model_in, t_int, encoder_hidden_states=prompt_embeds).sample
                 if do_cfg:
                     eps_uncond, eps_text = noise_pred.chunk(2)
                     latents, _x0 = ops.cfg_ddim_step(eps_uncond, eps_text, guidance_scale, latents, a_t, a_prev)
