@@ -1,0 +1,379 @@
+// GroupNorm (+ fused SiLU) for channels-last activations, forward and backward-to-input.
+//
+// Host-side UNet helper (reference: the diffusers ResnetBlock2D / Transformer2DModel GroupNorm + SiLU pairs
+// inside the UNet forward, pipeline_guided_attention.py:583-743).  PyTorch's GroupNorm runs three kernels plus a
+// separate SiLU, and returns an NCHW tensor even for a channels-last input, which makes MIOpen transpose
+// around every following convolution.  This pair of kernels keeps NHWC end to end:
+//   stats : one workgroup per (image, pixel block): coalesced row reads (4 B = 2 channels per lane; every
+//           channel pair lies in one group because C/G is even), per-thread sums, fixed-order LDS reduction
+//           to per-group partial (sum, sum of squares)                       -> workspace [B][NB][G][2]
+//   apply : folds the <= 32 partials (fixed order), y = silu((x - mean) * rstd * gamma + beta)
+// Backward recomputes the normalised value and the SiLU derivative, reduces (sum dyhat, sum dyhat*yhat) the same
+// way and writes dx; gamma/beta gradients are not produced (the UNet weights are frozen on this path).
+// HBM-bound: forward moves 2 reads + 1 write of the tensor (the second read hits L2/MALL at these sizes).
+#include "ga_common.h"
+
+using namespace ga;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxNB = 32;
+constexpr int kMaxNPT = 5;  // channel pairs per thread: C <= 2560
+
+// W consecutive channels handled by one lane per pixel: 2 (a 4-byte access for 16-bit types) when the group size
+// is even, which is every SD layer; 1 for odd group sizes (reduced-width test models).
+template <typename T, int W>
+struct Item {
+  T v[W];
+};
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + __expf(-z)); }
+
+// sums over this workgroup's pixels of (v0, v1) per channel pair, folded to groups in fixed order
+template <int NPT>
+__device__ __forceinline__ void fold_to_groups(const float (&s0)[NPT], const float (&s1)[NPT], int CP, int cpg, int G,
+                                               float* lds, float* out) {
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int cp = threadIdx.x + k * kThreads;
+    if (cp < CP) {
+      lds[2 * cp] = s0[k];
+      lds[2 * cp + 1] = s1[k];
+    }
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += kThreads) {
+    float a = 0.f, b = 0.f;
+    for (int cp = g * cpg; cp < (g + 1) * cpg; ++cp) {
+      a += lds[2 * cp];
+      b += lds[2 * cp + 1];
+    }
+    out[2 * g] = a;
+    out[2 * g + 1] = b;
+  }
+}
+
+template <typename T, int NPT, int W>
+__global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ partial,
+                                                            int HW, int C, int G, int PB) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.y, nb = blockIdx.x, CP = C / W, cpg = (C / G) / W;
+  const int p0 = nb * PB, p1 = min(HW, p0 + PB);
+  float s0[NPT], s1[NPT];
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) s0[k] = s1[k] = 0.f;
+  const Item<T, W>* xb = reinterpret_cast<const Item<T, W>*>(x) + (size_t)b * HW * CP;
+  for (int p = p0; p < p1; ++p) {
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int cp = threadIdx.x + k * kThreads;
+      if (cp < CP) {
+        const Item<T, W> v = xb[(size_t)p * CP + cp];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const float a = Traits<T>::to_f32(v.v[j]);
+          s0[k] += a;
+          s1[k] += a * a;
+        }
+      }
+    }
+  }
+  fold_to_groups<NPT>(s0, s1, CP, cpg, G, lds, partial + ((size_t)b * gridDim.x + nb) * G * 2);
+}
+
+// per-group (v0, v1) = fixed-order sum of the NB partials, into LDS
+__device__ __forceinline__ void gather_partials(const float* __restrict__ partial, int b, int NB, int G, float* g0,
+                                                float* g1) {
+  for (int g = threadIdx.x; g < G; g += kThreads) {
+    float a = 0.f, c = 0.f;
+    for (int nb = 0; nb < NB; ++nb) {
+      a += partial[((size_t)b * NB + nb) * G * 2 + 2 * g];
+      c += partial[((size_t)b * NB + nb) * G * 2 + 2 * g + 1];
+    }
+    g0[g] = a;
+    g1[g] = c;
+  }
+  __syncthreads();
+}
+
+template <typename T, bool ACT, int NPT, int W>
+__global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ partial,
+                                                            int NB, const T* __restrict__ gamma,
+                                                            const T* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ stats, int HW, int C, int G, int PB,
+                                                            float eps) {
+  __shared__ float mu[64], rs[64];
+  const int b = blockIdx.y, CP = C / W, cpg = (C / G) / W;
+  gather_partials(partial, b, NB, G, mu, rs);
+  const float inv_n = 1.0f / ((float)HW * (float)(C / G));
+  for (int g = threadIdx.x; g < G; g += kThreads) {
+    const double mean = (double)mu[g] * inv_n;
+    const double var = fmax((double)rs[g] * inv_n - mean * mean, 0.0);
+    const float r = rsqrtf((float)var + eps);
+    mu[g] = (float)mean;
+    rs[g] = r;
+    if (blockIdx.x == 0) {
+      stats[((size_t)b * G + g) * 2] = (float)mean;
+      stats[((size_t)b * G + g) * 2 + 1] = r;
+    }
+  }
+  __syncthreads();
+  float sc[NPT][W], sh[NPT][W];
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int cp = threadIdx.x + k * kThreads;
+    if (cp < CP) {
+      const int g = cp / cpg;
+      const Item<T, W> ga_ = reinterpret_cast<const Item<T, W>*>(gamma)[cp];
+      const Item<T, W> be = reinterpret_cast<const Item<T, W>*>(beta)[cp];
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        sc[k][j] = Traits<T>::to_f32(ga_.v[j]) * rs[g];
+        sh[k][j] = Traits<T>::to_f32(be.v[j]) - mu[g] * sc[k][j];
+      }
+    }
+  }
+  const int p0 = blockIdx.x * PB, p1 = min(HW, p0 + PB);
+  const Item<T, W>* xb = reinterpret_cast<const Item<T, W>*>(x) + (size_t)b * HW * CP;
+  Item<T, W>* yb = reinterpret_cast<Item<T, W>*>(y) + (size_t)b * HW * CP;
+  for (int p = p0; p < p1; ++p) {
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int cp = threadIdx.x + k * kThreads;
+      if (cp < CP) {
+        const Item<T, W> v = xb[(size_t)p * CP + cp];
+        Item<T, W> o;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          float z = Traits<T>::to_f32(v.v[j]) * sc[k][j] + sh[k][j];
+          if (ACT) z *= sigmoidf_(z);
+          o.v[j] = Traits<T>::from_f32(z);
+        }
+        yb[(size_t)p * CP + cp] = o;
+      }
+    }
+  }
+}
+
+// dyhat = dL/d(normalised value) for one element: through the affine and (optionally) SiLU
+template <bool ACT>
+__device__ __forceinline__ float dyhat_of(float yhat, float dy, float gam, float bet) {
+  float dz = dy;
+  if (ACT) {
+    const float z = gam * yhat + bet;
+    const float s = sigmoidf_(z);
+    dz = dy * s * (1.0f + z * (1.0f - s));
+  }
+  return dz * gam;
+}
+
+template <typename T, bool ACT, int NPT, int W>
+__global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                const T* __restrict__ gamma,
+                                                                const T* __restrict__ beta,
+                                                                const float* __restrict__ stats,
+                                                                float* __restrict__ partial, int HW, int C, int G,
+                                                                int PB) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.y, nb = blockIdx.x, CP = C / W, cpg = (C / G) / W;
+  const int p0 = nb * PB, p1 = min(HW, p0 + PB);
+  float s0[NPT], s1[NPT], mu[NPT], rs[NPT], g0[NPT][W], b0[NPT][W];
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    s0[k] = s1[k] = 0.f;
+    const int cp = threadIdx.x + k * kThreads;
+    if (cp < CP) {
+      const int g = cp / cpg;
+      mu[k] = stats[((size_t)b * G + g) * 2];
+      rs[k] = stats[((size_t)b * G + g) * 2 + 1];
+      const Item<T, W> ga_ = reinterpret_cast<const Item<T, W>*>(gamma)[cp];
+      const Item<T, W> be = reinterpret_cast<const Item<T, W>*>(beta)[cp];
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        g0[k][j] = Traits<T>::to_f32(ga_.v[j]);
+        b0[k][j] = Traits<T>::to_f32(be.v[j]);
+      }
+    }
+  }
+  const Item<T, W>* xb = reinterpret_cast<const Item<T, W>*>(x) + (size_t)b * HW * CP;
+  const Item<T, W>* db = reinterpret_cast<const Item<T, W>*>(dy) + (size_t)b * HW * CP;
+  for (int p = p0; p < p1; ++p) {
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int cp = threadIdx.x + k * kThreads;
+      if (cp < CP) {
+        const Item<T, W> v = xb[(size_t)p * CP + cp], d = db[(size_t)p * CP + cp];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const float yh = (Traits<T>::to_f32(v.v[j]) - mu[k]) * rs[k];
+          const float dh = dyhat_of<ACT>(yh, Traits<T>::to_f32(d.v[j]), g0[k][j], b0[k][j]);
+          s0[k] += dh;
+          s1[k] += dh * yh;
+        }
+      }
+    }
+  }
+  fold_to_groups<NPT>(s0, s1, CP, cpg, G, lds, partial + ((size_t)b * gridDim.x + nb) * G * 2);
+}
+
+template <typename T, bool ACT, int NPT, int W>
+__global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                const T* __restrict__ gamma,
+                                                                const T* __restrict__ beta,
+                                                                const float* __restrict__ stats,
+                                                                const float* __restrict__ partial, int NB,
+                                                                T* __restrict__ dx, int HW, int C, int G, int PB) {
+  __shared__ float m1[64], m2[64];
+  const int b = blockIdx.y, CP = C / W, cpg = (C / G) / W;
+  gather_partials(partial, b, NB, G, m1, m2);
+  const float inv_n = 1.0f / ((float)HW * (float)(C / G));
+  float mu[NPT], rs[NPT], a1[NPT], a2[NPT], g0[NPT][W], b0[NPT][W];
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int cp = threadIdx.x + k * kThreads;
+    if (cp < CP) {
+      const int g = cp / cpg;
+      mu[k] = stats[((size_t)b * G + g) * 2];
+      rs[k] = stats[((size_t)b * G + g) * 2 + 1];
+      a1[k] = m1[g] * inv_n;
+      a2[k] = m2[g] * inv_n;
+      const Item<T, W> ga_ = reinterpret_cast<const Item<T, W>*>(gamma)[cp];
+      const Item<T, W> be = reinterpret_cast<const Item<T, W>*>(beta)[cp];
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        g0[k][j] = Traits<T>::to_f32(ga_.v[j]);
+        b0[k][j] = Traits<T>::to_f32(be.v[j]);
+      }
+    }
+  }
+  const int p0 = blockIdx.x * PB, p1 = min(HW, p0 + PB);
+  const Item<T, W>* xb = reinterpret_cast<const Item<T, W>*>(x) + (size_t)b * HW * CP;
+  const Item<T, W>* db = reinterpret_cast<const Item<T, W>*>(dy) + (size_t)b * HW * CP;
+  Item<T, W>* ob = reinterpret_cast<Item<T, W>*>(dx) + (size_t)b * HW * CP;
+  for (int p = p0; p < p1; ++p) {
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int cp = threadIdx.x + k * kThreads;
+      if (cp < CP) {
+        const Item<T, W> v = xb[(size_t)p * CP + cp], d = db[(size_t)p * CP + cp];
+        Item<T, W> o;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const float yh = (Traits<T>::to_f32(v.v[j]) - mu[k]) * rs[k];
+          const float dh = dyhat_of<ACT>(yh, Traits<T>::to_f32(d.v[j]), g0[k][j], b0[k][j]);
+          o.v[j] = Traits<T>::from_f32(rs[k] * (dh - a1[k] - yh * a2[k]));
+        }
+        ob[(size_t)p * CP + cp] = o;
+      }
+    }
+  }
+}
+
+struct Geom {
+  int NB, PBs, NBa, PBa, NPT, W;
+  size_t lds;
+};
+
+int geometry(int B, int HW, int C, int G, Geom& g) {
+  if (B < 1 || HW < 1 || C < 1 || G < 1 || G > 64 || C % G != 0) return GA_ERR_SHAPE;
+  g.W = ((C / G) & 1) ? 1 : 2;
+  const int CP = C / g.W;
+  g.NPT = (CP + kThreads - 1) / kThreads;
+  if (g.NPT > kMaxNPT) return GA_ERR_SHAPE;
+  g.NB = HW >= kMaxNB * 8 ? kMaxNB : (HW + 7) / 8;          // stats: <= 32 pixel blocks per image
+  g.PBs = (HW + g.NB - 1) / g.NB;
+  g.NB = (HW + g.PBs - 1) / g.PBs;
+  g.PBa = HW >= 4096 ? 16 : (HW >= 1024 ? 8 : 4);            // apply: small blocks -> enough workgroups
+  g.NBa = (HW + g.PBa - 1) / g.PBa;
+  g.lds = sizeof(float) * 2 * CP;
+  return GA_OK;
+}
+
+template <typename T, bool ACT, int NPT, int W>
+int launch_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float* stats, float* ws, int B, int HW,
+                 int C, int G, float eps, const Geom& g, hipStream_t s) {
+  hipLaunchKernelGGL((gn_stats_kernel<T, NPT, W>), dim3(g.NB, B), dim3(kThreads), g.lds, s, (const T*)x, ws, HW, C, G,
+                     g.PBs);
+  hipLaunchKernelGGL((gn_apply_kernel<T, ACT, NPT, W>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x, ws, g.NB,
+                     (const T*)gamma, (const T*)beta, (T*)y, stats, HW, C, G, g.PBa, eps);
+  return check_launch();
+}
+
+template <typename T, bool ACT, int NPT, int W>
+int launch_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta, const float* stats, void* dx,
+                 float* ws, int B, int HW, int C, int G, const Geom& g, hipStream_t s) {
+  hipLaunchKernelGGL((gn_bwd_stats_kernel<T, ACT, NPT, W>), dim3(g.NB, B), dim3(kThreads), g.lds, s, (const T*)x,
+                     (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, HW, C, G, g.PBs);
+  hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT, NPT, W>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
+                     (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, g.NB, (T*)dx, HW, C, G, g.PBa);
+  return check_launch();
+}
+
+#define GA_GN_NPT(FN, T, ACT, ...)                                   \
+  if (g.W == 1) {                                                    \
+    switch (g.NPT) {                                                 \
+      case 1: return FN<T, ACT, 1, 1>(__VA_ARGS__);                  \
+      case 2: return FN<T, ACT, 2, 1>(__VA_ARGS__);                  \
+      default: return FN<T, ACT, 5, 1>(__VA_ARGS__);                 \
+    }                                                                \
+  }                                                                  \
+  switch (g.NPT) {                                                   \
+    case 1: return FN<T, ACT, 1, 2>(__VA_ARGS__);                    \
+    case 2: return FN<T, ACT, 2, 2>(__VA_ARGS__);                    \
+    case 3: return FN<T, ACT, 3, 2>(__VA_ARGS__);                    \
+    case 4: return FN<T, ACT, 4, 2>(__VA_ARGS__);                    \
+    default: return FN<T, ACT, 5, 2>(__VA_ARGS__);                   \
+  }
+
+template <typename T>
+int fwd_dtype(const void* x, const void* gamma, const void* beta, void* y, float* stats, float* ws, int B, int HW, int C,
+              int G, float eps, int act, const Geom& g, hipStream_t s) {
+  if (act) {
+    GA_GN_NPT(launch_fwd_t, T, true, x, gamma, beta, y, stats, ws, B, HW, C, G, eps, g, s)
+  }
+  GA_GN_NPT(launch_fwd_t, T, false, x, gamma, beta, y, stats, ws, B, HW, C, G, eps, g, s)
+}
+
+template <typename T>
+int bwd_dtype(const void* x, const void* dy, const void* gamma, const void* beta, const float* stats, void* dx,
+              float* ws, int B, int HW, int C, int G, int act, const Geom& g, hipStream_t s) {
+  if (act) {
+    GA_GN_NPT(launch_bwd_t, T, true, x, dy, gamma, beta, stats, dx, ws, B, HW, C, G, g, s)
+  }
+  GA_GN_NPT(launch_bwd_t, T, false, x, dy, gamma, beta, stats, dx, ws, B, HW, C, G, g, s)
+}
+
+}  // namespace
+
+extern "C" int ga_group_norm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* stats,
+                                 float* workspace, int B, int HW, int C, int G, float eps, int act_silu, int dtype,
+                                 ga_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !stats || !workspace) return GA_ERR_NULL;
+  Geom g;
+  int rc = geometry(B, HW, C, G, g);
+  if (rc != GA_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case GA_F16: return fwd_dtype<_Float16>(x, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
+    case GA_BF16: return fwd_dtype<bf16_t>(x, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
+    case GA_F32: return fwd_dtype<float>(x, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
+    default: return GA_ERR_DTYPE;
+  }
+}
+
+extern "C" int ga_group_norm_bwd(const void* x, const void* dy, const void* gamma, const void* beta,
+                                 const float* stats, void* dx, float* workspace, int B, int HW, int C, int G,
+                                 int act_silu, int dtype, ga_stream_t stream) {
+  if (!x || !dy || !gamma || !beta || !stats || !dx || !workspace) return GA_ERR_NULL;
+  Geom g;
+  int rc = geometry(B, HW, C, G, g);
+  if (rc != GA_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case GA_F16: return bwd_dtype<_Float16>(x, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
+    case GA_BF16: return bwd_dtype<bf16_t>(x, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
+    case GA_F32: return bwd_dtype<float>(x, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
+    default: return GA_ERR_DTYPE;
+  }
+}

@@ -319,3 +319,47 @@ def cfg_ddim_step(eps_uncond, eps_text, guidance, x, alpha_t, alpha_prev, want_x
                                   float(alpha_prev), _ptr(prev), _ptr(x0), x.numel(), dtype_code(x), stream_ptr()),
           "ga_cfg_ddim_step")
     return prev, x0
+
+
+# --------------------------------------------------------------------------------------- GroupNorm (+SiLU), NHWC
+def _nhwc(x):
+    return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+
+
+class GroupNormAct(torch.autograd.Function):
+    """y = [silu](group_norm(x)) on channels-last (B, C, H, W) tensors; differentiable w.r.t. x only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, act):
+        require_cuda(x, weight, bias)
+        if x.dim() != 4:
+            raise GaError("GroupNormAct expects a (B, C, H, W) tensor")
+        x = _nhwc(x)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+        ws = torch.empty((B * 32 * groups * 2,), dtype=torch.float32, device=x.device)
+        check(load().ga_group_norm_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(stats), _ptr(ws), B, H * W, C,
+                                       groups, float(eps), int(bool(act)), dtype_code(x), stream_ptr()),
+              "ga_group_norm_fwd")
+        ctx.save_for_backward(x, weight, bias, stats)
+        ctx.meta = (groups, bool(act))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise GaError("GroupNorm weight gradients are not part of the guided-attention path (frozen UNet)")
+        x, weight, bias, stats = ctx.saved_tensors
+        groups, act = ctx.meta
+        B, C, H, W = x.shape
+        dy = _nhwc(dy)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        ws = torch.empty((B * 32 * groups * 2,), dtype=torch.float32, device=x.device)
+        check(load().ga_group_norm_bwd(_ptr(x), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(stats), _ptr(dx), _ptr(ws), B,
+                                       H * W, C, groups, int(act), dtype_code(x), stream_ptr()), "ga_group_norm_bwd")
+        return dx, None, None, None, None, None
+
+
+def group_norm_act(x, weight, bias, groups, eps, act):
+    return GroupNormAct.apply(x, weight, bias, groups, eps, act)

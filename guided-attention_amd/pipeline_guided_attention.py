@@ -109,6 +109,11 @@ class GuidedAttention:
                 m.to(device=device, dtype=dtype)
         for p in self.unet.parameters():
             p.requires_grad_(False)  # only the latents are differentiated (reference :466)
+        if self.unet.device.type == "cuda":
+            # MI355X layout: activations and conv weights channels-last end to end (MIOpen's NHWC kernels without
+            # transposes) and the fused NHWC GroupNorm(+SiLU) HIP kernels in every norm layer
+            self.unet.to(memory_format=torch.channels_last)
+            self.unet.set_norm_impl(ops.group_norm_act)
         return self
 
     @property

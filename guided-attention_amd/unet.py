@@ -93,6 +93,23 @@ class Attention(nn.Module):
         return proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask)
 
 
+class GroupNormAct(nn.GroupNorm):
+    """GroupNorm with an optional fused SiLU.  Same parameters / state_dict keys as nn.GroupNorm.  `impl` is a
+    callable (x, weight, bias, groups, eps, act) -> y installed by the GPU pipeline (the channels-last HIP
+    kernels, ops.group_norm_act); None = the portable PyTorch ops (what the CPU oracle runs)."""
+
+    def __init__(self, num_groups, num_channels, eps=1e-5, act=False):
+        super().__init__(num_groups, num_channels, eps=eps)
+        self.act = act
+        self.impl = None
+
+    def forward(self, x):
+        if self.impl is not None:
+            return self.impl(x, self.weight, self.bias, self.num_groups, self.eps, self.act)
+        y = super().forward(x)
+        return F.silu(y) if self.act else y
+
+
 class GEGLU(nn.Module):
     def __init__(self, dim_in, dim_out):
         super().__init__()
@@ -135,7 +152,7 @@ class Transformer2DModel(nn.Module):
         super().__init__()
         inner = heads * dim_head
         self.use_linear_projection = use_linear_projection
-        self.norm = nn.GroupNorm(groups, in_channels, eps=1e-6)
+        self.norm = GroupNormAct(groups, in_channels, eps=1e-6, act=False)
         if use_linear_projection:
             self.proj_in = nn.Linear(in_channels, inner)
             self.proj_out = nn.Linear(inner, in_channels)
@@ -164,18 +181,18 @@ class Transformer2DModel(nn.Module):
 class ResnetBlock2D(nn.Module):
     def __init__(self, in_channels, out_channels, temb_channels, groups, eps):
         super().__init__()
-        self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps)
+        self.norm1 = GroupNormAct(groups, in_channels, eps=eps, act=True)
         self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
         self.time_emb_proj = nn.Linear(temb_channels, out_channels)
-        self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps)
+        self.norm2 = GroupNormAct(groups, out_channels, eps=eps, act=True)
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
     def forward(self, x, temb_act):
         """temb_act = SiLU(time embedding), computed once per UNet forward."""
-        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv1(self.norm1(x))  # norm1 / norm2 carry the SiLU
         h = h + self.time_emb_proj(temb_act)[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
+        h = self.conv2(self.norm2(h))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
         return x + h
@@ -323,7 +340,7 @@ class UNet2DConditionModel(nn.Module):
             self.up_blocks.append(UpBlock(cfg, in_c, out_c, prev_c, temb_c, rev_heads[i], i != len(ch) - 1,
                                           kind == "CrossAttnUpBlock2D"))
         self.num_upsamplers = len(ch) - 1
-        self.conv_norm_out = nn.GroupNorm(cfg.norm_num_groups, ch[0], eps=cfg.norm_eps)
+        self.conv_norm_out = GroupNormAct(cfg.norm_num_groups, ch[0], eps=cfg.norm_eps, act=True)
         self.conv_out = nn.Conv2d(ch[0], cfg.out_channels, 3, padding=1)
 
     # ---- attention-processor registry (diffusers protocol used by utils/ptp_utils.py:149-175)
@@ -347,6 +364,12 @@ class UNet2DConditionModel(nn.Module):
         else:
             for mod in mods.values():
                 mod.set_processor(processor)
+
+    def set_norm_impl(self, impl):
+        """Install (or with None remove) the GroupNorm(+SiLU) implementation of every norm layer."""
+        for m in self.modules():
+            if isinstance(m, GroupNormAct):
+                m.impl = impl
 
     @property
     def dtype(self):
@@ -389,7 +412,7 @@ class UNet2DConditionModel(nn.Module):
                 blk(x, skips, temb_act, encoder_hidden_states, upsample_size, n_layers=stop_after_up_block[1])
                 return UNetOutput(sample=None) if return_dict else (None,)
             x = blk(x, skips, temb_act, encoder_hidden_states, upsample_size)
-        x = self.conv_out(F.silu(self.conv_norm_out(x)))
+        x = self.conv_out(self.conv_norm_out(x))
         return UNetOutput(sample=x) if return_dict else (x,)
 
     # ---- weights

@@ -344,3 +344,31 @@ def test_latent_ops(ops, dt, n):
     x0r = (zs - math.sqrt(1 - a_t) * eps) / math.sqrt(a_t)
     close(x0, x0r, TOL[dt], "x0")
     close(prev, math.sqrt(a_p) * x0r + math.sqrt(1 - a_p) * eps, TOL[dt], "prev")
+
+
+# ------------------------------------------------------------------------------------- GroupNorm(+SiLU), NHWC
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("act", [True, False])
+@pytest.mark.parametrize("shape", [(1, 320, 64, 64), (2, 320, 64, 64), (1, 640, 32, 32), (1, 960, 64, 64),
+                                   (1, 1920, 32, 32), (2, 2560, 16, 16), (1, 1280, 8, 8), (1, 64, 4, 4), (1, 32, 4, 4), (2, 96, 3, 5)])
+def test_group_norm_act(ops, shape, act, dt):
+    """Fused channels-last GroupNorm(+SiLU) forward/backward vs PyTorch's own ops in fp64 on the CPU."""
+    B, C, H, W = shape
+    x = dev(hashrand.normalish(shape, 7 + C) * 1.7 + 0.3, DT[dt]).contiguous(memory_format=torch.channels_last)
+    w = dev(hashrand.normalish((C,), 8) * 0.5 + 1.0, DT[dt])
+    b = dev(hashrand.normalish((C,), 9) * 0.2, DT[dt])
+    g = dev(hashrand.normalish(shape, 10), DT[dt]).contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(True)
+    y = ops.group_norm_act(xa, w, b, 32, 1e-5, act)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(g)
+    xr = x.double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.group_norm(xr, 32, w.double().cpu(), b.double().cpu(), 1e-5)
+    if act:
+        yr = torch.nn.functional.silu(yr)
+    yr.backward(g.double().cpu())
+    close(y, yr.detach().numpy(), TOL[dt] * 2, "y")
+    close(xa.grad, xr.grad.numpy(), TOL[dt] * 3, "dx")
+    stride_input = x.contiguous()  # NCHW input is accepted and converted
+    y2 = ops.group_norm_act(stride_input, w, b, 32, 1e-5, act)
+    assert torch.equal(y2, y.detach())

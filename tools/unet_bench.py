@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""GPU time of the three captured passes of the guided-attention loop for the SD-1.x UNet (hipGraph replay,
+so host launch cost is excluded): guidance forward + loss (B=1, autograd), its backward to the latents, and
+the CFG forward (B=2).  usage: unet_bench.py [truncated] [nhwc-off]"""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from guided_attention_amd import run  # noqa: E402
+from guided_attention_amd.config import RunConfig  # noqa: E402
+from guided_attention_amd.graphs import GraphRunner  # noqa: E402
+from guided_attention_amd.pipeline_guided_attention import GuidedAttention  # noqa: E402
+from guided_attention_amd.text import SyntheticTextEncoder, WordTokenizer  # noqa: E402
+from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig  # noqa: E402
+from guided_attention_amd.utils import ptp_utils, shared_state as state  # noqa: E402
+
+
+def replay_ms(graph, n=10):
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    with torch.device("cuda"):
+        unet = UNet2DConditionModel(UNetConfig.sd15()).half()
+    pipe = GuidedAttention(unet, None, None, SyntheticTextEncoder(768), WordTokenizer()).to("cuda", torch.float16)
+    if "nhwc-off" in sys.argv:
+        pipe.unet.set_norm_impl(None)
+        pipe.unet.to(memory_format=torch.contiguous_format)
+    pipe.guidance_forward = "truncated" if "truncated" in sys.argv else "full"
+    rc = RunConfig(meta_prompt="a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55]", output_path="/tmp/ga_ub")
+    rc.stable = pipe
+    state.curHyperParams = state.get_hyperparam_states()[0]
+    run.overrideConfig(rc)
+    run.parseMetaPrompt(rc)
+    store = ptp_utils.AttentionStore()
+    ptp_utils.register_attention_control(pipe, store)
+    pipe._attention_store = store
+    pipe._truncate_at = pipe._truncation_point(16, 512, 512)
+    emb = torch.randn(2, 77, 768, device="cuda", dtype=torch.half)
+    lat = torch.randn(1, 4, 64, 64, device="cuda", dtype=torch.half)
+    r = GraphRunner(pipe, store, emb, lat, 16, True, 0.5, 3, False)
+    print(f"guidance forward + loss (B=1): {replay_ms(r.g_eval):7.3f} ms")
+    print(f"backward to the latents      : {replay_ms(r.g_grad):7.3f} ms")
+    print(f"CFG forward (B=2)            : {replay_ms(r.g_cfg):7.3f} ms")
+
+
+if __name__ == "__main__":
+    main()
