@@ -18,8 +18,9 @@ using namespace ga;
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxNB = 32;
+constexpr int kMaxNB = 64;
 constexpr int kMaxNPT = 5;  // channel pairs per thread: C <= 2560
+constexpr int kU = 8;       // pixels per lane whose loads are issued together
 
 // W consecutive channels handled by one lane per pixel: 2 (a 4-byte access for 16-bit types) when the group size
 // is even, which is every SD layer; 1 for odd group sizes (reduced-width test models).
@@ -64,35 +65,50 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict_
 #pragma unroll
   for (int k = 0; k < NPT; ++k) s0[k] = s1[k] = 0.f;
   const Item<T, W>* xb = reinterpret_cast<const Item<T, W>*>(x) + (size_t)b * HW * CP;
-  for (int p = p0; p < p1; ++p) {
 #pragma unroll
-    for (int k = 0; k < NPT; ++k) {
-      const int cp = threadIdx.x + k * kThreads;
-      if (cp < CP) {
-        const Item<T, W> v = xb[(size_t)p * CP + cp];
+  for (int k = 0; k < NPT; ++k) {
+    const int cp = threadIdx.x + k * kThreads;
+    if (cp >= CP) continue;
+    for (int p = p0; p < p1; p += kU) {  // kU independent loads in flight per lane, then the fixed-order adds
+      Item<T, W> v[kU];
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-          const float a = Traits<T>::to_f32(v.v[j]);
-          s0[k] += a;
-          s1[k] += a * a;
+      for (int u = 0; u < kU; ++u)
+        if (p + u < p1) v[u] = xb[(size_t)(p + u) * CP + cp];
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (p + u < p1) {
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            const float a = Traits<T>::to_f32(v[u].v[j]);
+            s0[k] += a;
+            s1[k] += a * a;
+          }
         }
-      }
     }
   }
   fold_to_groups<NPT>(s0, s1, CP, cpg, G, lds, partial + ((size_t)b * gridDim.x + nb) * G * 2);
 }
 
-// per-group (v0, v1) = fixed-order sum of the NB partials, into LDS
+// per-group (v0, v1) = fixed-order sum of the NB partials, into g0/g1 (LDS, >= 64 floats each).  All 256 lanes
+// load (lane -> group = lane % 32-ish slice of the partial list) so the <= 64 x G partials cost one round trip;
+// the slices are then added in a fixed order (deterministic).
 __device__ __forceinline__ void gather_partials(const float* __restrict__ partial, int b, int NB, int G, float* g0,
                                                 float* g1) {
-  for (int g = threadIdx.x; g < G; g += kThreads) {
-    float a = 0.f, c = 0.f;
-    for (int nb = 0; nb < NB; ++nb) {
+  __shared__ float slice[2][8][64];
+  const int g = threadIdx.x % 64, sl = threadIdx.x / 64;  // 4 slices of the partial list x 64 groups
+  float a = 0.f, c = 0.f;
+  if (g < G) {
+    for (int nb = sl; nb < NB; nb += 4) {
       a += partial[((size_t)b * NB + nb) * G * 2 + 2 * g];
       c += partial[((size_t)b * NB + nb) * G * 2 + 2 * g + 1];
     }
-    g0[g] = a;
-    g1[g] = c;
+  }
+  slice[0][sl][g] = a;
+  slice[1][sl][g] = c;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    g0[g] = (slice[0][0][g] + slice[0][1][g]) + (slice[0][2][g] + slice[0][3][g]);
+    g1[g] = (slice[1][0][g] + slice[1][1][g]) + (slice[1][2][g] + slice[1][3][g]);
   }
   __syncthreads();
 }
@@ -137,21 +153,27 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict_
   const int p0 = blockIdx.x * PB, p1 = min(HW, p0 + PB);
   const Item<T, W>* xb = reinterpret_cast<const Item<T, W>*>(x) + (size_t)b * HW * CP;
   Item<T, W>* yb = reinterpret_cast<Item<T, W>*>(y) + (size_t)b * HW * CP;
-  for (int p = p0; p < p1; ++p) {
 #pragma unroll
-    for (int k = 0; k < NPT; ++k) {
-      const int cp = threadIdx.x + k * kThreads;
-      if (cp < CP) {
-        const Item<T, W> v = xb[(size_t)p * CP + cp];
-        Item<T, W> o;
+  for (int k = 0; k < NPT; ++k) {
+    const int cp = threadIdx.x + k * kThreads;
+    if (cp >= CP) continue;
+    for (int p = p0; p < p1; p += kU) {
+      Item<T, W> v[kU];
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-          float z = Traits<T>::to_f32(v.v[j]) * sc[k][j] + sh[k][j];
-          if (ACT) z *= sigmoidf_(z);
-          o.v[j] = Traits<T>::from_f32(z);
+      for (int u = 0; u < kU; ++u)
+        if (p + u < p1) v[u] = xb[(size_t)(p + u) * CP + cp];
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (p + u < p1) {
+          Item<T, W> o;
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            float z = Traits<T>::to_f32(v[u].v[j]) * sc[k][j] + sh[k][j];
+            if (ACT) z *= sigmoidf_(z);
+            o.v[j] = Traits<T>::from_f32(z);
+          }
+          yb[(size_t)(p + u) * CP + cp] = o;
         }
-        yb[(size_t)p * CP + cp] = o;
-      }
     }
   }
 }
@@ -198,20 +220,29 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(const T* __restr
   }
   const Item<T, W>* xb = reinterpret_cast<const Item<T, W>*>(x) + (size_t)b * HW * CP;
   const Item<T, W>* db = reinterpret_cast<const Item<T, W>*>(dy) + (size_t)b * HW * CP;
-  for (int p = p0; p < p1; ++p) {
 #pragma unroll
-    for (int k = 0; k < NPT; ++k) {
-      const int cp = threadIdx.x + k * kThreads;
-      if (cp < CP) {
-        const Item<T, W> v = xb[(size_t)p * CP + cp], d = db[(size_t)p * CP + cp];
+  for (int k = 0; k < NPT; ++k) {
+    const int cp = threadIdx.x + k * kThreads;
+    if (cp >= CP) continue;
+    for (int p = p0; p < p1; p += kU) {
+      Item<T, W> v[kU], d[kU];
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-          const float yh = (Traits<T>::to_f32(v.v[j]) - mu[k]) * rs[k];
-          const float dh = dyhat_of<ACT>(yh, Traits<T>::to_f32(d.v[j]), g0[k][j], b0[k][j]);
-          s0[k] += dh;
-          s1[k] += dh * yh;
+      for (int u = 0; u < kU; ++u)
+        if (p + u < p1) {
+          v[u] = xb[(size_t)(p + u) * CP + cp];
+          d[u] = db[(size_t)(p + u) * CP + cp];
         }
-      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (p + u < p1) {
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            const float yh = (Traits<T>::to_f32(v[u].v[j]) - mu[k]) * rs[k];
+            const float dh = dyhat_of<ACT>(yh, Traits<T>::to_f32(d[u].v[j]), g0[k][j], b0[k][j]);
+            s0[k] += dh;
+            s1[k] += dh * yh;
+          }
+        }
     }
   }
   fold_to_groups<NPT>(s0, s1, CP, cpg, G, lds, partial + ((size_t)b * gridDim.x + nb) * G * 2);
@@ -251,21 +282,30 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
   const Item<T, W>* xb = reinterpret_cast<const Item<T, W>*>(x) + (size_t)b * HW * CP;
   const Item<T, W>* db = reinterpret_cast<const Item<T, W>*>(dy) + (size_t)b * HW * CP;
   Item<T, W>* ob = reinterpret_cast<Item<T, W>*>(dx) + (size_t)b * HW * CP;
-  for (int p = p0; p < p1; ++p) {
 #pragma unroll
-    for (int k = 0; k < NPT; ++k) {
-      const int cp = threadIdx.x + k * kThreads;
-      if (cp < CP) {
-        const Item<T, W> v = xb[(size_t)p * CP + cp], d = db[(size_t)p * CP + cp];
-        Item<T, W> o;
+  for (int k = 0; k < NPT; ++k) {
+    const int cp = threadIdx.x + k * kThreads;
+    if (cp >= CP) continue;
+    for (int p = p0; p < p1; p += kU) {
+      Item<T, W> v[kU], d[kU];
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-          const float yh = (Traits<T>::to_f32(v.v[j]) - mu[k]) * rs[k];
-          const float dh = dyhat_of<ACT>(yh, Traits<T>::to_f32(d.v[j]), g0[k][j], b0[k][j]);
-          o.v[j] = Traits<T>::from_f32(rs[k] * (dh - a1[k] - yh * a2[k]));
+      for (int u = 0; u < kU; ++u)
+        if (p + u < p1) {
+          v[u] = xb[(size_t)(p + u) * CP + cp];
+          d[u] = db[(size_t)(p + u) * CP + cp];
         }
-        ob[(size_t)p * CP + cp] = o;
-      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (p + u < p1) {
+          Item<T, W> o;
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            const float yh = (Traits<T>::to_f32(v[u].v[j]) - mu[k]) * rs[k];
+            const float dh = dyhat_of<ACT>(yh, Traits<T>::to_f32(d[u].v[j]), g0[k][j], b0[k][j]);
+            o.v[j] = Traits<T>::from_f32(rs[k] * (dh - a1[k] - yh * a2[k]));
+          }
+          ob[(size_t)(p + u) * CP + cp] = o;
+        }
     }
   }
 }
@@ -281,10 +321,10 @@ int geometry(int B, int HW, int C, int G, Geom& g) {
   const int CP = C / g.W;
   g.NPT = (CP + kThreads - 1) / kThreads;
   if (g.NPT > kMaxNPT) return GA_ERR_SHAPE;
-  g.NB = HW >= kMaxNB * 8 ? kMaxNB : (HW + 7) / 8;          // stats: <= 32 pixel blocks per image
+  g.NB = HW >= kMaxNB * 8 ? kMaxNB : (HW + 7) / 8;          // stats: <= 64 pixel blocks per image
   g.PBs = (HW + g.NB - 1) / g.NB;
   g.NB = (HW + g.PBs - 1) / g.PBs;
-  g.PBa = HW >= 4096 ? 16 : (HW >= 1024 ? 8 : 4);            // apply: small blocks -> enough workgroups
+  g.PBa = HW >= 1024 ? 8 : 4;                                // apply: small blocks -> enough workgroups
   g.NBa = (HW + g.PBa - 1) / g.PBa;
   g.lds = sizeof(float) * 2 * CP;
   return GA_OK;

@@ -338,7 +338,7 @@ class GroupNormAct(torch.autograd.Function):
         B, C, H, W = x.shape
         y = torch.empty_like(x, memory_format=torch.channels_last)
         stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
-        ws = torch.empty((B * 32 * groups * 2,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((B * 64 * groups * 2,), dtype=torch.float32, device=x.device)
         check(load().ga_group_norm_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(stats), _ptr(ws), B, H * W, C,
                                        groups, float(eps), int(bool(act)), dtype_code(x), stream_ptr()),
               "ga_group_norm_fwd")
@@ -355,7 +355,7 @@ class GroupNormAct(torch.autograd.Function):
         B, C, H, W = x.shape
         dy = _nhwc(dy)
         dx = torch.empty_like(x, memory_format=torch.channels_last)
-        ws = torch.empty((B * 32 * groups * 2,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((B * 64 * groups * 2,), dtype=torch.float32, device=x.device)
         check(load().ga_group_norm_bwd(_ptr(x), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(stats), _ptr(dx), _ptr(ws), B,
                                        H * W, C, groups, int(act), dtype_code(x), stream_ptr()), "ga_group_norm_bwd")
         return dx, None, None, None, None, None
