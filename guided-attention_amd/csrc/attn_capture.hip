@@ -14,10 +14,7 @@
 // Q, dO are read straight from the projection layout [B][N][H][D] (no head transpose copies) and
 // O, dQ are written back in it; P leaves through an LDS staging tile as 16-byte coalesced stores.
 // The kernels are HBM/L2-bound (about 26 FLOP/B), so MFMA shape efficiency is not the concern.
-#include <mutex>
-#include <unordered_map>
-
-#include "ga_common.h"
+#include "attn_common.h"
 
 using namespace ga;
 
@@ -25,23 +22,8 @@ namespace {
 
 constexpr int kNT = 8;  // key tiles of 16 -> Kt <= 128
 
-__host__ __device__ constexpr int round16(int x) { return (x + 15) & ~15; }
-
 template <typename T, int NT>
-struct Lds {
-  static constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte vector
-  static constexpr int KP = NT * 16;          // padded key count
-  // Row strides are padded by one 16-byte vector: every row stays 16-byte aligned for the staging stores,
-  // and the MFMA fragment reads (8 B per lane, 16 rows x 4 k-groups) fall on 64 distinct banks.
-  static constexpr int VS = KP + VEC;                             // transposed [D][key] image
-  __host__ __device__ static int ks(int DP) { return DP + VEC; }  // row-major [key][D] image
-  // The transposed image is written with 2-byte stores by lanes that hold consecutive 16-byte pieces of ONE key
-  // row, i.e. image rows VEC apart: with a plain stride those all fall on two banks (20-way conflict, ~5 us per
-  // workgroup at D = 160).  Row r is therefore shifted by 4 elements per VEC rows, which walks the banks.
-  static constexpr int ROT = 4;
-  __host__ __device__ static int tr(int r) { return r * VS + ROT * (r / VEC); }
-  __host__ __device__ static int tr_size(int DP) { return DP * VS + ROT * (DP / VEC); }
-};
+using Lds = TileLds<T, NT * 16>;
 
 // Stage one (batch, head) slice [key][D] of a [B][Kt][H][D] projection into LDS as a row-major image and/or a
 // transposed image; padding keys / columns are zero-filled.  All global loads of a pass are issued before the
@@ -90,22 +72,6 @@ __device__ __forceinline__ void stage_kv2(const T* __restrict__ srcA, T* rowA, T
         for (int i = 0; i < VEC; ++i) trB[Lds<T, NT>::tr(d + i) + key] = eb[i];
       }
     }
-  }
-}
-
-// NK = number of 16-wide chunks of the (padded) head dimension, a template parameter so that the per-lane
-// fragment arrays are exactly sized and statically indexed (NK = 3 / 5 / 10 for SD-1.x, 4 for SD-2.x / SDXL).
-
-// This lane's operand fragments of one activation row X[q][:] (Q or dO), all loads issued together so that
-// they overlap the K/V staging instead of forming one global round trip per 16-wide chunk.
-template <typename T, int NK>
-__device__ __forceinline__ void load_row_frags(const T* __restrict__ xrow, bool ok, int D, int g,
-                                               typename Traits<T>::frag (&x)[NK]) {
-#pragma unroll
-  for (int kc = 0; kc < NK; ++kc) {
-    const int d = (kc << 4) + (g << 2);
-    x[kc] = zero_frag<T>();
-    if (ok && d < D) x[kc] = load_frag<T>(xrow + d);
   }
 }
 
@@ -338,23 +304,6 @@ size_t bwd_lds_bytes(int DP) {
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;
-
-// Raise a kernel's dynamic-LDS limit above the 64 KB default; remembered per kernel so that the runtime call
-// happens on the first (eager, warm-up) launch only and never inside a stream capture.
-template <typename KernelT>
-int set_dyn_lds(KernelT kernel, size_t bytes) {
-  if (bytes <= 64 * 1024) return GA_OK;
-  static std::mutex mu;
-  static std::unordered_map<const void*, size_t> granted;
-  const void* fn = reinterpret_cast<const void*>(kernel);
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = granted.find(fn);
-  if (it != granted.end() && it->second >= bytes) return GA_OK;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) return GA_ERR_LAUNCH;
-  granted[fn] = bytes;
-  return GA_OK;
-}
 
 // Dispatch on NK = ceil(D / 16): exact instantiations for the head sizes of SD-1.x (40, 80, 160), SD-2.x / SDXL
 // (64) and small test sizes; anything else runs the next larger instantiation with zero-padded chunks.

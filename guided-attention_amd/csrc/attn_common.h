@@ -1,0 +1,63 @@
+// Building blocks shared by the attention kernels (attn_capture.hip, self_attn.hip): LDS tile layouts, operand
+// fragment loads, dynamic-LDS bookkeeping.
+#pragma once
+#include <mutex>
+#include <unordered_map>
+
+#include "ga_common.h"
+
+namespace ga {
+
+__host__ __device__ constexpr int round16(int x) { return (x + 15) & ~15; }
+
+// LDS images of a [KP keys][DP] tile.
+template <typename T, int KP_>
+struct TileLds {
+  static constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte vector
+  static constexpr int KP = KP_;              // (padded) keys per tile
+  // Row strides are padded by one 16-byte vector: every row stays 16-byte aligned for the staging stores,
+  // and the MFMA fragment reads (8 B per lane, 16 rows x 4 k-groups) fall on 64 distinct banks.
+  static constexpr int VS = KP + VEC;                             // transposed [D][key] image
+  __host__ __device__ static int ks(int DP) { return DP + VEC; }  // row-major [key][D] image
+  // The transposed image is written with 2-byte stores by lanes that hold consecutive 16-byte pieces of ONE key
+  // row, i.e. image rows VEC apart: with a plain stride those all fall on two banks (20-way conflict, ~5 us per
+  // workgroup at D = 160).  Row r is therefore shifted by 4 elements per VEC rows, which walks the banks.
+  static constexpr int ROT = 4;
+  __host__ __device__ static int tr(int r) { return r * VS + ROT * (r / VEC); }
+  __host__ __device__ static int tr_size(int DP) { return DP * VS + ROT * (DP / VEC); }
+};
+
+// NK = number of 16-wide chunks of the (padded) head dimension, a template parameter so that the per-lane
+// fragment arrays are exactly sized and statically indexed (NK = 3 / 5 / 10 for SD-1.x, 4 for SD-2.x / SDXL).
+
+// This lane's operand fragments of one activation row X[q][:] (Q or dO), all loads issued together so that
+// they overlap the K/V staging instead of forming one global round trip per 16-wide chunk.
+template <typename T, int NK>
+__device__ __forceinline__ void load_row_frags(const T* __restrict__ xrow, bool ok, int D, int g,
+                                               typename Traits<T>::frag (&x)[NK]) {
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc) {
+    const int d = (kc << 4) + (g << 2);
+    x[kc] = zero_frag<T>();
+    if (ok && d < D) x[kc] = load_frag<T>(xrow + d);
+  }
+}
+
+// Raise a kernel's dynamic-LDS limit above the 64 KB default; remembered per kernel so that the runtime call
+// happens on the first (eager, warm-up) launch only and never inside a stream capture.
+template <typename KernelT>
+inline int set_dyn_lds(KernelT kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return GA_OK;
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> granted;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = granted.find(fn);
+  if (it != granted.end() && it->second >= bytes) return GA_OK;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return GA_ERR_LAUNCH;
+  granted[fn] = bytes;
+  return GA_OK;
+}
+
+}  // namespace ga

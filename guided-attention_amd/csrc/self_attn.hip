@@ -1,0 +1,695 @@
+// Tiled (flash-style) attention for long key sequences — the UNet's self-attention layers (N = 64 ... 4096
+// keys) inside the same attention processor (utils/ptp_utils.py:66-146 with encoder_hidden_states = None).
+// The reference materialises P = softmax(scale Q K^T) as an (8, 4096, 4096) tensor per 64x64 layer (268 MB in
+// fp16, x5 layers, kept alive by autograd); here P never leaves the registers.
+//
+//   forward  : O = softmax(scale Q K^T) V, plus LSE (per query, log2 domain) for the backward
+//   backward : recompute-based, two kernels without atomics (deterministic):
+//                dq    : per query block, sweeps the key tiles:  dQ  = scale * sum_k dS K
+//                dk_dv : per key block, sweeps the query tiles:  dV = P^T dO,  dK = scale * dS^T Q
+//              with dS = P o (dO V^T - delta), delta = rowsum(dO o O) (prep kernel).
+//
+// gfx950 mapping (same transposed-score trick as attn_capture.hip): a wave owns QB x 16 queries (dq / forward) or
+// QB x 16 keys (dk_dv) ON ITS LANES; the swept tile (64 rows) sits in LDS as a bank-padded row-major image and/or a
+// bank-rotated transposed image, double-buffered, next tile prefetched to registers while the current one feeds
+// v_mfma_f32_16x16x16 (f16 / bf16; exact-f32 v_mfma_f32_16x16x4 for the f32 build).  Keys (or queries) land on
+// accumulator rows, so the softmax statistics of a lane's column are in-lane + two cross-lane steps, and every
+// accumulator tile that feeds a second contraction (P -> PV, dS -> dQ / dK, P -> dV) is already in B-operand
+// layout: no LDS round trip between chained MFMAs.  Tensors stay in the projection layout [B][N][H][D].
+// Workgroup ids run head-fastest so that, with 8 heads and round-robin XCD dispatch, the workgroups that sweep one
+// head's K/V share an XCD L2.   MFMA-bound for N >= 1024 (4 N^2 D flops per head forward), latency-bound below.
+#include "attn_common.h"
+
+using namespace ga;
+
+namespace {
+
+constexpr int kTile = 64;      // rows of the swept tile (keys in fwd/dq, queries in dk_dv)
+constexpr int kThreads = 256;  // 4 waves
+
+template <typename T>
+using TL = TileLds<T, kTile>;
+
+// ---- staging: [rows][D] slice of a [B][N][H][D] tensor -> registers -> LDS images -------------------------------
+// V16 = 16-byte vectors per thread and matrix for one 64-row tile (DP*64 / VEC / 256)
+template <typename T, int NK>
+struct Stage {
+  static constexpr int VEC = TL<T>::VEC;
+  static constexpr int DP = NK * 16;
+  static constexpr int VPR = DP / VEC;                                    // vectors per row
+  static constexpr int TOTAL = kTile * VPR;                               // vectors per tile
+  static constexpr int PER = (TOTAL + kThreads - 1) / kThreads;           // vectors per thread
+  uint4 v[PER];
+
+  __device__ __forceinline__ void load(const T* __restrict__ base, int row0, int N, int D, size_t row_stride) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int idx = u * kThreads + threadIdx.x;
+      const int r = idx / VPR, d = (idx - r * VPR) * VEC;
+      v[u] = uint4{0, 0, 0, 0};
+      if (idx < TOTAL && row0 + r < N && d < D) v[u] = *reinterpret_cast<const uint4*>(base + (size_t)(row0 + r) * row_stride + d);
+    }
+  }
+  __device__ __forceinline__ void store(T* rowmaj, T* transposed) const {
+    constexpr int KS = DP + VEC;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int idx = u * kThreads + threadIdx.x;
+      if (idx >= TOTAL) continue;
+      const int r = idx / VPR, d = (idx - r * VPR) * VEC;
+      if (rowmaj) *reinterpret_cast<uint4*>(rowmaj + r * KS + d) = v[u];
+      if (transposed) {
+        const T* e = reinterpret_cast<const T*>(&v[u]);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) transposed[TL<T>::tr(d + i) + r] = e[i];
+      }
+    }
+  }
+};
+
+template <typename T, int NK>
+__host__ __device__ constexpr int row_img() { return kTile * (NK * 16 + TL<T>::VEC); }
+template <typename T, int NK>
+__host__ __device__ constexpr int tr_img() { return NK * 16 * TL<T>::VS + TL<T>::ROT * (NK * 16 / TL<T>::VEC); }
+
+// acc[rb][cb] += Img[rb*16 + .][:] . X[cb][:]   (rows of the LDS image on accumulator rows, this lane's column
+// fragments X in registers);  NRB row blocks of 16, CB column blocks
+template <typename T, int NK, int NRB, int CB>
+__device__ __forceinline__ void rows_times_cols(const T* img, const typename Traits<T>::frag (&x)[CB][NK], int c, int g,
+                                                f32x4 (&acc)[NRB][CB]) {
+  constexpr int KS = NK * 16 + TL<T>::VEC;
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) {
+      const typename Traits<T>::frag a = load_frag<T>(img + (rb * 16 + c) * KS + kc * 16 + 4 * g);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = Traits<T>::mma16(a, x[cb][kc], acc[rb][cb]);
+    }
+}
+
+// out[dt][cb] += ImgT[dt*16 + .][rows] . F[rb][cb]   (transposed image rows = feature d; contraction over the 64
+// tile rows; F = accumulator tiles converted to operand fragments)
+template <typename T, int NK, int NRB, int CB>
+__device__ __forceinline__ void featT_times_frags(const T* imgT, const typename Traits<T>::frag (&f)[NRB][CB], int c,
+                                                  int g, f32x4 (&out)[NK][CB]) {
+#pragma unroll
+  for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const typename Traits<T>::frag a = load_frag<T>(imgT + TL<T>::tr(dt * 16 + c) + rb * 16 + 4 * g);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) out[dt][cb] = Traits<T>::mma16(a, f[rb][cb], out[dt][cb]);
+    }
+}
+
+template <typename T, int NK, int CB>
+__device__ __forceinline__ void load_col_frags(const T* __restrict__ base, size_t row_stride, int row0, int N, int D,
+                                               int c, int g, typename Traits<T>::frag (&x)[CB][NK]) {
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    const int row = row0 + cb * 16 + c;
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) {
+      const int d = kc * 16 + 4 * g;
+      x[cb][kc] = zero_frag<T>();
+      if (row < N && d < D) x[cb][kc] = load_frag<T>(base + (size_t)row * row_stride + d);
+    }
+  }
+}
+
+// out^T accumulators [NK][CB] (feature rows, this lane's column) -> global rows [col][d], scaled per column block
+template <typename T, int NK, int CB>
+__device__ __forceinline__ void store_colsT(T* __restrict__ base, size_t row_stride, int row0, int N, int D, int c,
+                                            int g, const f32x4 (&acc)[NK][CB], const float (&mul)[CB]) {
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    const int row = row0 + cb * 16 + c;
+    if (row >= N) continue;
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) {
+      const int d = dt * 16 + 4 * g;
+      if (d < D) {
+        typename Traits<T>::frag o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = Traits<T>::from_f32(acc[dt][cb][r] * mul[cb]);
+        store_frag<T>(base + (size_t)row * row_stride + d, o);
+      }
+    }
+  }
+}
+
+// raw v_exp_f32: arguments here are <= 0 (or the result is multiplied by something that dominates), so the
+// denormal-range fix-up sequence of exp2f (compare / select / ldexp per element) is dead weight
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ float quad_max(float v) {  // over the 4 lanes (g = 0..3) that share a column
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// Power-of-two running scale for accumulator tiles that enter a 16-bit MFMA as operands (dS): values are kept
+// <= 1 in magnitude relative to the largest seen so far; returns the exponent to apply now and rescales `acc`
+// (exact) when a larger magnitude arrives.  E is the current exponent (acc holds true * 2^E).
+template <int NK, int CB>
+__device__ __forceinline__ void rescale_running(float amax, int cb, int& E, f32x4 (&acc)[NK][CB]) {
+  if (!(amax > 0.f) || amax == INFINITY) return;
+  int e;
+  (void)frexpf(amax, &e);  // amax = m * 2^e, m in [0.5, 1)
+  const int want = -e;
+  if (want < E) {
+    const float f = ldexpf(1.0f, want - E);
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[dt][cb][r] *= f;
+    E = want;
+  }
+}
+
+constexpr int kNoExp = 100;  // "no data yet" exponent (2^100 * 0 = 0)
+
+// =================================================================================================== forward
+template <typename T, int NK, int QB, int NBUF>
+__global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                                 const T* __restrict__ V, T* __restrict__ O,
+                                                                 float* __restrict__ LSE, int H, int N, int D, int nqt,
+                                                                 float scale) {
+  using Tr = Traits<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // one buffer = [K row-major | V transposed]; buffers are addressed as base + cur * kBuf so that the compiler
+  // keeps the LDS address space (a local array of pointers decays to generic pointers -> flat_load + vmcnt(0))
+  T* const lds = reinterpret_cast<T*>(smem);
+  constexpr int kBuf = NBUF == 2 ? row_img<T, NK>() + tr_img<T, NK>() : 0;
+  constexpr int kVoff = row_img<T, NK>();
+
+  const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const size_t rs = (size_t)H * D;  // row stride of the [N][H][D] slice
+  const T* Qb = Q + ((size_t)b * N * H + head) * D;
+  const T* Kb = K + ((size_t)b * N * H + head) * D;
+  const T* Vb = V + ((size_t)b * N * H + head) * D;
+  const int q0 = qt * (4 * QB * 16) + wave * (QB * 16);
+  const float c1 = scale * 1.4426950408889634f;
+
+  typename Tr::frag qf[QB][NK];
+  load_col_frags<T, NK, QB>(Qb, rs, q0, N, D, c, g, qf);
+
+  Stage<T, NK> sk, sv;
+  sk.load(Kb, 0, N, D, rs);
+  sv.load(Vb, 0, N, D, rs);
+  sk.store(lds, nullptr);
+  sv.store(nullptr, lds + kVoff);
+  __syncthreads();
+
+  f32x4 o[NK][QB];
+  float m[QB], l[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m[qb] = -INFINITY;
+    l[qb] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) o[dt][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int ntiles = (N + kTile - 1) / kTile;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < ntiles) {  // prefetch the next tile into registers; it lands in LDS after this tile's math
+      sk.load(Kb, (kt + 1) * kTile, N, D, rs);
+      sv.load(Vb, (kt + 1) * kTile, N, D, rs);
+    }
+    f32x4 s[4][QB];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) s[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const T* kimg = lds + cur * kBuf;
+    const T* vimg = kimg + kVoff;
+    rows_times_cols<T, NK, 4, QB>(kimg, qf, c, g, s);
+    const int key0 = kt * kTile;
+    if (key0 + kTile > N) {  // only the last, partial tile needs the key mask (uniform branch)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + kb * 16 + 4 * g + r >= N) s[kb][qb][r] = -INFINITY;
+    }
+    typename Tr::frag pf[4][QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
+      mx = quad_max(mx);
+      const float mn = fmaxf(m[qb], mx);
+      const float mc = mn * c1;
+      const float alpha = fast_exp2(m[qb] * c1 - mc);  // exp2(-inf) = 0 on the first tile
+      float sum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp2(s[kb][qb][r] * c1 - mc);
+          sum += p;
+          pf[kb][qb][r] = Tr::from_f32(p);
+        }
+      l[qb] = l[qb] * alpha + quad_sum(sum);
+      m[qb] = mn;
+#pragma unroll
+      for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][qb][r] *= alpha;
+    }
+    featT_times_frags<T, NK, 4, QB>(vimg, pf, c, g, o);
+    if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before it is overwritten
+    if (kt + 1 < ntiles) {
+      T* nxt = lds + (cur ^ 1) * kBuf;
+      sk.store(nxt, nullptr);
+      sv.store(nullptr, nxt + kVoff);
+    }
+    __syncthreads();
+  }
+  float inv[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    inv[qb] = 1.0f / l[qb];
+    const int q = q0 + qb * 16 + c;
+    if (LSE != nullptr && g == 0 && q < N) LSE[((size_t)b * H + head) * N + q] = m[qb] * c1 + log2f(l[qb]);
+  }
+  store_colsT<T, NK, QB>(O + ((size_t)b * N * H + head) * D, rs, q0, N, D, c, g, o, inv);
+}
+
+// =================================================================================================== backward prep
+// delta[bh][q] = sum_d dO[q][d] * O[q][d]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void self_attn_delta_kernel(const T* __restrict__ O, const T* __restrict__ dO,
+                                                                   float* __restrict__ delta, int H, int N, int D,
+                                                                   long long rows) {
+  const long long row = (long long)blockIdx.x * kThreads + threadIdx.x;  // row = (b*N + q)*H + head
+  if (row >= rows) return;
+  const T* o = O + row * D;
+  const T* d = dO + row * D;
+  float acc = 0.f;
+  for (int i = 0; i < D; i += 4) {
+    const typename Traits<T>::frag a = load_frag<T>(o + i), e = load_frag<T>(d + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc += Traits<T>::to_f32(a[j]) * Traits<T>::to_f32(e[j]);
+  }
+  const long long head = row % H, bq = row / H, q = bq % N, b = bq / N;
+  delta[((size_t)b * H + head) * N + q] = acc;
+}
+
+// =================================================================================================== backward dQ
+template <typename T, int NK, int QB, int NBUF>
+__global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                                    const T* __restrict__ V, const T* __restrict__ dO,
+                                                                    const float* __restrict__ LSE,
+                                                                    const float* __restrict__ delta,
+                                                                    T* __restrict__ dQ, int H, int N, int D, int nqt,
+                                                                    float scale) {
+  using Tr = Traits<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // one buffer = [K row-major | V row-major | K transposed]
+  T* const lds = reinterpret_cast<T*>(smem);
+  constexpr int kVoff = row_img<T, NK>(), kToff = 2 * row_img<T, NK>();
+  constexpr int kBuf = NBUF == 2 ? 2 * row_img<T, NK>() + tr_img<T, NK>() : 0;
+  const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const size_t rs = (size_t)H * D;
+  const size_t off = ((size_t)b * N * H + head) * D;
+  const int q0 = qt * (4 * QB * 16) + wave * (QB * 16);
+  const float c1 = scale * 1.4426950408889634f;
+
+  typename Tr::frag qf[QB][NK], dof[QB][NK];
+  load_col_frags<T, NK, QB>(Q + off, rs, q0, N, D, c, g, qf);
+  load_col_frags<T, NK, QB>(dO + off, rs, q0, N, D, c, g, dof);
+  float lse[QB], dl[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = q0 + qb * 16 + c;
+    lse[qb] = q < N ? LSE[((size_t)b * H + head) * N + q] : 0.f;
+    dl[qb] = q < N ? delta[((size_t)b * H + head) * N + q] : 0.f;
+  }
+  Stage<T, NK> sk, sv;
+  sk.load(K + off, 0, N, D, rs);
+  sv.load(V + off, 0, N, D, rs);
+  sk.store(lds, lds + kToff);
+  sv.store(lds + kVoff, nullptr);
+  __syncthreads();
+
+  f32x4 acc[NK][QB];
+  int E[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    E[qb] = kNoExp;
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) acc[dt][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int ntiles = (N + kTile - 1) / kTile;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < ntiles) {
+      sk.load(K + off, (kt + 1) * kTile, N, D, rs);
+      sv.load(V + off, (kt + 1) * kTile, N, D, rs);
+    }
+    f32x4 s[4][QB], dp[4][QB];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) s[kb][qb] = dp[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const T* buf = lds + cur * kBuf;
+    rows_times_cols<T, NK, 4, QB>(buf, qf, c, g, s);
+    rows_times_cols<T, NK, 4, QB>(buf + kVoff, dof, c, g, dp);
+    const int key0 = kt * kTile;
+    if (key0 + kTile > N) {  // partial last tile: masked keys get p = exp2(-inf) = 0
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + kb * 16 + 4 * g + r >= N) s[kb][qb][r] = -INFINITY;
+    }
+    typename Tr::frag dsf[4][QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float amax = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp2(s[kb][qb][r] * c1 - lse[qb]);
+          const float ds = p * (dp[kb][qb][r] - dl[qb]);
+          s[kb][qb][r] = ds;
+          amax = fmaxf(amax, fabsf(ds));
+        }
+      if (sizeof(T) == 2) rescale_running<NK, QB>(quad_max(amax), qb, E[qb], acc);
+      const float f = (sizeof(T) == 2 && E[qb] != kNoExp) ? ldexpf(1.0f, E[qb]) : 1.0f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsf[kb][qb][r] = Tr::from_f32(s[kb][qb][r] * f);
+    }
+    featT_times_frags<T, NK, 4, QB>(buf + kToff, dsf, c, g, acc);
+    if (NBUF == 1) __syncthreads();
+    if (kt + 1 < ntiles) {
+      T* nxt = lds + (cur ^ 1) * kBuf;
+      sk.store(nxt, nxt + kToff);
+      sv.store(nxt + kVoff, nullptr);
+    }
+    __syncthreads();
+  }
+  float mul[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) mul[qb] = (sizeof(T) == 2 && E[qb] != kNoExp) ? scale * ldexpf(1.0f, -E[qb]) : scale;
+  store_colsT<T, NK, QB>(dQ + off, rs, q0, N, D, c, g, acc, mul);
+}
+
+// =================================================================================================== backward dK, dV
+// A wave owns KB x 16 keys on its lanes; the workgroup sweeps 64-query tiles (Q and dO row-major + transposed images).
+template <typename T, int NK, int KB, int NBUF>
+__global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                                      const T* __restrict__ V,
+                                                                      const T* __restrict__ dO,
+                                                                      const float* __restrict__ LSE,
+                                                                      const float* __restrict__ delta,
+                                                                      T* __restrict__ dK, T* __restrict__ dV, int H,
+                                                                      int N, int D, int nkt, float scale) {
+  using Tr = Traits<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // one buffer = [Q row-major | Q transposed | dO row-major | dO transposed]; then the per-query LSE / delta rows
+  T* const lds = reinterpret_cast<T*>(smem);
+  constexpr int kQt = row_img<T, NK>(), kDr = kQt + tr_img<T, NK>(), kDt = kDr + row_img<T, NK>();
+  constexpr int kOne = 2 * row_img<T, NK>() + 2 * tr_img<T, NK>();
+  constexpr int kBuf = NBUF == 2 ? kOne : 0;
+  float* const stats = reinterpret_cast<float*>(lds + NBUF * kOne);  // [2][2][kTile]: (LSE, delta) per buffer
+  constexpr int kSbuf = 2 * kTile;
+  const int head = blockIdx.x % H, rest = blockIdx.x / H, ktile = rest % nkt, b = rest / nkt;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const size_t rs = (size_t)H * D;
+  const size_t off = ((size_t)b * N * H + head) * D;
+  const size_t soff = ((size_t)b * H + head) * N;
+  const int k0 = ktile * (4 * KB * 16) + wave * (KB * 16);
+  const float c1 = scale * 1.4426950408889634f;
+
+  typename Tr::frag kf[KB][NK], vf[KB][NK];
+  load_col_frags<T, NK, KB>(K + off, rs, k0, N, D, c, g, kf);
+  load_col_frags<T, NK, KB>(V + off, rs, k0, N, D, c, g, vf);
+
+  Stage<T, NK> sq, sd;
+  float pl = 0.f, pd = 0.f;  // this thread's prefetched LSE / delta entry (threads 0..63)
+  auto load_stats = [&](int q0t) {
+    if (threadIdx.x < kTile) {
+      const int q = q0t + threadIdx.x;
+      pl = q < N ? LSE[soff + q] : 0.f;
+      pd = q < N ? delta[soff + q] : 0.f;
+    }
+  };
+  sq.load(Q + off, 0, N, D, rs);
+  sd.load(dO + off, 0, N, D, rs);
+  load_stats(0);
+  sq.store(lds, lds + kQt);
+  sd.store(lds + kDr, lds + kDt);
+  if (threadIdx.x < kTile) {
+    stats[threadIdx.x] = pl;
+    stats[kTile + threadIdx.x] = pd;
+  }
+  __syncthreads();
+
+  f32x4 dk[NK][KB], dv[NK][KB];
+  int E[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    E[kb] = kNoExp;
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) dk[dt][kb] = dv[dt][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int ntiles = (N + kTile - 1) / kTile;
+  for (int qt = 0; qt < ntiles; ++qt) {
+    const int cur = qt & 1;
+    if (qt + 1 < ntiles) {
+      sq.load(Q + off, (qt + 1) * kTile, N, D, rs);
+      sd.load(dO + off, (qt + 1) * kTile, N, D, rs);
+      load_stats((qt + 1) * kTile);
+    }
+    // S[q rows][key cols] and dP[q rows][key cols]
+    f32x4 s[4][KB], dp[4][KB];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) s[qb][kb] = dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const T* buf = lds + cur * kBuf;
+    const float* Lq = stats + cur * kSbuf;
+    const float* Dq = Lq + kTile;
+    rows_times_cols<T, NK, 4, KB>(buf, kf, c, g, s);
+    rows_times_cols<T, NK, 4, KB>(buf + kDr, vf, c, g, dp);
+    const int q0t = qt * kTile;
+    typename Tr::frag pf[4][KB], dsf[4][KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const bool key_live = k0 + kb * 16 + c < N;
+      float amax = 0.f;
+#pragma unroll
+      for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = qb * 16 + 4 * g + r;
+          const bool live = key_live && (q0t + qi < N);
+          const float p = live ? fast_exp2(s[qb][kb][r] * c1 - Lq[qi]) : 0.f;
+          const float ds = p * (dp[qb][kb][r] - Dq[qi]);
+          pf[qb][kb][r] = Tr::from_f32(p);
+          s[qb][kb][r] = ds;
+          amax = fmaxf(amax, fabsf(ds));
+        }
+      if (sizeof(T) == 2) rescale_running<NK, KB>(quad_max(amax), kb, E[kb], dk);
+      const float f = (sizeof(T) == 2 && E[kb] != kNoExp) ? ldexpf(1.0f, E[kb]) : 1.0f;
+#pragma unroll
+      for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsf[qb][kb][r] = Tr::from_f32(s[qb][kb][r] * f);
+    }
+    featT_times_frags<T, NK, 4, KB>(buf + kDt, pf, c, g, dv);  // dV^T += dO^T P
+    featT_times_frags<T, NK, 4, KB>(buf + kQt, dsf, c, g, dk);  // dK^T += Q^T dS
+    if (NBUF == 1) __syncthreads();
+    if (qt + 1 < ntiles) {
+      T* nxt = lds + (cur ^ 1) * kBuf;
+      sq.store(nxt, nxt + kQt);
+      sd.store(nxt + kDr, nxt + kDt);
+      if (threadIdx.x < kTile) {
+        stats[(cur ^ 1) * kSbuf + threadIdx.x] = pl;
+        stats[(cur ^ 1) * kSbuf + kTile + threadIdx.x] = pd;
+      }
+    }
+    __syncthreads();
+  }
+  float mk[KB], one[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    mk[kb] = (sizeof(T) == 2 && E[kb] != kNoExp) ? scale * ldexpf(1.0f, -E[kb]) : scale;
+    one[kb] = 1.0f;
+  }
+  store_colsT<T, NK, KB>(dK + off, rs, k0, N, D, c, g, dk, mk);
+  store_colsT<T, NK, KB>(dV + off, rs, k0, N, D, c, g, dv, one);
+}
+
+// =================================================================================================== host side
+// LDS tile buffers: double-buffered for the 16-bit types at head sizes <= 80 (the long-sequence layers, where the
+// prefetch matters); single-buffered otherwise so that D = 160 and the f32 build fit in 160 KB
+template <typename T, int NK>
+struct Bufs {
+  static constexpr int value = (sizeof(T) == 2 && NK <= 5) ? 2 : 1;
+};
+template <typename T, int NK>
+size_t fwd_lds() { return sizeof(T) * Bufs<T, NK>::value * (row_img<T, NK>() + tr_img<T, NK>()); }
+template <typename T, int NK>
+size_t dq_lds() { return sizeof(T) * Bufs<T, NK>::value * (2 * row_img<T, NK>() + tr_img<T, NK>()); }
+template <typename T, int NK>
+size_t dkdv_lds() {
+  return sizeof(T) * Bufs<T, NK>::value * (2 * row_img<T, NK>() + 2 * tr_img<T, NK>()) + sizeof(float) * 4 * kTile;
+}
+
+constexpr size_t kLdsLimit = 160 * 1024;
+
+// Columns (queries, or keys in dk_dv) per wave = 16 * CB.  CB = 2 halves the LDS operand traffic per MFMA but needs
+// ~200 VGPRs and halves the number of workgroups; at batch 1-2 the layers only have 1024-2048 column blocks in all,
+// and a lone wave per SIMD cannot hide its own MFMA / LDS / exp latencies.  Measured on the 4096-token layer:
+// B = 1: CB = 1 116 us vs CB = 2 139 us; B = 2: CB = 2 170 us vs CB = 1 254 us.  Hence: CB = 2 only when it still
+// leaves >= 512 workgroups (2 per CU) and the head is small enough for the register budget.
+template <int NK>
+bool wide_columns(int B, int H, int N) {
+  return NK <= 5 && (long long)B * H * ((N + 127) / 128) >= 512;
+}
+
+template <typename T, int NK, int QB>
+int launch_fwd_cb(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D,
+                  float scale, hipStream_t s) {
+  const size_t lds = fwd_lds<T, NK>();
+  if (lds > kLdsLimit) return GA_ERR_SHAPE;
+  const int nqt = (N + 64 * QB - 1) / (64 * QB);
+  auto k = self_attn_fwd_kernel<T, NK, QB, Bufs<T, NK>::value>;
+  int rc = set_dyn_lds(k, lds);
+  if (rc != GA_OK) return rc;
+  hipLaunchKernelGGL(k, dim3((unsigned)(B * H * nqt)), dim3(kThreads), lds, s, (const T*)Q, (const T*)K, (const T*)V,
+                     (T*)O, LSE, H, N, D, nqt, scale);
+  return check_launch();
+}
+
+template <typename T, int NK>
+int launch_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D, float scale,
+               hipStream_t s) {
+  if constexpr (NK <= 5) {
+    if (wide_columns<NK>(B, H, N)) return launch_fwd_cb<T, NK, 2>(Q, K, V, O, LSE, B, H, N, D, scale, s);
+  }
+  return launch_fwd_cb<T, NK, 1>(Q, K, V, O, LSE, B, H, N, D, scale, s);
+}
+
+template <typename T, int NK, int CB>
+int launch_bwd_cb(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                  float* delta, void* dQ, void* dK, void* dV, int B, int H, int N, int D, float scale, hipStream_t s) {
+  const size_t l1 = dq_lds<T, NK>(), l2 = dkdv_lds<T, NK>();
+  if (l1 > kLdsLimit || l2 > kLdsLimit) return GA_ERR_SHAPE;
+  const long long rows = (long long)B * N * H;
+  hipLaunchKernelGGL(self_attn_delta_kernel<T>, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     s, (const T*)O, (const T*)dO, delta, H, N, D, rows);
+  const int nt = (N + 64 * CB - 1) / (64 * CB);
+  auto kq = self_attn_bwd_dq_kernel<T, NK, CB, Bufs<T, NK>::value>;
+  auto kk = self_attn_bwd_dkdv_kernel<T, NK, 1, Bufs<T, NK>::value>;  // dk_dv: 16 keys per wave (register budget)
+  int rc = set_dyn_lds(kq, l1);
+  if (rc != GA_OK) return rc;
+  rc = set_dyn_lds(kk, l2);
+  if (rc != GA_OK) return rc;
+  hipLaunchKernelGGL(kq, dim3((unsigned)(B * H * nt)), dim3(kThreads), l1, s, (const T*)Q, (const T*)K, (const T*)V,
+                     (const T*)dO, LSE, (const float*)delta, (T*)dQ, H, N, D, nt, scale);
+  const int nk = (N + 63) / 64;
+  hipLaunchKernelGGL(kk, dim3((unsigned)(B * H * nk)), dim3(kThreads), l2, s, (const T*)Q, (const T*)K, (const T*)V,
+                     (const T*)dO, LSE, (const float*)delta, (T*)dK, (T*)dV, H, N, D, nk, scale);
+  return check_launch();
+}
+
+template <typename T, int NK>
+int launch_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+               float* delta, void* dQ, void* dK, void* dV, int B, int H, int N, int D, float scale, hipStream_t s) {
+  if constexpr (NK <= 5) {
+    if (wide_columns<NK>(B, H, N))
+      return launch_bwd_cb<T, NK, 2>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, scale, s);
+  }
+  return launch_bwd_cb<T, NK, 1>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, scale, s);
+}
+
+#define GA_SA_NK(CALL)                                  \
+  do {                                                  \
+    const int nk = (D + 15) / 16;                       \
+    if (nk <= 1) return CALL(1);                        \
+    if (nk == 2) return CALL(2);                        \
+    if (nk == 3) return CALL(3);                        \
+    if (nk == 4) return CALL(4);                        \
+    if (nk == 5) return CALL(5);                        \
+    if (nk <= 8) return CALL(8);                        \
+    if (nk <= 10) return CALL(10);                      \
+    return GA_ERR_SHAPE;                                \
+  } while (0)
+
+int check_args(int B, int H, int N, int D) {
+  if (B <= 0 || H <= 0 || N <= 0 || D <= 0 || D > 160) return GA_ERR_SHAPE;
+  if (D % 8 != 0) return GA_ERR_ALIGN;
+  if ((long long)B * H * ((N + 63) / 64) > 0x7fffffffLL) return GA_ERR_SHAPE;
+  return GA_OK;
+}
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+int fwd_t(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D, float scale,
+          hipStream_t s) {
+#define GA_CALL(NKV) launch_fwd<T, NKV>(Q, K, V, O, LSE, B, H, N, D, scale, s)
+  GA_SA_NK(GA_CALL);
+#undef GA_CALL
+}
+template <typename T>
+int bwd_t(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* delta,
+          void* dQ, void* dK, void* dV, int B, int H, int N, int D, float scale, hipStream_t s) {
+#define GA_CALL(NKV) launch_bwd<T, NKV>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, scale, s)
+  GA_SA_NK(GA_CALL);
+#undef GA_CALL
+}
+
+}  // namespace
+
+extern "C" int ga_self_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N,
+                                int D, float scale, int dtype, ga_stream_t stream) {
+  if (!Q || !K || !V || !O) return GA_ERR_NULL;
+  int rc = check_args(B, H, N, D);
+  if (rc != GA_OK) return rc;
+  if (!al16(Q) || !al16(K) || !al16(V) || !al16(O)) return GA_ERR_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case GA_F16: return fwd_t<_Float16>(Q, K, V, O, LSE, B, H, N, D, scale, s);
+    case GA_BF16: return fwd_t<bf16_t>(Q, K, V, O, LSE, B, H, N, D, scale, s);
+    case GA_F32: return fwd_t<float>(Q, K, V, O, LSE, B, H, N, D, scale, s);
+    default: return GA_ERR_DTYPE;
+  }
+}
+
+extern "C" int ga_self_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                                const float* LSE, float* delta, void* dQ, void* dK, void* dV, int B, int H, int N,
+                                int D, float scale, int dtype, ga_stream_t stream) {
+  if (!Q || !K || !V || !O || !dO || !LSE || !delta || !dQ || !dK || !dV) return GA_ERR_NULL;
+  int rc = check_args(B, H, N, D);
+  if (rc != GA_OK) return rc;
+  if (!al16(Q) || !al16(K) || !al16(V) || !al16(O) || !al16(dO) || !al16(dQ) || !al16(dK) || !al16(dV))
+    return GA_ERR_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case GA_F16: return bwd_t<_Float16>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, scale, s);
+    case GA_BF16: return bwd_t<bf16_t>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, scale, s);
+    case GA_F32: return bwd_t<float>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, scale, s);
+    default: return GA_ERR_DTYPE;
+  }
+}

@@ -363,3 +363,54 @@ class GroupNormAct(torch.autograd.Function):
 
 def group_norm_act(x, weight, bias, groups, eps, act):
     return GroupNormAct.apply(x, weight, bias, groups, eps, act)
+
+
+# --------------------------------------------------------------------------------------- tiled self-attention
+def self_attn_fwd(q, k, v, heads, scale, want_lse=True):
+    """q,k,v (B,N,C) projections -> (o (B,N,C), lse (B*heads,N) f32 log2-domain or None)."""
+    require_cuda(q, k, v)
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    B, N, C = q.shape
+    o = torch.empty_like(q)
+    lse = torch.empty((B * heads, N), dtype=torch.float32, device=q.device) if want_lse else None
+    check(load().ga_self_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), B, heads, N, C // heads, float(scale),
+                                  dtype_code(q), stream_ptr()), "ga_self_attn_fwd")
+    return o, lse
+
+
+def self_attn_bwd(q, k, v, o, d_o, lse, heads, scale):
+    require_cuda(q, k, v, o, d_o, lse)
+    B, N, C = q.shape
+    d_o = d_o.contiguous()
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty_like(lse)
+    check(load().ga_self_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(delta), _ptr(dq),
+                                  _ptr(dk), _ptr(dv), B, heads, N, C // heads, float(scale), dtype_code(q),
+                                  stream_ptr()), "ga_self_attn_bwd")
+    return dq, dk, dv
+
+
+class SelfAttention(torch.autograd.Function):
+    """softmax(scale q k^T) v for long key sequences; the probabilities are never materialised."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        need = any(ctx.needs_input_grad[:3])
+        o, lse = self_attn_fwd(q, k, v, heads, scale, want_lse=need)
+        if need:
+            ctx.save_for_backward(q, k, v, o, lse)
+        ctx.meta = (heads, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, lse = ctx.saved_tensors
+        heads, scale = ctx.meta
+        dq, dk, dv = self_attn_bwd(q, k, v, o, d_o, lse, heads, scale)
+        return dq, dk, dv, None, None
+
+
+def self_attention_supported(q, heads):
+    d = q.shape[-1] // heads
+    return q.is_cuda and d % 8 == 0 and d <= (80 if q.dtype == torch.float32 else 160) and q.dtype in _lib.DTYPE_CODE

@@ -33,13 +33,15 @@ class ProbsNotCaptured:
 
 
 def _tiled_attention(q, k, v, heads, scale):
-    """softmax(scale q k^T) v for long key sequences (self-attention), probabilities never materialised.
-    q,k,v: (B, N, heads*d) projections -> (B, N, heads*d)."""
-    B, N, C = q.shape
-    d = C // heads
-    qh, kh, vh = (t.view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
-    o = F.scaled_dot_product_attention(qh, kh, vh, scale=scale)
-    return o.transpose(1, 2).reshape(B, N, C)
+    """softmax(scale q k^T) v for long key sequences (self-attention), probabilities never materialised:
+    the HIP flash kernels (ga_self_attn_fwd/bwd).  q,k,v: (B, N, heads*d) projections -> (B, N, heads*d)."""
+    if not q.is_cuda:
+        raise GaError("attention runs on the GPU only; there is no CPU fallback")
+    if ops.self_attention_supported(q, heads):
+        return ops.SelfAttention.apply(q, k, v, heads, scale)
+    # outside the kernels' envelope (f32 with head_dim > 80, head_dim > 160 or not a multiple of 8): the
+    # materialising GPU path, explicitly
+    return _materialised_attention(q, k, v, heads, scale)[0]
 
 
 def _materialised_attention(q, k, v, heads, scale):
@@ -86,8 +88,6 @@ class AttendExciteCrossAttnProcessor:
         elif want:
             out, probs = _materialised_attention(query, key, value, attn.heads, attn.scale)
         else:
-            if not query.is_cuda:
-                raise GaError("attention runs on the GPU only; there is no CPU fallback")
             out = _tiled_attention(query, key, value, attn.heads, attn.scale)
         if store is not None:
             if probs is None:

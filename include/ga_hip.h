@@ -151,6 +151,19 @@ int ga_cfg_ddim_step(const void* eps_uncond, const void* eps_text, float guidanc
                      ga_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Tiled self-attention for long key sequences (the encoder_hidden_states = None case of the processor,
+ * utils/ptp_utils.py:66-93 with :97-146): O = softmax(scale Q K^T) V without materialising P.
+ *   Q,K,V,O,dO,dQ,dK,dV [B][N][H][D] T (projection layout); LSE, delta [B*H][N] f32 (LSE is written by the
+ *   forward, in the log2 domain, and read by the backward; delta is scratch the backward fills).
+ *   D % 8 == 0, D <= 160 (f32: D <= 80).  Backward = 3 launches (delta, dQ, dK+dV), no atomics.
+ */
+int ga_self_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE,
+                     int B, int H, int N, int D, float scale, int dtype, ga_stream_t stream);
+int ga_self_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                     const float* LSE, float* delta, void* dQ, void* dK, void* dV,
+                     int B, int H, int N, int D, float scale, int dtype, ga_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * UNet host helper: GroupNorm (+ fused SiLU) on channels-last activations, forward and backward to the
  * input.  Stands in for the GroupNorm -> SiLU pairs of the diffusers UNet blocks the reference runs in
  * pipeline_guided_attention.py:583-743 (diffusers 0.12.1 ResnetBlock2D / Transformer2DModel).

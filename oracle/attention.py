@@ -116,3 +116,8 @@ def capture_bwd_numpy(Q, K, V, scale, dO, dP_direct=None):
     dK = scale * dS.transpose(0, 2, 1) @ Q
     dV = P.transpose(0, 2, 1) @ dO
     return dQ, dK, dV
+
+
+def full_bwd_numpy(Q, K, V, scale, dO):
+    """All three gradients of O = softmax(scale Q K^T) V (the algebra of ga_self_attn_bwd)."""
+    return capture_bwd_numpy(Q, K, V, scale, dO, None)

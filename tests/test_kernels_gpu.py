@@ -372,3 +372,66 @@ def test_group_norm_act(ops, shape, act, dt):
     stride_input = x.contiguous()  # NCHW input is accepted and converted
     y2 = ops.group_norm_act(stride_input, w, b, 32, 1e-5, act)
     assert torch.equal(y2, y.detach())
+
+
+# ------------------------------------------------------------------------------------- tiled self-attention
+SA_SHAPES = [  # B, H, N, D
+    (1, 8, 4096, 40), (1, 8, 1024, 80), (1, 8, 256, 160), (1, 8, 64, 160), (2, 8, 1024, 80),  # SD-1.x layers
+    (1, 5, 576, 64), (1, 2, 1000, 40), (1, 2, 130, 16), (1, 3, 77, 8), (1, 1, 2, 8), (2, 2, 200, 48), (1, 2, 65, 128),
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", SA_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_self_attention_fwd_bwd(ops, shape, dt):
+    B, H, N, D = shape
+    if dt == "f32" and D > 80:
+        pytest.skip("f32 build covers head_dim <= 80")
+    spread = 1.5 if N <= 1024 else 1.0
+    q = dev(hashrand.normalish((B, N, H * D), 11 + N) * spread, DT[dt])
+    k = dev(hashrand.normalish((B, N, H * D), 12 + N) * spread, DT[dt])
+    v = dev(hashrand.normalish((B, N, H * D), 13 + N), DT[dt])
+    d_o = dev(hashrand.normalish((B, N, H * D), 14 + N), DT[dt])
+    scale = D ** -0.5
+    o, lse = ops.self_attn_fwd(q, k, v, H, scale)
+    Pref, Oref = oattn.capture_fwd_numpy(to_bh(q, H), to_bh(k, H), to_bh(v, H), scale)
+    close(o, from_bh(Oref, B, H), TOL[dt], "O")
+    S = scale * np.einsum("bnd,bmd->bnm", to_bh(q, H), to_bh(k, H))
+    lse_ref = (np.log(np.exp(S - S.max(-1, keepdims=True)).sum(-1)) + S.max(-1)) / np.log(2.0)
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref, rtol=0, atol={"f32": 2e-4, "f16": 2e-2, "bf16": 1e-1}[dt])
+    dq, dk, dv = ops.self_attn_bwd(q, k, v, o, d_o, lse, H, scale)
+    # reference gradients use the kernel's own (rounded) O for delta, like any flash backward
+    dQ, dK, dV = oattn.full_bwd_numpy(to_bh(q, H), to_bh(k, H), to_bh(v, H), scale, to_bh(d_o, H))
+    close(dq, from_bh(dQ, B, H), TOL[dt] * 3, "dQ")
+    close(dk, from_bh(dK, B, H), TOL[dt] * 3, "dK")
+    close(dv, from_bh(dV, B, H), TOL[dt] * 3, "dV")
+
+
+def test_self_attention_tiny_upstream_gradients_fp16(ops):
+    """Small upstream gradients (dO ~ 1e-3 -> dS ~ 1e-5, below fp16's normal range 6e-5): the running
+    power-of-two rescale must keep dQ / dK at operand-rounding accuracy.  (Smaller dO would make the fp16
+    OUTPUTS subnormal, which no kernel can fix.)"""
+    B, H, N, D = 1, 8, 1024, 80
+    q = dev(hashrand.normalish((B, N, H * D), 21), torch.float16)
+    k = dev(hashrand.normalish((B, N, H * D), 22), torch.float16)
+    v = dev(hashrand.normalish((B, N, H * D), 23), torch.float16)
+    d_o = dev(hashrand.normalish((B, N, H * D), 24) * 1e-3, torch.float16)
+    o, lse = ops.self_attn_fwd(q, k, v, H, D ** -0.5)
+    dq, dk, dv = ops.self_attn_bwd(q, k, v, o, d_o, lse, H, D ** -0.5)
+    dQ, dK, dV = oattn.full_bwd_numpy(to_bh(q, H), to_bh(k, H), to_bh(v, H), D ** -0.5, to_bh(d_o, H))
+    close(dq, from_bh(dQ, B, H), 8e-3, "dQ tiny")
+    close(dk, from_bh(dK, B, H), 8e-3, "dK tiny")
+    close(dv, from_bh(dV, B, H), 8e-3, "dV tiny")
+
+
+def test_self_attention_autograd(ops):
+    B, H, N, D = 1, 4, 300, 40
+    q, k, v = (dev(hashrand.normalish((B, N, H * D), 31 + i), torch.float32).requires_grad_(True) for i in range(3))
+    w = dev(hashrand.normalish((B, N, H * D), 35), torch.float32)
+    (ops.SelfAttention.apply(q, k, v, H, D ** -0.5) * w).sum().backward()
+    q2, k2, v2 = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (oattn.head_split(t, H) for t in (q2, k2, v2))
+    ref = oattn.head_merge(torch.bmm(torch.softmax(torch.bmm(qh, kh.transpose(1, 2)) * D ** -0.5, -1), vh), H)
+    (ref * w).sum().backward()
+    for a, b, n in ((q, q2, "dq"), (k, k2, "dk"), (v, v2, "dv")):
+        close(a.grad, b.grad.double().cpu().numpy(), 1e-4, n)

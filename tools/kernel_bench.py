@@ -34,5 +34,63 @@ def main():
                 print(f"{kind:18s} {B:2d} {N:5d} {D:4d} {str(flag):>5s} {us:8.2f} {gbs:8.1f} {gbs / 8000:6.3f}", flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--self-attn" not in sys.argv:
     main()
+
+
+def self_attn_bench():
+    import torch
+    print(f"\n{'self-attn':12s} {'B':>2s} {'N':>5s} {'D':>4s} {'fwd us':>8s} {'TF/s':>7s} {'bwd us':>8s} {'TF/s':>7s}   (SDPA fwd us, bwd us)")
+    for B, N, D in ((1, 4096, 40), (2, 4096, 40), (1, 1024, 80), (2, 1024, 80), (1, 256, 160), (1, 64, 160)):
+        H = 8
+        q, k, v, do = (torch.randn(B, N, H * D, device="cuda", dtype=torch.half) for _ in range(4))
+        o, lse = ops.self_attn_fwd(q, k, v, H, D ** -0.5)
+
+        def timed(fn, iters=50):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fn()
+                side.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(iters):
+                        fn()
+                g.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                side.synchronize()
+                e0.record(side)
+                g.replay()
+                e1.record(side)
+                side.synchronize()
+            torch.cuda.current_stream().wait_stream(side)
+            return e0.elapsed_time(e1) * 1e3 / iters
+
+        f_us = timed(lambda: ops.self_attn_fwd(q, k, v, H, D ** -0.5))
+        b_us = timed(lambda: ops.self_attn_bwd(q, k, v, o, do, lse, H, D ** -0.5))
+        qh, kh, vh = (t.view(B, N, H, D).transpose(1, 2).detach().requires_grad_(True) for t in (q, k, v))
+        def eager(fn, iters=30):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / iters
+
+        with torch.no_grad():
+            sf = eager(lambda: torch.nn.functional.scaled_dot_product_attention(qh, kh, vh))
+        so = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh)
+        gout = torch.randn_like(so)
+        sb = eager(lambda: torch.autograd.grad(so, [qh, kh, vh], gout, retain_graph=True))
+        fl = 4.0 * B * H * N * N * D
+        print(f"{'':12s} {B:2d} {N:5d} {D:4d} {f_us:8.1f} {fl / f_us / 1e6:7.1f} {b_us:8.1f} {2.5 * fl / b_us / 1e6:7.1f}   ({sf:.1f}, {sb:.1f})",
+              flush=True)
+
+
+if __name__ == "__main__" and "--self-attn" in sys.argv:
+    self_attn_bench()
