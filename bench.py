@@ -114,43 +114,62 @@ def usable_cores():
     return n
 
 
-def capture_bytes(key):
-    """Algorithmic HBM bytes of one capture-kernel launch: forward = Q + O + K + V
-    (+ P when it is stored); backward = Q + dO + dQ + K + V (+ the broadcast dP map)."""
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
+
+
+def kernel_work(key):
+    """Algorithmic work of ONE call of a hand-written kernel: ("hbm", bytes) or ("mfma", flops).
+    capture fwd  = Q + O + K + V (+ P when stored);  capture bwd = Q + dO + dQ + K + V (+ the broadcast dP map)
+    self-attn    = 4 N^2 D flops per head forward, 2.5x that for the backward (5 matrix products, recompute not counted)
+    GroupNorm    = read x + write y (fwd), read x, dy + write dx (bwd)."""
     kind, B, H, N, Kt, D, flag, dt = key
     esz = 4 if dt == "torch.float32" else 2
+    if kind.startswith("group_norm"):
+        elems = B * N * D  # here H = groups, N = pixels, D = channels
+        return "hbm", esz * elems * (2 if kind == "group_norm_fwd" else 3)
     C = H * D
-    kv = 2 * B * Kt * C
     if kind == "attn_capture_fwd":
-        return esz * (2 * B * N * C + kv + (B * H * N * Kt if flag else 0))
-    return esz * (3 * B * N * C + kv + (N * Kt if flag else 0))
+        return "hbm", esz * (2 * B * N * C + 2 * B * Kt * C + (B * H * N * Kt if flag else 0))
+    if kind == "attn_capture_bwd":
+        return "hbm", esz * (3 * B * N * C + 2 * B * Kt * C + (N * Kt if flag else 0))
+    flops = 4.0 * B * H * N * N * D
+    return "mfma", flops * (1.0 if kind == "self_attn_fwd" else 2.5)
 
 
 def roofline_entry(census, ops):
-    """Dominant hand-written kernel: the capture kernel (forward or backward symbol) with the largest total time
-    over the timed region.  achieved = sum of algorithmic bytes over its launches / sum of their durations, each
-    shape's duration measured by a back-to-back replay between two HIP events on the launch stream; the same
-    weighted mean is what `rocprofv3 --kernel-trace --stats` reports as the symbol's AverageNs."""
+    """Dominant hand-written kernel = the ga_* entry point with the largest total time over the timed region.
+    achieved = sum of algorithmic work over its calls / sum of their durations; each shape's duration is measured by a
+    back-to-back hipGraph replay between two HIP events on the launch stream (the weighted mean equals what
+    `rocprofv3 --kernel-trace --stats` reports as the kernel's AverageNs: profiles/)."""
     per_kind = {}
     for key, count in census.items():
         us = ops.replay_launch_us(key)
-        d = per_kind.setdefault(key[0], {"time_us": 0.0, "bytes": 0, "launches": 0, "shapes": []})
+        bound, work = kernel_work(key)
+        d = per_kind.setdefault(key[0], {"bound": bound, "time_us": 0.0, "work": 0.0, "calls": 0, "shapes": []})
         d["time_us"] += us * count
-        d["bytes"] += capture_bytes(key) * count
-        d["launches"] += count
-        d["shapes"].append({"B": key[1], "N": key[3], "D": key[5], "flag": key[6], "launches": count,
-                            "launch_us": round(us, 2), "GBps": round(capture_bytes(key) / us / 1e3, 1)})
+        d["work"] += work * count
+        d["calls"] += count
+        rate = work / us / 1e3 if bound == "hbm" else work / us / 1e6  # GB/s or TFLOP/s
+        d["shapes"].append({"B": key[1], "H": key[2], "N": key[3], "D": key[5], "flag": key[6], "calls": count,
+                            "call_us": round(us, 2), "rate": round(rate, 1)})
     if not per_kind:
         return None
+
+    def summary(kind, d):
+        if d["bound"] == "hbm":
+            achieved, peak, unit = d["work"] / d["time_us"] / 1e3, HBM_PEAK_GBS, "GB/s"
+        else:
+            achieved, peak, unit = d["work"] / d["time_us"] / 1e6, MFMA_PEAK_TFLOPS, "TFLOP/s"
+        return {"bound": d["bound"], "kernel": "ga_" + kind, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
+                "frac": round(achieved / peak, 4), "avg_call_us": round(d["time_us"] / d["calls"], 2),
+                "calls": d["calls"], "total_ms": round(d["time_us"] / 1e3, 2)}
+
     kind, d = max(per_kind.items(), key=lambda kv: kv[1]["time_us"])
-    achieved = d["bytes"] / d["time_us"] / 1e3
-    return {"bound": "hbm", "kernel": kind, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "avg_launch_us": round(d["time_us"] / d["launches"], 2), "launches": d["launches"],
-            "algorithmic_bytes_per_launch": d["bytes"] // d["launches"],
-            "shapes": sorted(d["shapes"], key=lambda x: -x["launches"] * x["launch_us"])[:6],
-            "other_kernels": {k: {"avg_launch_us": round(v["time_us"] / v["launches"], 2),
-                                  "GBps": round(v["bytes"] / v["time_us"] / 1e3, 1)} for k, v in per_kind.items() if k != kind}}
+    out = summary(kind, d)
+    out["traffic"] = None
+    out["shapes"] = sorted(d["shapes"], key=lambda x: -x["calls"] * x["call_us"])[:6]
+    out["other_kernels"] = [summary(k, v) for k, v in sorted(per_kind.items(), key=lambda kv: -kv[1]["time_us"]) if k != kind]
+    return out
 
 
 def cpu_baseline(args, cfg, calls, rc):

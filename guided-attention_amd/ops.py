@@ -57,32 +57,71 @@ def add_census(launches):
             _CENSUS[key] = _CENSUS.get(key, 0) + n
 
 
-def replay_launch_us(key, iters=200):
-    """Average duration (us) of one launch of a recorded capture-kernel shape, inputs resident in HBM:
-    `iters` launches captured into one hipGraph (no host in the loop: a Python-driven loop is launch-bound at
-    ~10 us per call and hides the kernel time), replayed between two HIP events on the launch stream."""
+def replay_launch_us(key, iters=100):
+    """Average duration (us) of one launch of a recorded kernel shape, inputs resident in HBM: `iters` launches
+    captured into one hipGraph (no host in the loop: a Python-driven loop is launch-bound at ~10 us per call and
+    hides the kernel time), replayed between two HIP events on the launch stream.  For the self-attention and
+    GroupNorm backward the figure covers the launches of one backward call (3 resp. 2 kernels)."""
     kind, B, H, N, Kt, D, flag, dt = key
     dtype = {"torch.float16": torch.float16, "torch.bfloat16": torch.bfloat16, "torch.float32": torch.float32}[dt]
     dev = torch.device("cuda", torch.cuda.current_device())
-    q = torch.randn(B, N, H * D, device=dev, dtype=dtype)
-    k = torch.randn(B, Kt, H * D, device=dev, dtype=dtype)
-    v = torch.randn(B, Kt, H * D, device=dev, dtype=dtype)
-    out = torch.empty_like(q)
-    code, scale = dtype_code(q), D ** -0.5
     lib = load()
+    if kind.startswith("group_norm"):
+        groups, HW, C = H, N, D
+        side_len = int(round(HW ** 0.5))
+        x = torch.randn(B, C, side_len, HW // side_len, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
+        w, b_ = torch.ones(C, device=dev, dtype=dtype), torch.zeros(C, device=dev, dtype=dtype)
+        y, dy = torch.empty_like(x), torch.randn_like(x)
+        stats = torch.empty(B, groups, 2, device=dev, dtype=torch.float32)
+        ws = torch.empty(B * 64 * groups * 2, device=dev, dtype=torch.float32)
+        code = dtype_code(x)
+        check(lib.ga_group_norm_fwd(_ptr(x), _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(ws), B, HW, C, groups, 1e-5,
+                                    int(flag), code, stream_ptr()), "replay gn")
+        if kind == "group_norm_fwd":
+            def fn():
+                check(lib.ga_group_norm_fwd(_ptr(x), _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(ws), B, HW, C, groups,
+                                            1e-5, int(flag), code, stream_ptr()), "replay gn fwd")
+        else:
+            def fn():
+                check(lib.ga_group_norm_bwd(_ptr(x), _ptr(dy), _ptr(w), _ptr(b_), _ptr(stats), _ptr(y), _ptr(ws), B, HW, C,
+                                            groups, int(flag), code, stream_ptr()), "replay gn bwd")
+    else:
+        q = torch.randn(B, N, H * D, device=dev, dtype=dtype)
+        k = torch.randn(B, Kt, H * D, device=dev, dtype=dtype)
+        v = torch.randn(B, Kt, H * D, device=dev, dtype=dtype)
+        out = torch.empty_like(q)
+        code, scale = dtype_code(q), D ** -0.5
     if kind == "attn_capture_fwd":
         probs = torch.empty(B * H, N, Kt, device=dev, dtype=dtype) if flag else None
 
         def fn():
             check(lib.ga_attn_capture_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(probs), B, H, N, Kt, D, scale,
                                           code, stream_ptr()), "replay fwd")
-    else:
+    elif kind == "attn_capture_bwd":
         d_o = torch.randn_like(q)
         dp = torch.randn(N, Kt, device=dev, dtype=dtype) * 1e-3 if flag else None
 
         def fn():
             check(lib.ga_attn_capture_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(d_o), _ptr(dp), 0, Kt, _ptr(out), None, None,
                                           B, H, N, Kt, D, scale, code, stream_ptr()), "replay bwd")
+    elif kind in ("self_attn_fwd", "self_attn_bwd"):
+        lse = torch.empty(B * H, N, device=dev, dtype=torch.float32)
+        check(lib.ga_self_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, N, D, scale, code,
+                                   stream_ptr()), "replay sa")
+        if kind == "self_attn_fwd":
+            lse_arg = lse if flag else None
+
+            def fn():
+                check(lib.ga_self_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse_arg), B, H, N, D, scale, code,
+                                           stream_ptr()), "replay sa fwd")
+        else:
+            d_o, delta = torch.randn_like(q), torch.empty_like(lse)
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+
+            def fn():
+                check(lib.ga_self_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(d_o), _ptr(lse), _ptr(delta),
+                                           _ptr(dq), _ptr(dk), _ptr(dv), B, H, N, D, scale, code, stream_ptr()),
+                      "replay sa bwd")
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -339,6 +378,7 @@ class GroupNormAct(torch.autograd.Function):
         y = torch.empty_like(x, memory_format=torch.channels_last)
         stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
         ws = torch.empty((B * 64 * groups * 2,), dtype=torch.float32, device=x.device)
+        _count(("group_norm_fwd", B, groups, H * W, 0, C, bool(act), str(x.dtype)))
         check(load().ga_group_norm_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(stats), _ptr(ws), B, H * W, C,
                                        groups, float(eps), int(bool(act)), dtype_code(x), stream_ptr()),
               "ga_group_norm_fwd")
@@ -356,6 +396,7 @@ class GroupNormAct(torch.autograd.Function):
         dy = _nhwc(dy)
         dx = torch.empty_like(x, memory_format=torch.channels_last)
         ws = torch.empty((B * 64 * groups * 2,), dtype=torch.float32, device=x.device)
+        _count(("group_norm_bwd", B, groups, H * W, 0, C, bool(act), str(x.dtype)))
         check(load().ga_group_norm_bwd(_ptr(x), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(stats), _ptr(dx), _ptr(ws), B,
                                        H * W, C, groups, int(act), dtype_code(x), stream_ptr()), "ga_group_norm_bwd")
         return dx, None, None, None, None, None
@@ -373,6 +414,7 @@ def self_attn_fwd(q, k, v, heads, scale, want_lse=True):
     B, N, C = q.shape
     o = torch.empty_like(q)
     lse = torch.empty((B * heads, N), dtype=torch.float32, device=q.device) if want_lse else None
+    _count(("self_attn_fwd", B, heads, N, N, C // heads, bool(want_lse), str(q.dtype)))
     check(load().ga_self_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), B, heads, N, C // heads, float(scale),
                                   dtype_code(q), stream_ptr()), "ga_self_attn_fwd")
     return o, lse
@@ -384,6 +426,7 @@ def self_attn_bwd(q, k, v, o, d_o, lse, heads, scale):
     d_o = d_o.contiguous()
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = torch.empty_like(lse)
+    _count(("self_attn_bwd", B, heads, N, N, C // heads, True, str(q.dtype)))
     check(load().ga_self_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(delta), _ptr(dq),
                                   _ptr(dk), _ptr(dv), B, heads, N, C // heads, float(scale), dtype_code(q),
                                   stream_ptr()), "ga_self_attn_bwd")
