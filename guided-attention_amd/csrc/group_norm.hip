@@ -18,9 +18,9 @@ using namespace ga;
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxNB = 64;
+constexpr int kMaxNB = 256;
 constexpr int kMaxNPT = 5;  // channel pairs per thread: C <= 2560
-constexpr int kU = 8;       // pixels per lane whose loads are issued together
+constexpr int kU = 8;       // pixels per lane whose loads are issued together (16 in the apply kernels)
 
 // W consecutive channels handled by one lane per pixel: 2 (a 4-byte access for 16-bit types) when the group size
 // is even, which is every SD layer; 1 for odd group sizes (reduced-width test models).
@@ -89,52 +89,59 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict_
   fold_to_groups<NPT>(s0, s1, CP, cpg, G, lds, partial + ((size_t)b * gridDim.x + nb) * G * 2);
 }
 
-// per-group (v0, v1) = fixed-order sum of the NB partials, into g0/g1 (LDS, >= 64 floats each).  All 256 lanes
-// load (lane -> group = lane % 32-ish slice of the partial list) so the <= 64 x G partials cost one round trip;
-// the slices are then added in a fixed order (deterministic).
-__device__ __forceinline__ void gather_partials(const float* __restrict__ partial, int b, int NB, int G, float* g0,
-                                                float* g1) {
-  __shared__ float slice[2][8][64];
-  const int g = threadIdx.x % 64, sl = threadIdx.x / 64;  // 4 slices of the partial list x 64 groups
-  float a = 0.f, c = 0.f;
-  if (g < G) {
-    for (int nb = sl; nb < NB; nb += 4) {
-      a += partial[((size_t)b * NB + nb) * G * 2 + 2 * g];
-      c += partial[((size_t)b * NB + nb) * G * 2 + 2 * g + 1];
+// One workgroup per image folds the NB per-block partials of every group in a fixed order (4 slices x 64 groups,
+// loads unrolled 8-deep) and turns them into what the apply kernels need:
+//   FWD : out[b][g] = (mean, rstd)            BWD : out[b][g] = (mean of dyhat, mean of dyhat*yhat)
+template <bool FWD>
+__global__ __launch_bounds__(kThreads) void gn_finalize_kernel(const float* __restrict__ partial, int NB, int G,
+                                                               float inv_n, float eps, float* __restrict__ out) {
+  // 256 lanes = 4 slices x 64 groups; a lane's <= 64 partials are fetched as float2 in two batches of 32 loads
+  __shared__ float slice[2][4][64];
+  const int b = blockIdx.x, g = threadIdx.x % 64, sl = threadIdx.x / 64;
+  float sa = 0.f, sc = 0.f;
+  const float2* pp = reinterpret_cast<const float2*>(partial) + (size_t)b * NB * G + g;
+  for (int nb0 = sl; nb0 < NB; nb0 += 128) {
+    float2 v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int nb = nb0 + 4 * i;
+      v[i] = float2{0.f, 0.f};
+      if (g < G && nb < NB) v[i] = pp[(size_t)nb * G];
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      sa += v[i].x;
+      sc += v[i].y;
     }
   }
-  slice[0][sl][g] = a;
-  slice[1][sl][g] = c;
+  slice[0][sl][g] = sa;
+  slice[1][sl][g] = sc;
   __syncthreads();
-  if (threadIdx.x < 64) {
-    g0[g] = (slice[0][0][g] + slice[0][1][g]) + (slice[0][2][g] + slice[0][3][g]);
-    g1[g] = (slice[1][0][g] + slice[1][1][g]) + (slice[1][2][g] + slice[1][3][g]);
+  if (threadIdx.x < G) {
+    const float v0 = (slice[0][0][g] + slice[0][1][g]) + (slice[0][2][g] + slice[0][3][g]);
+    const float v1 = (slice[1][0][g] + slice[1][1][g]) + (slice[1][2][g] + slice[1][3][g]);
+    float o0, o1;
+    if (FWD) {
+      const double mean = (double)v0 * inv_n;
+      const double var = fmax((double)v1 * inv_n - mean * mean, 0.0);
+      o0 = (float)mean;
+      o1 = rsqrtf((float)var + eps);
+    } else {
+      o0 = v0 * inv_n;
+      o1 = v1 * inv_n;
+    }
+    out[((size_t)b * G + g) * 2] = o0;
+    out[((size_t)b * G + g) * 2 + 1] = o1;
   }
-  __syncthreads();
 }
 
 template <typename T, bool ACT, int NPT, int W>
-__global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ partial,
-                                                            int NB, const T* __restrict__ gamma,
+__global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
                                                             const T* __restrict__ beta, T* __restrict__ y,
-                                                            float* __restrict__ stats, int HW, int C, int G, int PB,
-                                                            float eps) {
-  __shared__ float mu[64], rs[64];
+                                                            const float* __restrict__ stats, int HW, int C, int G,
+                                                            int PB) {
   const int b = blockIdx.y, CP = C / W, cpg = (C / G) / W;
-  gather_partials(partial, b, NB, G, mu, rs);
-  const float inv_n = 1.0f / ((float)HW * (float)(C / G));
-  for (int g = threadIdx.x; g < G; g += kThreads) {
-    const double mean = (double)mu[g] * inv_n;
-    const double var = fmax((double)rs[g] * inv_n - mean * mean, 0.0);
-    const float r = rsqrtf((float)var + eps);
-    mu[g] = (float)mean;
-    rs[g] = r;
-    if (blockIdx.x == 0) {
-      stats[((size_t)b * G + g) * 2] = (float)mean;
-      stats[((size_t)b * G + g) * 2 + 1] = r;
-    }
-  }
-  __syncthreads();
+  const float* mu_rs = stats + (size_t)b * G * 2;
   float sc[NPT][W], sh[NPT][W];
 #pragma unroll
   for (int k = 0; k < NPT; ++k) {
@@ -145,8 +152,8 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict_
       const Item<T, W> be = reinterpret_cast<const Item<T, W>*>(beta)[cp];
 #pragma unroll
       for (int j = 0; j < W; ++j) {
-        sc[k][j] = Traits<T>::to_f32(ga_.v[j]) * rs[g];
-        sh[k][j] = Traits<T>::to_f32(be.v[j]) - mu[g] * sc[k][j];
+        sc[k][j] = Traits<T>::to_f32(ga_.v[j]) * mu_rs[2 * g + 1];
+        sh[k][j] = Traits<T>::to_f32(be.v[j]) - mu_rs[2 * g] * sc[k][j];
       }
     }
   }
@@ -253,12 +260,9 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
                                                                 const T* __restrict__ gamma,
                                                                 const T* __restrict__ beta,
                                                                 const float* __restrict__ stats,
-                                                                const float* __restrict__ partial, int NB,
-                                                                T* __restrict__ dx, int HW, int C, int G, int PB) {
-  __shared__ float m1[64], m2[64];
+                                                                const float* __restrict__ fin, T* __restrict__ dx,
+                                                                int HW, int C, int G, int PB) {
   const int b = blockIdx.y, CP = C / W, cpg = (C / G) / W;
-  gather_partials(partial, b, NB, G, m1, m2);
-  const float inv_n = 1.0f / ((float)HW * (float)(C / G));
   float mu[NPT], rs[NPT], a1[NPT], a2[NPT], g0[NPT][W], b0[NPT][W];
 #pragma unroll
   for (int k = 0; k < NPT; ++k) {
@@ -267,8 +271,8 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
       const int g = cp / cpg;
       mu[k] = stats[((size_t)b * G + g) * 2];
       rs[k] = stats[((size_t)b * G + g) * 2 + 1];
-      a1[k] = m1[g] * inv_n;
-      a2[k] = m2[g] * inv_n;
+      a1[k] = fin[((size_t)b * G + g) * 2];
+      a2[k] = fin[((size_t)b * G + g) * 2 + 1];
       const Item<T, W> ga_ = reinterpret_cast<const Item<T, W>*>(gamma)[cp];
       const Item<T, W> be = reinterpret_cast<const Item<T, W>*>(beta)[cp];
 #pragma unroll
@@ -317,14 +321,14 @@ struct Geom {
 
 int geometry(int B, int HW, int C, int G, Geom& g) {
   if (B < 1 || HW < 1 || C < 1 || G < 1 || G > 64 || C % G != 0) return GA_ERR_SHAPE;
-  g.W = ((C / G) & 1) ? 1 : 2;
+  const int cg = C / G;
+  g.W = (cg % 4 == 0) ? 4 : ((cg & 1) ? 1 : 2);  // 8-byte accesses when a group holds a multiple of 4 channels
   const int CP = C / g.W;
   g.NPT = (CP + kThreads - 1) / kThreads;
   if (g.NPT > kMaxNPT) return GA_ERR_SHAPE;
-  g.NB = HW >= kMaxNB * 8 ? kMaxNB : (HW + 7) / 8;          // stats: <= 64 pixel blocks per image
-  g.PBs = (HW + g.NB - 1) / g.NB;
+  g.PBs = (HW + kMaxNB - 1) / kMaxNB < 8 ? 8 : (HW + kMaxNB - 1) / kMaxNB;  // stats: <= 256 blocks of >= 8 pixels
   g.NB = (HW + g.PBs - 1) / g.PBs;
-  g.PBa = HW >= 1024 ? 8 : 4;                                // apply: small blocks -> enough workgroups
+  g.PBa = HW >= 4096 ? 16 : (HW >= 1024 ? 8 : 4);                            // apply: small blocks
   g.NBa = (HW + g.PBa - 1) / g.PBa;
   g.lds = sizeof(float) * 2 * CP;
   return GA_OK;
@@ -333,20 +337,25 @@ int geometry(int B, int HW, int C, int G, Geom& g) {
 template <typename T, bool ACT, int NPT, int W>
 int launch_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float* stats, float* ws, int B, int HW,
                  int C, int G, float eps, const Geom& g, hipStream_t s) {
+  const float inv_n = 1.0f / ((float)HW * (float)(C / G));
   hipLaunchKernelGGL((gn_stats_kernel<T, NPT, W>), dim3(g.NB, B), dim3(kThreads), g.lds, s, (const T*)x, ws, HW, C, G,
                      g.PBs);
-  hipLaunchKernelGGL((gn_apply_kernel<T, ACT, NPT, W>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x, ws, g.NB,
-                     (const T*)gamma, (const T*)beta, (T*)y, stats, HW, C, G, g.PBa, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(B), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, eps, stats);
+  hipLaunchKernelGGL((gn_apply_kernel<T, ACT, NPT, W>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
+                     (const T*)gamma, (const T*)beta, (T*)y, stats, HW, C, G, g.PBa);
   return check_launch();
 }
 
 template <typename T, bool ACT, int NPT, int W>
 int launch_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta, const float* stats, void* dx,
                  float* ws, int B, int HW, int C, int G, const Geom& g, hipStream_t s) {
+  const float inv_n = 1.0f / ((float)HW * (float)(C / G));
+  float* fin = ws + (size_t)B * kMaxNB * G * 2;  // [B][G][2] behind the partials
   hipLaunchKernelGGL((gn_bwd_stats_kernel<T, ACT, NPT, W>), dim3(g.NB, B), dim3(kThreads), g.lds, s, (const T*)x,
                      (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, HW, C, G, g.PBs);
+  hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(B), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, 0.0f, fin);
   hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT, NPT, W>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
-                     (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, g.NB, (T*)dx, HW, C, G, g.PBa);
+                     (const T*)dy, (const T*)gamma, (const T*)beta, stats, fin, (T*)dx, HW, C, G, g.PBa);
   return check_launch();
 }
 
@@ -356,6 +365,13 @@ int launch_bwd_t(const void* x, const void* dy, const void* gamma, const void* b
       case 1: return FN<T, ACT, 1, 1>(__VA_ARGS__);                  \
       case 2: return FN<T, ACT, 2, 1>(__VA_ARGS__);                  \
       default: return FN<T, ACT, 5, 1>(__VA_ARGS__);                 \
+    }                                                                \
+  }                                                                  \
+  if (g.W == 4) {                                                    \
+    switch (g.NPT) {                                                 \
+      case 1: return FN<T, ACT, 1, 4>(__VA_ARGS__);                  \
+      case 2: return FN<T, ACT, 2, 4>(__VA_ARGS__);                  \
+      default: return FN<T, ACT, 3, 4>(__VA_ARGS__);                 \
     }                                                                \
   }                                                                  \
   switch (g.NPT) {                                                   \

@@ -73,7 +73,7 @@ def replay_launch_us(key, iters=100):
         w, b_ = torch.ones(C, device=dev, dtype=dtype), torch.zeros(C, device=dev, dtype=dtype)
         y, dy = torch.empty_like(x), torch.randn_like(x)
         stats = torch.empty(B, groups, 2, device=dev, dtype=torch.float32)
-        ws = torch.empty(B * 64 * groups * 2, device=dev, dtype=torch.float32)
+        ws = torch.empty(B * 257 * groups * 2, device=dev, dtype=torch.float32)
         code = dtype_code(x)
         check(lib.ga_group_norm_fwd(_ptr(x), _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(ws), B, HW, C, groups, 1e-5,
                                     int(flag), code, stream_ptr()), "replay gn")
@@ -377,7 +377,7 @@ class GroupNormAct(torch.autograd.Function):
         B, C, H, W = x.shape
         y = torch.empty_like(x, memory_format=torch.channels_last)
         stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
-        ws = torch.empty((B * 64 * groups * 2,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((B * 257 * groups * 2,), dtype=torch.float32, device=x.device)
         _count(("group_norm_fwd", B, groups, H * W, 0, C, bool(act), str(x.dtype)))
         check(load().ga_group_norm_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(stats), _ptr(ws), B, H * W, C,
                                        groups, float(eps), int(bool(act)), dtype_code(x), stream_ptr()),
@@ -395,7 +395,7 @@ class GroupNormAct(torch.autograd.Function):
         B, C, H, W = x.shape
         dy = _nhwc(dy)
         dx = torch.empty_like(x, memory_format=torch.channels_last)
-        ws = torch.empty((B * 64 * groups * 2,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((B * 257 * groups * 2,), dtype=torch.float32, device=x.device)
         _count(("group_norm_bwd", B, groups, H * W, 0, C, bool(act), str(x.dtype)))
         check(load().ga_group_norm_bwd(_ptr(x), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(stats), _ptr(dx), _ptr(ws), B,
                                        H * W, C, groups, int(act), dtype_code(x), stream_ptr()), "ga_group_norm_bwd")

@@ -165,13 +165,13 @@ int ga_self_attn_bwd(const void* Q, const void* K, const void* V, const void* O,
 
 /* ---------------------------------------------------------------------------------------------
  * UNet host helper: GroupNorm (+ fused SiLU) on channels-last activations, forward and backward to the
- * input.  Stands in for the GroupNorm -> SiLU pairs of the diffusers UNet blocks the reference runs in
+ * input (3 launches each: per-block partial sums, per-image finalize, apply).  Stands in for the GroupNorm -> SiLU pairs of the diffusers UNet blocks the reference runs in
  * pipeline_guided_attention.py:583-743 (diffusers 0.12.1 ResnetBlock2D / Transformer2DModel).
  *   x, y, dy, dx [B][HW][C] T (NHWC); gamma, beta [C] T; stats [B][G][2] f32 (mean, rstd), written by the
- *   forward and read by the backward; workspace [B][64][G][2] f32 scratch.  C/G must be even, G <= 64,
+ *   forward and read by the backward; workspace GA_GN_WORKSPACE_FLOATS(B, G) f32 scratch.  C/G must be even, G <= 64,
  *   C <= 2560.  gamma/beta gradients are not produced (weights are frozen on this path).
  */
-#define GA_GN_WORKSPACE_FLOATS(B, G) ((B) * 64 * (G) * 2)
+#define GA_GN_WORKSPACE_FLOATS(B, G) ((B) * 257 * (G) * 2)
 int ga_group_norm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* stats, float* workspace,
                       int B, int HW, int C, int G, float eps, int act_silu, int dtype, ga_stream_t stream);
 int ga_group_norm_bwd(const void* x, const void* dy, const void* gamma, const void* beta, const float* stats,

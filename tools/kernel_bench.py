@@ -34,7 +34,7 @@ def main():
                 print(f"{kind:18s} {B:2d} {N:5d} {D:4d} {str(flag):>5s} {us:8.2f} {gbs:8.1f} {gbs / 8000:6.3f}", flush=True)
 
 
-if __name__ == "__main__" and "--self-attn" not in sys.argv:
+if __name__ == "__main__" and "--self-attn" not in sys.argv and "--group-norm" not in sys.argv:
     main()
 
 
@@ -94,3 +94,17 @@ def self_attn_bench():
 
 if __name__ == "__main__" and "--self-attn" in sys.argv:
     self_attn_bench()
+
+
+def group_norm_bench():
+    print(f"\n{'group_norm':12s} {'B':>2s} {'C':>5s} {'HW':>5s} {'fwd us':>8s} {'GB/s':>7s} {'bwd us':>8s} {'GB/s':>7s}")
+    for B, C, HW in ((1, 320, 4096), (2, 320, 4096), (1, 640, 4096), (1, 960, 4096), (1, 640, 1024), (1, 1280, 1024),
+                     (1, 1920, 1024), (1, 1280, 256), (1, 2560, 256), (1, 1280, 64), (1, 2560, 64)):
+        f = ops.replay_launch_us(("group_norm_fwd", B, 32, HW, 0, C, True, "torch.float16"))
+        b = ops.replay_launch_us(("group_norm_bwd", B, 32, HW, 0, C, True, "torch.float16"))
+        nbytes = 2 * B * C * HW
+        print(f"{'':12s} {B:2d} {C:5d} {HW:5d} {f:8.2f} {2 * nbytes / f / 1e3:7.1f} {b:8.2f} {3 * nbytes / b / 1e3:7.1f}", flush=True)
+
+
+if __name__ == "__main__" and "--group-norm" in sys.argv:
+    group_norm_bench()
