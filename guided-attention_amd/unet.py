@@ -189,9 +189,11 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
     def forward(self, x, temb_act):
-        """temb_act = SiLU(time embedding), computed once per UNet forward."""
+        """temb_act = SiLU(time embedding), computed once per UNet forward; or the dict the UNet prepared with this
+        block's time_emb_proj(temb_act) already evaluated (all blocks in one GEMM)."""
         h = self.conv1(self.norm1(x))  # norm1 / norm2 carry the SiLU
-        h = h + self.time_emb_proj(temb_act)[:, :, None, None]
+        tproj = temb_act[id(self)] if isinstance(temb_act, dict) else self.time_emb_proj(temb_act)
+        h = h + tproj[:, :, None, None]
         h = self.conv2(self.norm2(h))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
@@ -365,6 +367,24 @@ class UNet2DConditionModel(nn.Module):
             for mod in mods.values():
                 mod.set_processor(processor)
 
+    def _time_projections(self, temb_act):
+        """Every ResnetBlock2D adds time_emb_proj(SiLU(temb)): 22 GEMMs with one row of input each.  They are
+        evaluated as ONE GEMM against the row-concatenated weights (built once; rebuilt if a weight changes) and
+        handed to the blocks as views."""
+        blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        key = tuple((b.time_emb_proj.weight.data_ptr(), b.time_emb_proj.weight._version, b.time_emb_proj.bias._version)
+                    for b in blocks)
+        cache = self.__dict__.get("_tproj_cache")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                w = torch.cat([b.time_emb_proj.weight for b in blocks], dim=0)
+                bias = torch.cat([b.time_emb_proj.bias for b in blocks], dim=0)
+            cache = (key, w, bias, [b.time_emb_proj.out_features for b in blocks])
+            self.__dict__["_tproj_cache"] = cache
+        _, w, bias, sizes = cache
+        parts = F.linear(temb_act, w, bias).split(sizes, dim=1)
+        return {id(b): p for b, p in zip(blocks, parts)}
+
     def set_norm_impl(self, impl):
         """Install (or with None remove) the GroupNorm(+SiLU) implementation of every norm layer."""
         for m in self.modules():
@@ -395,7 +415,7 @@ class UNet2DConditionModel(nn.Module):
             timestep = timestep[None].to(sample.device)
         timestep = timestep.expand(sample.shape[0])
         t_emb = timestep_embedding(timestep, cfg.block_out_channels[0]).to(self.dtype)
-        temb_act = F.silu(self.time_embedding(t_emb))
+        temb_act = self._time_projections(F.silu(self.time_embedding(t_emb)))
 
         x = self.conv_in(sample)
         skips = [x]

@@ -161,3 +161,25 @@ def test_cpu_pipeline_is_refused():
     with pytest.raises(GaError):
         pipe(prompt=None, prompt_embeds=torch.zeros(1, 77, 48), negative_prompt_embeds=torch.zeros(1, 77, 48),
              attention_store=AttentionStore(), latents=torch.zeros(1, 4, 32, 32), output_type="latent")
+
+
+def test_graph_runner_follows_a_new_prompt_embedding():
+    """The captured graphs read the cached text K/V projections: a new prompt embedding on a cached runner must
+    refresh them (and an in-place edit of the embedding must invalidate the eager cache)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    meta = dict(G9[2], steps=3)
+    unet, embeds, lat0, noise, thr = g9_setup(meta)
+    pipe = build_product(unet, torch.float32)
+    other = torch.from_numpy(hashrand.normalish((2, 77, 48), 4242))
+    first, _ = run_product(pipe, meta, embeds, lat0, noise, thr, use_graphs=True)
+    second, _ = run_product(pipe, meta, other, lat0, noise, thr, use_graphs=True)   # same runner, new prompt
+    pipe.use_graphs = False
+    eager_other, _ = run_product(pipe, meta, other, lat0, noise, thr)
+    eager_first, _ = run_product(pipe, meta, embeds, lat0, noise, thr)
+
+    def rel(a, b):
+        return (a.latents - b.latents).abs().max().item() / b.latents.abs().max().item()
+
+    assert rel(second, eager_other) < 2e-4 and rel(first, eager_first) < 2e-4
+    assert rel(second, first) > 1e-2  # the prompt really changed the result

@@ -30,6 +30,8 @@ def replay_ms(graph, n=10):
 
 
 def main():
+    if "benchmark" in sys.argv:
+        torch.backends.cudnn.benchmark = True  # MIOpen: exhaustive find instead of the default heuristic pick
     with torch.device("cuda"):
         unet = UNet2DConditionModel(UNetConfig.sd15()).half()
     pipe = GuidedAttention(unet, None, None, SyntheticTextEncoder(768), WordTokenizer()).to("cuda", torch.float16)
