@@ -178,7 +178,7 @@ template <typename T, int NK, int QB, int NBUF>
 __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                                  const T* __restrict__ V, T* __restrict__ O,
                                                                  float* __restrict__ LSE, int H, int N, int D, int nqt,
-                                                                 float scale) {
+                                                                 int ldq, float scale) {
   using Tr = Traits<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // one buffer = [K row-major | V transposed]; buffers are addressed as base + cur * kBuf so that the compiler
@@ -189,10 +189,11 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
 
   const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const size_t rs = (size_t)H * D;  // row stride of the [N][H][D] slice
-  const T* Qb = Q + ((size_t)b * N * H + head) * D;
-  const T* Kb = K + ((size_t)b * N * H + head) * D;
-  const T* Vb = V + ((size_t)b * N * H + head) * D;
+  const size_t rs = (size_t)ldq;     // row stride of Q / K / V (H*D, or 3*H*D when they are slices of a fused QKV)
+  const size_t rso = (size_t)H * D;  // row stride of O
+  const T* Qb = Q + (size_t)b * N * rs + (size_t)head * D;
+  const T* Kb = K + (size_t)b * N * rs + (size_t)head * D;
+  const T* Vb = V + (size_t)b * N * rs + (size_t)head * D;
   const int q0 = qt * (4 * QB * 16) + wave * (QB * 16);
   const float c1 = scale * 1.4426950408889634f;
 
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
     const int q = q0 + qb * 16 + c;
     if (LSE != nullptr && g == 0 && q < N) LSE[((size_t)b * H + head) * N + q] = m[qb] * c1 + log2f(l[qb]);
   }
-  store_colsT<T, NK, QB>(O + ((size_t)b * N * H + head) * D, rs, q0, N, D, c, g, o, inv);
+  store_colsT<T, NK, QB>(O + ((size_t)b * N * H + head) * D, rso, q0, N, D, c, g, o, inv);
 }
 
 // =================================================================================================== backward prep
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
                                                                     const float* __restrict__ LSE,
                                                                     const float* __restrict__ delta,
                                                                     T* __restrict__ dQ, int H, int N, int D, int nqt,
-                                                                    float scale) {
+                                                                    int ldq, float scale) {
   using Tr = Traits<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // one buffer = [K row-major | V row-major | K transposed]
@@ -323,14 +324,15 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
   constexpr int kBuf = NBUF == 2 ? 2 * row_img<T, NK>() + tr_img<T, NK>() : 0;
   const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const size_t rs = (size_t)H * D;
-  const size_t off = ((size_t)b * N * H + head) * D;
+  const size_t rs = (size_t)ldq, rso = (size_t)H * D;
+  const size_t off = (size_t)b * N * rs + (size_t)head * D;    // into Q / K / V / dQ
+  const size_t offo = ((size_t)b * N * H + head) * D;          // into dO
   const int q0 = qt * (4 * QB * 16) + wave * (QB * 16);
   const float c1 = scale * 1.4426950408889634f;
 
   typename Tr::frag qf[QB][NK], dof[QB][NK];
   load_col_frags<T, NK, QB>(Q + off, rs, q0, N, D, c, g, qf);
-  load_col_frags<T, NK, QB>(dO + off, rs, q0, N, D, c, g, dof);
+  load_col_frags<T, NK, QB>(dO + offo, rso, q0, N, D, c, g, dof);
   float lse[QB], dl[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
                                                                       const float* __restrict__ LSE,
                                                                       const float* __restrict__ delta,
                                                                       T* __restrict__ dK, T* __restrict__ dV, int H,
-                                                                      int N, int D, int nkt, float scale) {
+                                                                      int N, int D, int nkt, int ldq, float scale) {
   using Tr = Traits<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // one buffer = [Q row-major | Q transposed | dO row-major | dO transposed]; then the per-query LSE / delta rows
@@ -434,8 +436,9 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
   constexpr int kSbuf = 2 * kTile;
   const int head = blockIdx.x % H, rest = blockIdx.x / H, ktile = rest % nkt, b = rest / nkt;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const size_t rs = (size_t)H * D;
-  const size_t off = ((size_t)b * N * H + head) * D;
+  const size_t rs = (size_t)ldq, rso = (size_t)H * D;
+  const size_t off = (size_t)b * N * rs + (size_t)head * D;    // into Q / K / V / dK / dV
+  const size_t offo = ((size_t)b * N * H + head) * D;          // into dO
   const size_t soff = ((size_t)b * H + head) * N;
   const int k0 = ktile * (4 * KB * 16) + wave * (KB * 16);
   const float c1 = scale * 1.4426950408889634f;
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
     }
   };
   sq.load(Q + off, 0, N, D, rs);
-  sd.load(dO + off, 0, N, D, rs);
+  sd.load(dO + offo, 0, N, D, rso);
   load_stats(0);
   sq.store(lds, lds + kQt);
   sd.store(lds + kDr, lds + kDt);
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
     const int cur = qt & 1;
     if (qt + 1 < ntiles) {
       sq.load(Q + off, (qt + 1) * kTile, N, D, rs);
-      sd.load(dO + off, (qt + 1) * kTile, N, D, rs);
+      sd.load(dO + offo, (qt + 1) * kTile, N, D, rso);
       load_stats((qt + 1) * kTile);
     }
     // S[q rows][key cols] and dP[q rows][key cols]
@@ -570,7 +573,7 @@ bool wide_columns(int B, int H, int N) {
 
 template <typename T, int NK, int QB>
 int launch_fwd_cb(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D,
-                  float scale, hipStream_t s) {
+                  int ldq, float scale, hipStream_t s) {
   const size_t lds = fwd_lds<T, NK>();
   if (lds > kLdsLimit) return GA_ERR_SHAPE;
   const int nqt = (N + 64 * QB - 1) / (64 * QB);
@@ -578,22 +581,23 @@ int launch_fwd_cb(const void* Q, const void* K, const void* V, void* O, float* L
   int rc = set_dyn_lds(k, lds);
   if (rc != GA_OK) return rc;
   hipLaunchKernelGGL(k, dim3((unsigned)(B * H * nqt)), dim3(kThreads), lds, s, (const T*)Q, (const T*)K, (const T*)V,
-                     (T*)O, LSE, H, N, D, nqt, scale);
+                     (T*)O, LSE, H, N, D, nqt, ldq, scale);
   return check_launch();
 }
 
 template <typename T, int NK>
-int launch_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D, float scale,
-               hipStream_t s) {
+int launch_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D, int ldq,
+               float scale, hipStream_t s) {
   if constexpr (NK <= 5) {
-    if (wide_columns<NK>(B, H, N)) return launch_fwd_cb<T, NK, 2>(Q, K, V, O, LSE, B, H, N, D, scale, s);
+    if (wide_columns<NK>(B, H, N)) return launch_fwd_cb<T, NK, 2>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
   }
-  return launch_fwd_cb<T, NK, 1>(Q, K, V, O, LSE, B, H, N, D, scale, s);
+  return launch_fwd_cb<T, NK, 1>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
 }
 
 template <typename T, int NK, int CB>
 int launch_bwd_cb(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
-                  float* delta, void* dQ, void* dK, void* dV, int B, int H, int N, int D, float scale, hipStream_t s) {
+                  float* delta, void* dQ, void* dK, void* dV, int B, int H, int N, int D, int ldq, float scale,
+                  hipStream_t s) {
   const size_t l1 = dq_lds<T, NK>(), l2 = dkdv_lds<T, NK>();
   if (l1 > kLdsLimit || l2 > kLdsLimit) return GA_ERR_SHAPE;
   const long long rows = (long long)B * N * H;
@@ -607,21 +611,22 @@ int launch_bwd_cb(const void* Q, const void* K, const void* V, const void* O, co
   rc = set_dyn_lds(kk, l2);
   if (rc != GA_OK) return rc;
   hipLaunchKernelGGL(kq, dim3((unsigned)(B * H * nt)), dim3(kThreads), l1, s, (const T*)Q, (const T*)K, (const T*)V,
-                     (const T*)dO, LSE, (const float*)delta, (T*)dQ, H, N, D, nt, scale);
+                     (const T*)dO, LSE, (const float*)delta, (T*)dQ, H, N, D, nt, ldq, scale);
   const int nk = (N + 63) / 64;
   hipLaunchKernelGGL(kk, dim3((unsigned)(B * H * nk)), dim3(kThreads), l2, s, (const T*)Q, (const T*)K, (const T*)V,
-                     (const T*)dO, LSE, (const float*)delta, (T*)dK, (T*)dV, H, N, D, nk, scale);
+                     (const T*)dO, LSE, (const float*)delta, (T*)dK, (T*)dV, H, N, D, nk, ldq, scale);
   return check_launch();
 }
 
 template <typename T, int NK>
 int launch_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
-               float* delta, void* dQ, void* dK, void* dV, int B, int H, int N, int D, float scale, hipStream_t s) {
+               float* delta, void* dQ, void* dK, void* dV, int B, int H, int N, int D, int ldq, float scale,
+               hipStream_t s) {
   if constexpr (NK <= 5) {
     if (wide_columns<NK>(B, H, N))
-      return launch_bwd_cb<T, NK, 2>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, scale, s);
+      return launch_bwd_cb<T, NK, 2>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);
   }
-  return launch_bwd_cb<T, NK, 1>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, scale, s);
+  return launch_bwd_cb<T, NK, 1>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);
 }
 
 #define GA_SA_NK(CALL)                                  \
@@ -646,16 +651,16 @@ int check_args(int B, int H, int N, int D) {
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename T>
-int fwd_t(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D, float scale,
-          hipStream_t s) {
-#define GA_CALL(NKV) launch_fwd<T, NKV>(Q, K, V, O, LSE, B, H, N, D, scale, s)
+int fwd_t(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D, int ldq,
+          float scale, hipStream_t s) {
+#define GA_CALL(NKV) launch_fwd<T, NKV>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s)
   GA_SA_NK(GA_CALL);
 #undef GA_CALL
 }
 template <typename T>
 int bwd_t(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* delta,
-          void* dQ, void* dK, void* dV, int B, int H, int N, int D, float scale, hipStream_t s) {
-#define GA_CALL(NKV) launch_bwd<T, NKV>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, scale, s)
+          void* dQ, void* dK, void* dV, int B, int H, int N, int D, int ldq, float scale, hipStream_t s) {
+#define GA_CALL(NKV) launch_bwd<T, NKV>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s)
   GA_SA_NK(GA_CALL);
 #undef GA_CALL
 }
@@ -663,33 +668,37 @@ int bwd_t(const void* Q, const void* K, const void* V, const void* O, const void
 }  // namespace
 
 extern "C" int ga_self_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N,
-                                int D, float scale, int dtype, ga_stream_t stream) {
+                                int D, int ld_qkv, float scale, int dtype, ga_stream_t stream) {
   if (!Q || !K || !V || !O) return GA_ERR_NULL;
   int rc = check_args(B, H, N, D);
   if (rc != GA_OK) return rc;
+  const int ldq = ld_qkv > 0 ? ld_qkv : H * D;
+  if (ldq < H * D || ldq % 8 != 0) return GA_ERR_SHAPE;
   if (!al16(Q) || !al16(K) || !al16(V) || !al16(O)) return GA_ERR_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case GA_F16: return fwd_t<_Float16>(Q, K, V, O, LSE, B, H, N, D, scale, s);
-    case GA_BF16: return fwd_t<bf16_t>(Q, K, V, O, LSE, B, H, N, D, scale, s);
-    case GA_F32: return fwd_t<float>(Q, K, V, O, LSE, B, H, N, D, scale, s);
+    case GA_F16: return fwd_t<_Float16>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
+    case GA_BF16: return fwd_t<bf16_t>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
+    case GA_F32: return fwd_t<float>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
     default: return GA_ERR_DTYPE;
   }
 }
 
 extern "C" int ga_self_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
                                 const float* LSE, float* delta, void* dQ, void* dK, void* dV, int B, int H, int N,
-                                int D, float scale, int dtype, ga_stream_t stream) {
+                                int D, int ld_qkv, float scale, int dtype, ga_stream_t stream) {
   if (!Q || !K || !V || !O || !dO || !LSE || !delta || !dQ || !dK || !dV) return GA_ERR_NULL;
   int rc = check_args(B, H, N, D);
   if (rc != GA_OK) return rc;
+  const int ldq = ld_qkv > 0 ? ld_qkv : H * D;
+  if (ldq < H * D || ldq % 8 != 0) return GA_ERR_SHAPE;
   if (!al16(Q) || !al16(K) || !al16(V) || !al16(O) || !al16(dO) || !al16(dQ) || !al16(dK) || !al16(dV))
     return GA_ERR_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case GA_F16: return bwd_t<_Float16>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, scale, s);
-    case GA_BF16: return bwd_t<bf16_t>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, scale, s);
-    case GA_F32: return bwd_t<float>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, scale, s);
+    case GA_F16: return bwd_t<_Float16>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);
+    case GA_BF16: return bwd_t<bf16_t>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);
+    case GA_F32: return bwd_t<float>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);
     default: return GA_ERR_DTYPE;
   }
 }

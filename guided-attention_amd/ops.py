@@ -106,21 +106,21 @@ def replay_launch_us(key, iters=100):
                                           B, H, N, Kt, D, scale, code, stream_ptr()), "replay bwd")
     elif kind in ("self_attn_fwd", "self_attn_bwd"):
         lse = torch.empty(B * H, N, device=dev, dtype=torch.float32)
-        check(lib.ga_self_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, N, D, scale, code,
+        check(lib.ga_self_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, N, D, 0, scale, code,
                                    stream_ptr()), "replay sa")
         if kind == "self_attn_fwd":
             lse_arg = lse if flag else None
 
             def fn():
-                check(lib.ga_self_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse_arg), B, H, N, D, scale, code,
-                                           stream_ptr()), "replay sa fwd")
+                check(lib.ga_self_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse_arg), B, H, N, D, 0, scale,
+                                           code, stream_ptr()), "replay sa fwd")
         else:
             d_o, delta = torch.randn_like(q), torch.empty_like(lse)
             dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
 
             def fn():
                 check(lib.ga_self_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(d_o), _ptr(lse), _ptr(delta),
-                                           _ptr(dq), _ptr(dk), _ptr(dv), B, H, N, D, scale, code, stream_ptr()),
+                                           _ptr(dq), _ptr(dk), _ptr(dv), B, H, N, D, 0, scale, code, stream_ptr()),
                       "replay sa bwd")
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -407,6 +407,10 @@ def group_norm_act(x, weight, bias, groups, eps, act):
 
 
 # --------------------------------------------------------------------------------------- tiled self-attention
+def _sub_ptr(t, elem_offset):
+    return ctypes.c_void_p(t.data_ptr() + elem_offset * t.element_size())
+
+
 def self_attn_fwd(q, k, v, heads, scale, want_lse=True):
     """q,k,v (B,N,C) projections -> (o (B,N,C), lse (B*heads,N) f32 log2-domain or None)."""
     require_cuda(q, k, v)
@@ -415,8 +419,8 @@ def self_attn_fwd(q, k, v, heads, scale, want_lse=True):
     o = torch.empty_like(q)
     lse = torch.empty((B * heads, N), dtype=torch.float32, device=q.device) if want_lse else None
     _count(("self_attn_fwd", B, heads, N, N, C // heads, bool(want_lse), str(q.dtype)))
-    check(load().ga_self_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), B, heads, N, C // heads, float(scale),
-                                  dtype_code(q), stream_ptr()), "ga_self_attn_fwd")
+    check(load().ga_self_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), B, heads, N, C // heads, 0,
+                                  float(scale), dtype_code(q), stream_ptr()), "ga_self_attn_fwd")
     return o, lse
 
 
@@ -428,7 +432,7 @@ def self_attn_bwd(q, k, v, o, d_o, lse, heads, scale):
     delta = torch.empty_like(lse)
     _count(("self_attn_bwd", B, heads, N, N, C // heads, True, str(q.dtype)))
     check(load().ga_self_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(delta), _ptr(dq),
-                                  _ptr(dk), _ptr(dv), B, heads, N, C // heads, float(scale), dtype_code(q),
+                                  _ptr(dk), _ptr(dv), B, heads, N, C // heads, 0, float(scale), dtype_code(q),
                                   stream_ptr()), "ga_self_attn_bwd")
     return dq, dk, dv
 
@@ -454,6 +458,46 @@ class SelfAttention(torch.autograd.Function):
         return dq, dk, dv, None, None
 
 
-def self_attention_supported(q, heads):
-    d = q.shape[-1] // heads
+class SelfAttentionFusedQKV(torch.autograd.Function):
+    """Same kernels on ONE (B, N, 3C) tensor [q | k | v] (the output of a fused QKV projection): the kernels read
+    the three column slices in place (row stride 3C) and the backward writes dq | dk | dv into one (B, N, 3C)
+    tensor, so the projection's backward is a single GEMM too."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale):
+        require_cuda(qkv)
+        qkv = qkv.contiguous()
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        need = ctx.needs_input_grad[0]
+        o = torch.empty((B, N, C), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B * heads, N), dtype=torch.float32, device=qkv.device) if need else None
+        _count(("self_attn_fwd", B, heads, N, N, C // heads, bool(need), str(qkv.dtype)))
+        check(load().ga_self_attn_fwd(_sub_ptr(qkv, 0), _sub_ptr(qkv, C), _sub_ptr(qkv, 2 * C), _ptr(o), _ptr(lse), B,
+                                      heads, N, C // heads, C3, float(scale), dtype_code(qkv), stream_ptr()),
+              "ga_self_attn_fwd")
+        if need:
+            ctx.save_for_backward(qkv, o, lse)
+        ctx.meta = (heads, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv, o, lse = ctx.saved_tensors
+        heads, scale = ctx.meta
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        d_o = d_o.contiguous()
+        d_qkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        _count(("self_attn_bwd", B, heads, N, N, C // heads, True, str(qkv.dtype)))
+        check(load().ga_self_attn_bwd(_sub_ptr(qkv, 0), _sub_ptr(qkv, C), _sub_ptr(qkv, 2 * C), _ptr(o), _ptr(d_o),
+                                      _ptr(lse), _ptr(delta), _sub_ptr(d_qkv, 0), _sub_ptr(d_qkv, C),
+                                      _sub_ptr(d_qkv, 2 * C), B, heads, N, C // heads, C3, float(scale),
+                                      dtype_code(qkv), stream_ptr()), "ga_self_attn_bwd")
+        return d_qkv, None, None
+
+
+def self_attention_supported(q, heads, channels=None):
+    d = (channels or q.shape[-1]) // heads
     return q.is_cuda and d % 8 == 0 and d <= (80 if q.dtype == torch.float32 else 160) and q.dtype in _lib.DTYPE_CODE

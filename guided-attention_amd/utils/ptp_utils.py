@@ -80,6 +80,19 @@ def cached_context_projections(attn, context):
     return hit[1], hit[2]
 
 
+def fused_qkv_projection(attn, hidden_states):
+    """[to_q | to_k | to_v](hidden_states) as ONE GEMM against the row-concatenated weights (built once per module,
+    rebuilt if a weight changes).  Parameter names / state_dict are untouched."""
+    ws = (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight)
+    key = tuple((w.data_ptr(), w._version) for w in ws)
+    cache = attn.__dict__.get("_qkv_cache")
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            cache = (key, torch.cat(ws, dim=0))
+        attn.__dict__["_qkv_cache"] = cache
+    return F.linear(hidden_states, cache[1])
+
+
 def refresh_context_projections(unet):
     """Recompute every cached (K, V) pair IN PLACE from its context tensor and re-key it: used after the static
     prompt-embedding buffer of the hipGraph runner was overwritten (the captured kernels read these tensors)."""
@@ -110,6 +123,18 @@ class AttendExciteCrossAttnProcessor:
         if state.curHyperParams is not None and state.curHyperParams.get("paint_with_words_stop", 0):
             raise NotImplementedError("paint-with-words (off by default in the reference) is not provided")
         is_cross = encoder_hidden_states is not None
+        store = self.attnstore
+        if not is_cross:
+            n_pix = hidden_states.shape[1]
+            fused_ok = (n_pix > MAX_CAPTURE_KEYS or torch.is_grad_enabled()) and hidden_states.is_cuda and \
+                ops.self_attention_supported(hidden_states, attn.heads, attn.to_q.out_features)
+            if fused_ok and not (store is not None and store.wants_probs(False, n_pix)):
+                # self-attention without capture: one fused QKV GEMM, flash kernels on its column slices
+                out = ops.SelfAttentionFusedQKV.apply(fused_qkv_projection(attn, hidden_states), attn.heads, attn.scale)
+                if store is not None:
+                    store(ProbsNotCaptured((hidden_states.shape[0] * attn.heads, n_pix, n_pix), out.dtype, out.device),
+                          False, self.place_in_unet)
+                return attn.to_out[1](attn.to_out[0](out))
         context = encoder_hidden_states if is_cross else hidden_states
         query = attn.to_q(hidden_states)
         if is_cross and not context.requires_grad:
@@ -118,7 +143,6 @@ class AttendExciteCrossAttnProcessor:
             key = attn.to_k(context)
             value = attn.to_v(context)
         n_pix, n_keys = query.shape[1], key.shape[1]
-        store = self.attnstore
         want = store is not None and store.wants_probs(is_cross, n_pix)
         probs = None
         ctx_needs_grad = torch.is_grad_enabled() and (key.requires_grad or value.requires_grad)

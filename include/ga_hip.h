@@ -155,13 +155,15 @@ int ga_cfg_ddim_step(const void* eps_uncond, const void* eps_text, float guidanc
  * utils/ptp_utils.py:66-93 with :97-146): O = softmax(scale Q K^T) V without materialising P.
  *   Q,K,V,O,dO,dQ,dK,dV [B][N][H][D] T (projection layout); LSE, delta [B*H][N] f32 (LSE is written by the
  *   forward, in the log2 domain, and read by the backward; delta is scratch the backward fills).
- *   D % 8 == 0, D <= 160 (f32: D <= 80).  Backward = 3 launches (delta, dQ, dK+dV), no atomics.
+ *   ld_qkv = row stride (elements) of Q, K, V and of dQ, dK, dV: 0 (= H*D) for separate projections, 3*H*D when
+   they are the three column slices of one fused QKV projection (pass the slice base pointers); O / dO are dense.
+   D % 8 == 0, D <= 160 (f32: D <= 80).  Backward = 3 launches (delta, dQ, dK+dV), no atomics.
  */
 int ga_self_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE,
-                     int B, int H, int N, int D, float scale, int dtype, ga_stream_t stream);
+                     int B, int H, int N, int D, int ld_qkv, float scale, int dtype, ga_stream_t stream);
 int ga_self_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
                      const float* LSE, float* delta, void* dQ, void* dK, void* dV,
-                     int B, int H, int N, int D, float scale, int dtype, ga_stream_t stream);
+                     int B, int H, int N, int D, int ld_qkv, float scale, int dtype, ga_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * UNet host helper: GroupNorm (+ fused SiLU) on channels-last activations, forward and backward to the

@@ -435,3 +435,19 @@ def test_self_attention_autograd(ops):
     (ref * w).sum().backward()
     for a, b, n in ((q, q2, "dq"), (k, k2, "dk"), (v, v2, "dv")):
         close(a.grad, b.grad.double().cpu().numpy(), 1e-4, n)
+
+
+def test_self_attention_fused_qkv_matches_separate(ops):
+    """The kernels on the three column slices of one (B, N, 3C) tensor == on three separate tensors (bitwise: same
+    instruction stream, only the row stride differs), forward and backward."""
+    B, H, N, D = 2, 8, 320, 40
+    C = H * D
+    qkv = dev(hashrand.normalish((B, N, 3 * C), 71), torch.float16).requires_grad_(True)
+    w = dev(hashrand.normalish((B, N, C), 72), torch.float16)
+    o = ops.SelfAttentionFusedQKV.apply(qkv, H, D ** -0.5)
+    (o * w).sum().backward()
+    q, k, v = (t.contiguous().detach().requires_grad_(True) for t in qkv.detach().split(C, dim=-1))
+    o2 = ops.SelfAttention.apply(q, k, v, H, D ** -0.5)
+    (o2 * w).sum().backward()
+    assert torch.equal(o, o2)
+    assert torch.equal(qkv.grad, torch.cat([q.grad, k.grad, v.grad], dim=-1))
