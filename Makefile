@@ -5,7 +5,9 @@ CSRC    := guided-attention_amd/csrc
 SRCS    := $(wildcard $(CSRC)/*.hip)
 OBJS    := $(SRCS:.hip=.o)
 LIB     := guided-attention_amd/libga_hip.so
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+# -amdgpu-mfma-vgpr-form: MFMA results stay in VGPRs (gfx950's register file is unified), which removes the
+# v_accvgpr_read/write traffic around every softmax step (108 -> 0 per loop iteration in self_attn_fwd)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form
 
 all: $(LIB) oracle
 

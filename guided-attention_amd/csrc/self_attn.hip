@@ -24,30 +24,73 @@ using namespace ga;
 
 namespace {
 
-constexpr int kTile = 64;      // rows of the swept tile (keys in fwd/dq, queries in dk_dv)
 constexpr int kThreads = 256;  // 4 waves
 
-template <typename T>
-using TL = TileLds<T, kTile>;
+// KT = rows of the swept tile (keys in fwd / dq, queries in dk_dv): 64, or 128 where the registers allow it
+// (fewer barriers and loop overheads per key: the 16-query forward ran 111 -> 91 us on the 4096-token layer).
+template <typename T, int KT>
+using TL = TileLds<T, KT>;
 
 // ---- staging: [rows][D] slice of a [B][N][H][D] tensor -> registers -> LDS images -------------------------------
 // V16 = 16-byte vectors per thread and matrix for one 64-row tile (DP*64 / VEC / 256)
-template <typename T, int NK>
+// PRE = true keeps the per-lane global addresses in registers (computed once; full tiles load without exec-mask
+// branches): fastest where registers are free (forward).  PRE = false recomputes them per tile and costs no
+// registers: the backward kernels sit at the VGPR limit and lost 15 % with the resident addresses.
+template <typename T, int NK, int KT, bool PRE>
 struct Stage {
-  static constexpr int VEC = TL<T>::VEC;
+  static constexpr int VEC = TL<T, KT>::VEC;
   static constexpr int DP = NK * 16;
   static constexpr int VPR = DP / VEC;                                    // vectors per row
-  static constexpr int TOTAL = kTile * VPR;                               // vectors per tile
+  static constexpr int TOTAL = KT * VPR;                                  // vectors per tile
   static constexpr int PER = (TOTAL + kThreads - 1) / kThreads;           // vectors per thread
+  static constexpr int NP = PRE ? PER : 1;
   uint4 v[PER];
+  const T* gp[NP];  // PRE: this lane's vector u of tile 0 (clamped when idle); else gp[0] = slice base
+  int row[NP];      // PRE: row inside the tile, -1 = idle lane; else row[0] = D
 
-  __device__ __forceinline__ void load(const T* __restrict__ base, int row0, int N, int D, size_t row_stride) {
+  __device__ __forceinline__ void init(const T* __restrict__ base, int D, size_t row_stride) {
+    if (PRE) {
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int idx = u * kThreads + threadIdx.x;
-      const int r = idx / VPR, d = (idx - r * VPR) * VEC;
-      v[u] = uint4{0, 0, 0, 0};
-      if (idx < TOTAL && row0 + r < N && d < D) v[u] = *reinterpret_cast<const uint4*>(base + (size_t)(row0 + r) * row_stride + d);
+      for (int u = 0; u < PER; ++u) {
+        const int idx = u * kThreads + threadIdx.x;
+        const int r = idx / VPR, d = (idx - r * VPR) * VEC;
+        const bool live = idx < TOTAL && d < D;
+        row[u < NP ? u : 0] = live ? r : -1;
+        gp[u < NP ? u : 0] = live ? base + (size_t)r * row_stride + d : base;
+      }
+    } else {
+      gp[0] = base;
+      row[0] = D;
+    }
+  }
+  __device__ __forceinline__ void load(int row0, int N, size_t row_stride) {
+    if (PRE) {
+      const size_t adv = (size_t)row0 * row_stride;
+      if (row0 + KT <= N) {  // full tile: unconditional loads, idle lanes zeroed by a select
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const int i = u < NP ? u : 0;
+          const uint4 x = *reinterpret_cast<const uint4*>(gp[i] + (row[i] >= 0 ? adv : 0));
+          v[u] = row[i] >= 0 ? x : uint4{0, 0, 0, 0};
+        }
+      } else {  // the last, partial tile
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const int i = u < NP ? u : 0;
+          v[u] = uint4{0, 0, 0, 0};
+          if (row[i] >= 0 && row0 + row[i] < N) v[u] = *reinterpret_cast<const uint4*>(gp[i] + adv);
+        }
+      }
+    } else {
+      const int D = row[0];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int idx = u * kThreads + threadIdx.x;
+        const int r = idx / VPR, d = (idx - r * VPR) * VEC;
+        v[u] = uint4{0, 0, 0, 0};
+        if (idx < TOTAL && row0 + r < N && d < D)
+          v[u] = *reinterpret_cast<const uint4*>(gp[0] + (size_t)(row0 + r) * row_stride + d);
+      }
     }
   }
   __device__ __forceinline__ void store(T* rowmaj, T* transposed) const {
@@ -61,23 +104,25 @@ struct Stage {
       if (transposed) {
         const T* e = reinterpret_cast<const T*>(&v[u]);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) transposed[TL<T>::tr(d + i) + r] = e[i];
+        for (int i = 0; i < VEC; ++i) transposed[TL<T, KT>::tr(d + i) + r] = e[i];
       }
     }
   }
 };
 
-template <typename T, int NK>
-__host__ __device__ constexpr int row_img() { return kTile * (NK * 16 + TL<T>::VEC); }
-template <typename T, int NK>
-__host__ __device__ constexpr int tr_img() { return NK * 16 * TL<T>::VS + TL<T>::ROT * (NK * 16 / TL<T>::VEC); }
+template <typename T, int NK, int KT>
+__host__ __device__ constexpr int row_img() { return KT * (NK * 16 + TL<T, KT>::VEC); }
+template <typename T, int NK, int KT>
+__host__ __device__ constexpr int tr_img() {
+  return NK * 16 * TL<T, KT>::VS + TL<T, KT>::ROT * (NK * 16 / TL<T, KT>::VEC);
+}
 
 // acc[rb][cb] += Img[rb*16 + .][:] . X[cb][:]   (rows of the LDS image on accumulator rows, this lane's column
 // fragments X in registers);  NRB row blocks of 16, CB column blocks
 template <typename T, int NK, int NRB, int CB>
 __device__ __forceinline__ void rows_times_cols(const T* img, const typename Traits<T>::frag (&x)[CB][NK], int c, int g,
                                                 f32x4 (&acc)[NRB][CB]) {
-  constexpr int KS = NK * 16 + TL<T>::VEC;
+  constexpr int KS = NK * 16 + TileLds<T, 64>::VEC;
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -97,7 +142,7 @@ __device__ __forceinline__ void featT_times_frags(const T* imgT, const typename 
   for (int dt = 0; dt < NK; ++dt)
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
-      const typename Traits<T>::frag a = load_frag<T>(imgT + TL<T>::tr(dt * 16 + c) + rb * 16 + 4 * g);
+      const typename Traits<T>::frag a = load_frag<T>(imgT + TL<T, NRB * 16>::tr(dt * 16 + c) + rb * 16 + 4 * g);
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) out[dt][cb] = Traits<T>::mma16(a, f[rb][cb], out[dt][cb]);
     }
@@ -174,7 +219,7 @@ __device__ __forceinline__ void rescale_running(float amax, int cb, int& E, f32x
 constexpr int kNoExp = 100;  // "no data yet" exponent (2^100 * 0 = 0)
 
 // =================================================================================================== forward
-template <typename T, int NK, int QB, int NBUF>
+template <typename T, int NK, int QB, int NBUF, int KT>
 __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                                  const T* __restrict__ V, T* __restrict__ O,
                                                                  float* __restrict__ LSE, int H, int N, int D, int nqt,
@@ -184,8 +229,8 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
   // one buffer = [K row-major | V transposed]; buffers are addressed as base + cur * kBuf so that the compiler
   // keeps the LDS address space (a local array of pointers decays to generic pointers -> flat_load + vmcnt(0))
   T* const lds = reinterpret_cast<T*>(smem);
-  constexpr int kBuf = NBUF == 2 ? row_img<T, NK>() + tr_img<T, NK>() : 0;
-  constexpr int kVoff = row_img<T, NK>();
+  constexpr int kBuf = NBUF == 2 ? row_img<T, NK, KT>() + tr_img<T, NK, KT>() : 0;
+  constexpr int kVoff = row_img<T, NK, KT>();
 
   const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
@@ -200,9 +245,11 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
   typename Tr::frag qf[QB][NK];
   load_col_frags<T, NK, QB>(Qb, rs, q0, N, D, c, g, qf);
 
-  Stage<T, NK> sk, sv;
-  sk.load(Kb, 0, N, D, rs);
-  sv.load(Vb, 0, N, D, rs);
+  Stage<T, NK, KT, true> sk, sv;
+  sk.init(Kb, D, rs);
+  sv.init(Vb, D, rs);
+  sk.load(0, N, rs);
+  sv.load(0, N, rs);
   sk.store(lds, nullptr);
   sv.store(nullptr, lds + kVoff);
   __syncthreads();
@@ -216,37 +263,37 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
 #pragma unroll
     for (int dt = 0; dt < NK; ++dt) o[dt][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int ntiles = (N + kTile - 1) / kTile;
+  const int ntiles = (N + KT - 1) / KT;
   for (int kt = 0; kt < ntiles; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < ntiles) {  // prefetch the next tile into registers; it lands in LDS after this tile's math
-      sk.load(Kb, (kt + 1) * kTile, N, D, rs);
-      sv.load(Vb, (kt + 1) * kTile, N, D, rs);
+      sk.load((kt + 1) * KT, N, rs);
+      sv.load((kt + 1) * KT, N, rs);
     }
-    f32x4 s[4][QB];
+    f32x4 s[KT / 16][QB];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+    for (int kb = 0; kb < KT / 16; ++kb)
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) s[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const T* kimg = lds + cur * kBuf;
     const T* vimg = kimg + kVoff;
-    rows_times_cols<T, NK, 4, QB>(kimg, qf, c, g, s);
-    const int key0 = kt * kTile;
-    if (key0 + kTile > N) {  // only the last, partial tile needs the key mask (uniform branch)
+    rows_times_cols<T, NK, KT / 16, QB>(kimg, qf, c, g, s);
+    const int key0 = kt * KT;
+    if (key0 + KT > N) {  // only the last, partial tile needs the key mask (uniform branch)
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < KT / 16; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (key0 + kb * 16 + 4 * g + r >= N) s[kb][qb][r] = -INFINITY;
     }
-    typename Tr::frag pf[4][QB];
+    typename Tr::frag pf[KT / 16][QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       float mx = -INFINITY;
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+      for (int kb = 0; kb < KT / 16; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
       mx = quad_max(mx);
@@ -255,7 +302,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
       const float alpha = fast_exp2(m[qb] * c1 - mc);  // exp2(-inf) = 0 on the first tile
       float sum = 0.f;
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+      for (int kb = 0; kb < KT / 16; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = fast_exp2(s[kb][qb][r] * c1 - mc);
@@ -269,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[dt][qb][r] *= alpha;
     }
-    featT_times_frags<T, NK, 4, QB>(vimg, pf, c, g, o);
+    featT_times_frags<T, NK, KT / 16, QB>(vimg, pf, c, g, o);
     if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before it is overwritten
     if (kt + 1 < ntiles) {
       T* nxt = lds + (cur ^ 1) * kBuf;
@@ -309,7 +356,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_delta_kernel(const T* __re
 }
 
 // =================================================================================================== backward dQ
-template <typename T, int NK, int QB, int NBUF>
+template <typename T, int NK, int QB, int NBUF, int KT>
 __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                                     const T* __restrict__ V, const T* __restrict__ dO,
                                                                     const float* __restrict__ LSE,
@@ -320,8 +367,8 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // one buffer = [K row-major | V row-major | K transposed]
   T* const lds = reinterpret_cast<T*>(smem);
-  constexpr int kVoff = row_img<T, NK>(), kToff = 2 * row_img<T, NK>();
-  constexpr int kBuf = NBUF == 2 ? 2 * row_img<T, NK>() + tr_img<T, NK>() : 0;
+  constexpr int kVoff = row_img<T, NK, KT>(), kToff = 2 * row_img<T, NK, KT>();
+  constexpr int kBuf = NBUF == 2 ? 2 * row_img<T, NK, KT>() + tr_img<T, NK, KT>() : 0;
   const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq, rso = (size_t)H * D;
@@ -340,9 +387,11 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
     lse[qb] = q < N ? LSE[((size_t)b * H + head) * N + q] : 0.f;
     dl[qb] = q < N ? delta[((size_t)b * H + head) * N + q] : 0.f;
   }
-  Stage<T, NK> sk, sv;
-  sk.load(K + off, 0, N, D, rs);
-  sv.load(V + off, 0, N, D, rs);
+  Stage<T, NK, KT, false> sk, sv;
+  sk.init(K + off, D, rs);
+  sv.init(V + off, D, rs);
+  sk.load(0, N, rs);
+  sv.load(0, N, rs);
   sk.store(lds, lds + kToff);
   sv.store(lds + kVoff, nullptr);
   __syncthreads();
@@ -355,37 +404,37 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
 #pragma unroll
     for (int dt = 0; dt < NK; ++dt) acc[dt][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int ntiles = (N + kTile - 1) / kTile;
+  const int ntiles = (N + KT - 1) / KT;
   for (int kt = 0; kt < ntiles; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < ntiles) {
-      sk.load(K + off, (kt + 1) * kTile, N, D, rs);
-      sv.load(V + off, (kt + 1) * kTile, N, D, rs);
+      sk.load((kt + 1) * KT, N, rs);
+      sv.load((kt + 1) * KT, N, rs);
     }
-    f32x4 s[4][QB], dp[4][QB];
+    f32x4 s[KT / 16][QB], dp[KT / 16][QB];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+    for (int kb = 0; kb < KT / 16; ++kb)
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) s[kb][qb] = dp[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const T* buf = lds + cur * kBuf;
-    rows_times_cols<T, NK, 4, QB>(buf, qf, c, g, s);
-    rows_times_cols<T, NK, 4, QB>(buf + kVoff, dof, c, g, dp);
-    const int key0 = kt * kTile;
-    if (key0 + kTile > N) {  // partial last tile: masked keys get p = exp2(-inf) = 0
+    rows_times_cols<T, NK, KT / 16, QB>(buf, qf, c, g, s);
+    rows_times_cols<T, NK, KT / 16, QB>(buf + kVoff, dof, c, g, dp);
+    const int key0 = kt * KT;
+    if (key0 + KT > N) {  // partial last tile: masked keys get p = exp2(-inf) = 0
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < KT / 16; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (key0 + kb * 16 + 4 * g + r >= N) s[kb][qb][r] = -INFINITY;
     }
-    typename Tr::frag dsf[4][QB];
+    typename Tr::frag dsf[KT / 16][QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       float amax = 0.f;
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+      for (int kb = 0; kb < KT / 16; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = fast_exp2(s[kb][qb][r] * c1 - lse[qb]);
@@ -396,11 +445,11 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
       if (sizeof(T) == 2) rescale_running<NK, QB>(quad_max(amax), qb, E[qb], acc);
       const float f = (sizeof(T) == 2 && E[qb] != kNoExp) ? ldexpf(1.0f, E[qb]) : 1.0f;
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+      for (int kb = 0; kb < KT / 16; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dsf[kb][qb][r] = Tr::from_f32(s[kb][qb][r] * f);
     }
-    featT_times_frags<T, NK, 4, QB>(buf + kToff, dsf, c, g, acc);
+    featT_times_frags<T, NK, KT / 16, QB>(buf + kToff, dsf, c, g, acc);
     if (NBUF == 1) __syncthreads();
     if (kt + 1 < ntiles) {
       T* nxt = lds + (cur ^ 1) * kBuf;
@@ -417,7 +466,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
 
 // =================================================================================================== backward dK, dV
 // A wave owns KB x 16 keys on its lanes; the workgroup sweeps 64-query tiles (Q and dO row-major + transposed images).
-template <typename T, int NK, int KB, int NBUF>
+template <typename T, int NK, int KB, int NBUF, int KT>
 __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                                       const T* __restrict__ V,
                                                                       const T* __restrict__ dO,
@@ -429,11 +478,11 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // one buffer = [Q row-major | Q transposed | dO row-major | dO transposed]; then the per-query LSE / delta rows
   T* const lds = reinterpret_cast<T*>(smem);
-  constexpr int kQt = row_img<T, NK>(), kDr = kQt + tr_img<T, NK>(), kDt = kDr + row_img<T, NK>();
-  constexpr int kOne = 2 * row_img<T, NK>() + 2 * tr_img<T, NK>();
+  constexpr int kQt = row_img<T, NK, KT>(), kDr = kQt + tr_img<T, NK, KT>(), kDt = kDr + row_img<T, NK, KT>();
+  constexpr int kOne = 2 * row_img<T, NK, KT>() + 2 * tr_img<T, NK, KT>();
   constexpr int kBuf = NBUF == 2 ? kOne : 0;
-  float* const stats = reinterpret_cast<float*>(lds + NBUF * kOne);  // [2][2][kTile]: (LSE, delta) per buffer
-  constexpr int kSbuf = 2 * kTile;
+  float* const stats = reinterpret_cast<float*>(lds + NBUF * kOne);  // [2][2][KT]: (LSE, delta) per buffer
+  constexpr int kSbuf = 2 * KT;
   const int head = blockIdx.x % H, rest = blockIdx.x / H, ktile = rest % nkt, b = rest / nkt;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq, rso = (size_t)H * D;
@@ -447,23 +496,25 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
   load_col_frags<T, NK, KB>(K + off, rs, k0, N, D, c, g, kf);
   load_col_frags<T, NK, KB>(V + off, rs, k0, N, D, c, g, vf);
 
-  Stage<T, NK> sq, sd;
+  Stage<T, NK, KT, false> sq, sd;
   float pl = 0.f, pd = 0.f;  // this thread's prefetched LSE / delta entry (threads 0..63)
   auto load_stats = [&](int q0t) {
-    if (threadIdx.x < kTile) {
+    if (threadIdx.x < KT) {
       const int q = q0t + threadIdx.x;
       pl = q < N ? LSE[soff + q] : 0.f;
       pd = q < N ? delta[soff + q] : 0.f;
     }
   };
-  sq.load(Q + off, 0, N, D, rs);
-  sd.load(dO + offo, 0, N, D, rso);
+  sq.init(Q + off, D, rs);
+  sd.init(dO + offo, D, rso);
+  sq.load(0, N, rs);
+  sd.load(0, N, rso);
   load_stats(0);
   sq.store(lds, lds + kQt);
   sd.store(lds + kDr, lds + kDt);
-  if (threadIdx.x < kTile) {
+  if (threadIdx.x < KT) {
     stats[threadIdx.x] = pl;
-    stats[kTile + threadIdx.x] = pd;
+    stats[KT + threadIdx.x] = pd;
   }
   __syncthreads();
 
@@ -475,33 +526,33 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
 #pragma unroll
     for (int dt = 0; dt < NK; ++dt) dk[dt][kb] = dv[dt][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int ntiles = (N + kTile - 1) / kTile;
+  const int ntiles = (N + KT - 1) / KT;
   for (int qt = 0; qt < ntiles; ++qt) {
     const int cur = qt & 1;
     if (qt + 1 < ntiles) {
-      sq.load(Q + off, (qt + 1) * kTile, N, D, rs);
-      sd.load(dO + offo, (qt + 1) * kTile, N, D, rso);
-      load_stats((qt + 1) * kTile);
+      sq.load((qt + 1) * KT, N, rs);
+      sd.load((qt + 1) * KT, N, rso);
+      load_stats((qt + 1) * KT);
     }
     // S[q rows][key cols] and dP[q rows][key cols]
-    f32x4 s[4][KB], dp[4][KB];
+    f32x4 s[KT / 16][KB], dp[KT / 16][KB];
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb)
+    for (int qb = 0; qb < KT / 16; ++qb)
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) s[qb][kb] = dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const T* buf = lds + cur * kBuf;
     const float* Lq = stats + cur * kSbuf;
-    const float* Dq = Lq + kTile;
-    rows_times_cols<T, NK, 4, KB>(buf, kf, c, g, s);
-    rows_times_cols<T, NK, 4, KB>(buf + kDr, vf, c, g, dp);
-    const int q0t = qt * kTile;
-    typename Tr::frag pf[4][KB], dsf[4][KB];
+    const float* Dq = Lq + KT;
+    rows_times_cols<T, NK, KT / 16, KB>(buf, kf, c, g, s);
+    rows_times_cols<T, NK, KT / 16, KB>(buf + kDr, vf, c, g, dp);
+    const int q0t = qt * KT;
+    typename Tr::frag pf[KT / 16][KB], dsf[KT / 16][KB];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const bool key_live = k0 + kb * 16 + c < N;
       float amax = 0.f;
 #pragma unroll
-      for (int qb = 0; qb < 4; ++qb)
+      for (int qb = 0; qb < KT / 16; ++qb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qi = qb * 16 + 4 * g + r;
@@ -515,20 +566,20 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
       if (sizeof(T) == 2) rescale_running<NK, KB>(quad_max(amax), kb, E[kb], dk);
       const float f = (sizeof(T) == 2 && E[kb] != kNoExp) ? ldexpf(1.0f, E[kb]) : 1.0f;
 #pragma unroll
-      for (int qb = 0; qb < 4; ++qb)
+      for (int qb = 0; qb < KT / 16; ++qb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dsf[qb][kb][r] = Tr::from_f32(s[qb][kb][r] * f);
     }
-    featT_times_frags<T, NK, 4, KB>(buf + kDt, pf, c, g, dv);  // dV^T += dO^T P
-    featT_times_frags<T, NK, 4, KB>(buf + kQt, dsf, c, g, dk);  // dK^T += Q^T dS
+    featT_times_frags<T, NK, KT / 16, KB>(buf + kDt, pf, c, g, dv);  // dV^T += dO^T P
+    featT_times_frags<T, NK, KT / 16, KB>(buf + kQt, dsf, c, g, dk);  // dK^T += Q^T dS
     if (NBUF == 1) __syncthreads();
     if (qt + 1 < ntiles) {
       T* nxt = lds + (cur ^ 1) * kBuf;
       sq.store(nxt, nxt + kQt);
       sd.store(nxt + kDr, nxt + kDt);
-      if (threadIdx.x < kTile) {
+      if (threadIdx.x < KT) {
         stats[(cur ^ 1) * kSbuf + threadIdx.x] = pl;
-        stats[(cur ^ 1) * kSbuf + kTile + threadIdx.x] = pd;
+        stats[(cur ^ 1) * kSbuf + KT + threadIdx.x] = pd;
       }
     }
     __syncthreads();
@@ -550,13 +601,13 @@ template <typename T, int NK>
 struct Bufs {
   static constexpr int value = (sizeof(T) == 2 && NK <= 5) ? 2 : 1;
 };
-template <typename T, int NK>
-size_t fwd_lds() { return sizeof(T) * Bufs<T, NK>::value * (row_img<T, NK>() + tr_img<T, NK>()); }
-template <typename T, int NK>
-size_t dq_lds() { return sizeof(T) * Bufs<T, NK>::value * (2 * row_img<T, NK>() + tr_img<T, NK>()); }
-template <typename T, int NK>
+template <typename T, int NK, int KT>
+size_t fwd_lds() { return sizeof(T) * Bufs<T, NK>::value * (row_img<T, NK, KT>() + tr_img<T, NK, KT>()); }
+template <typename T, int NK, int KT>
+size_t dq_lds() { return sizeof(T) * Bufs<T, NK>::value * (2 * row_img<T, NK, KT>() + tr_img<T, NK, KT>()); }
+template <typename T, int NK, int KT>
 size_t dkdv_lds() {
-  return sizeof(T) * Bufs<T, NK>::value * (2 * row_img<T, NK>() + 2 * tr_img<T, NK>()) + sizeof(float) * 4 * kTile;
+  return sizeof(T) * Bufs<T, NK>::value * (2 * row_img<T, NK, KT>() + 2 * tr_img<T, NK, KT>()) + sizeof(float) * 4 * KT;
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -574,10 +625,12 @@ bool wide_columns(int B, int H, int N) {
 template <typename T, int NK, int QB>
 int launch_fwd_cb(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D,
                   int ldq, float scale, hipStream_t s) {
-  const size_t lds = fwd_lds<T, NK>();
+  // 128-key tiles for the 16-query forward at small head sizes (register budget allows it), 64 otherwise
+  constexpr int KT = (QB == 1 && NK <= 5 && sizeof(T) == 2) ? 128 : 64;
+  const size_t lds = fwd_lds<T, NK, KT>();
   if (lds > kLdsLimit) return GA_ERR_SHAPE;
   const int nqt = (N + 64 * QB - 1) / (64 * QB);
-  auto k = self_attn_fwd_kernel<T, NK, QB, Bufs<T, NK>::value>;
+  auto k = self_attn_fwd_kernel<T, NK, QB, Bufs<T, NK>::value, KT>;
   int rc = set_dyn_lds(k, lds);
   if (rc != GA_OK) return rc;
   hipLaunchKernelGGL(k, dim3((unsigned)(B * H * nqt)), dim3(kThreads), lds, s, (const T*)Q, (const T*)K, (const T*)V,
@@ -598,14 +651,15 @@ template <typename T, int NK, int CB>
 int launch_bwd_cb(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                   float* delta, void* dQ, void* dK, void* dV, int B, int H, int N, int D, int ldq, float scale,
                   hipStream_t s) {
-  const size_t l1 = dq_lds<T, NK>(), l2 = dkdv_lds<T, NK>();
+  constexpr int KT = 64;
+  const size_t l1 = dq_lds<T, NK, KT>(), l2 = dkdv_lds<T, NK, KT>();
   if (l1 > kLdsLimit || l2 > kLdsLimit) return GA_ERR_SHAPE;
   const long long rows = (long long)B * N * H;
   hipLaunchKernelGGL(self_attn_delta_kernel<T>, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                      s, (const T*)O, (const T*)dO, delta, H, N, D, rows);
   const int nt = (N + 64 * CB - 1) / (64 * CB);
-  auto kq = self_attn_bwd_dq_kernel<T, NK, CB, Bufs<T, NK>::value>;
-  auto kk = self_attn_bwd_dkdv_kernel<T, NK, 1, Bufs<T, NK>::value>;  // dk_dv: 16 keys per wave (register budget)
+  auto kq = self_attn_bwd_dq_kernel<T, NK, CB, Bufs<T, NK>::value, KT>;
+  auto kk = self_attn_bwd_dkdv_kernel<T, NK, 1, Bufs<T, NK>::value, KT>;  // dk_dv: 16 keys per wave (register budget)
   int rc = set_dyn_lds(kq, l1);
   if (rc != GA_OK) return rc;
   rc = set_dyn_lds(kk, l2);
