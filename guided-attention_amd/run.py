@@ -1,7 +1,7 @@
 """Entry points with the reference's names (run.py): `setup`, `load_model`, `parseMetaPrompt`,
 `overrideConfig`, `run_on_prompt`, `execute`, the custom-loss plugin API (`CustomLossBase`,
-`register_custom_loss`) and a `main()` CLI taking the RunConfig fields as `--flags` (argparse: pyrallis
-is not available here).  `ToLeftOf` and the Flask front-end are "next" rows."""
+`register_custom_loss`, `ToLeftOf`) and a `main()` CLI taking the RunConfig fields as `--flags` (argparse:
+pyrallis is not available here).  The Flask front-end is out of scope."""
 import argparse
 import dataclasses
 import sys
@@ -145,6 +145,36 @@ class CustomLossBase(ABC):
         return image_map / image_map.sum() if pixel_wise_normalization else image_map
 
 
+class ToLeftOf(CustomLossBase):
+    """`[CustomLoss:toLeftOf (a, b)]`: the attention centroid of sub-prompt a must sit at least 20 % of the map width
+    to the left of b's (reference run.py:180-225, including its normalisation of BOTH centroids by the token count
+    of the left sub-prompt).  Plain PyTorch on the GPU map; differentiated by autograd and added to the fused loss."""
+
+    def calc_loss(self, cross_attention_maps, text_args: str) -> torch.Tensor:
+        args = self.parse_text_args(self.quote_items_in_tuple(text_args))
+        left = self.find_indices_for_sub_prompt(args[0])
+        right = self.find_indices_for_sub_prompt(args[1])
+        width = cross_attention_maps.shape[1]
+        cols = torch.arange(width, device=cross_attention_maps.device, dtype=cross_attention_maps.dtype) + 0.5
+
+        def centroid(idx):
+            total = cross_attention_maps.new_zeros(1)
+            for i in idx:
+                total = total + (self.get_map_for_token(cross_attention_maps, i, True) * cols[None, :]).sum() / len(left)
+            return total
+
+        gap = .2 * width
+        loss = (centroid(left) + gap - centroid(right)) / width * 9
+        return torch.clamp(loss, min=0)
+
+    def subprompts_of_interest(self, text_args: str) -> list:
+        return list(self.parse_text_args(self.quote_items_in_tuple(text_args)))
+
+    def quote_items_in_tuple(self, text_args):
+        items = text_args.strip("()").split(",")
+        return "(" + ",".join(f"'{item.strip()}'" for item in items) + ")"
+
+
 def register_custom_loss(name: str, customLoss: CustomLossBase):
     if not hasattr(shared_state.config, "registered_loss_functions"):
         shared_state.config.registered_loss_functions = {}
@@ -176,6 +206,7 @@ def _parse_cli(argv):
 def main(argv=None):
     config = _parse_cli(sys.argv[1:] if argv is None else argv)
     setup(config)
+    register_custom_loss("toLeftOf", ToLeftOf())  # as the reference's main() does (run.py:240)
     if config.interactive:
         raise NotImplementedError("the Flask front-end is out of scope; POST the meta-prompt to your own service")
     execute(config)

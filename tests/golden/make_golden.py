@@ -677,6 +677,32 @@ def g9_loop():
     np.savez_compressed(OUT / "g9_loop.npz", **arrs)
     (OUT / "g9_loop.json").write_text(json.dumps(meta, indent=1))
 
+# ----------------------------------------------------------------------------- G10 custom loss plugin
+def g10_custom_loss():
+    import run as ref_run  # pyrallis is a placeholder; ToLeftOf / CustomLossBase are plain classes
+    h = Harness()
+    mp = "a [cat:.2,.5] and a [vase:.7,.5] [CustomLoss:toLeftOf (cat, vase)]"
+    cfg = fresh_config(mp)
+    cfg.registered_loss_functions = {"toLeftOf": ref_run.ToLeftOf()}
+    cfg.stable = types.SimpleNamespace(tokenizer=h.tokenizer)
+    state.config = cfg
+    state.curHyperParams = dict(state.hyperParameterOverrides)
+    cfg.prompt, cfg.meta_info, cfg.custom_loss = helpers.parse_prompt(mp)
+    arrs = {}
+    for name, kind, seed in (("bos", "bos", 31), ("sharp", "sharp", 32)):
+        A0 = make_maps(kind, seed)
+        A_leaf = A0.clone().requires_grad_(True)
+        text = torch.softmax(A_leaf[:, :, 1:-1] * 100, dim=-1)
+        fn, args = cfg.custom_loss["toLeftOf"]
+        v = fn.calc_loss(text, args)
+        (gA,) = torch.autograd.grad(v.sum(), [A_leaf], allow_unused=True)
+        arrs[f"{name}.A"] = f32(A0)
+        arrs[f"{name}.loss"] = f32(v)
+        arrs[f"{name}.dA"] = f32(gA if gA is not None else torch.zeros_like(A0))
+    np.savez_compressed(OUT / "g10_custom_loss.npz", **arrs)
+    (OUT / "g10_custom_loss.json").write_text(json.dumps({"meta_prompt": mp, "prompt": cfg.prompt, "args": cfg.custom_loss["toLeftOf"][1],
+                                                         "meta_info": ser_meta(cfg.meta_info)}))
+
 
 def main():
     torch.manual_seed(0)
@@ -690,6 +716,7 @@ def main():
     g7_aggregate()
     g8_update()
     g9_loop()
+    g10_custom_loss()
     for p in sorted(OUT.glob("g*")):
         print(f"{p.name:32s} {p.stat().st_size:9d} B")
 

@@ -183,3 +183,35 @@ def test_graph_runner_follows_a_new_prompt_embedding():
 
     assert rel(second, eager_other) < 2e-4 and rel(first, eager_first) < 2e-4
     assert rel(second, first) > 1e-2  # the prompt really changed the result
+
+
+def test_custom_loss_plugin_against_reference_fixture():
+    """`[CustomLoss:toLeftOf (cat, vase)]`: the plugin API (register_custom_loss / CustomLossBase / ToLeftOf) on the
+    GPU against the reference's own ToLeftOf.calc_loss and its autograd gradient (tests/golden/g10)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from types import SimpleNamespace
+    from guided_attention_amd import run
+    from guided_attention_amd.config import RunConfig
+    from guided_attention_amd.text import WordTokenizer
+    from guided_attention_amd.utils import helpers, shared_state as state
+    meta = load_json("g10_custom_loss.json")
+    g = load_npz("g10_custom_loss.npz")
+    cfg = RunConfig(meta_prompt=meta["meta_prompt"], output_path="/tmp/ga_test_out")
+    cfg.stable = SimpleNamespace(tokenizer=WordTokenizer())
+    state.config = cfg
+    state.curHyperParams = dict(state.hyperParameterOverrides)
+    run.register_custom_loss("toLeftOf", run.ToLeftOf())
+    run.parseMetaPrompt(cfg)
+    assert cfg.prompt == meta["prompt"] and list(cfg.custom_loss) == ["toLeftOf"] and cfg.custom_loss["toLeftOf"][1] == meta["args"]
+    assert sorted(cfg.token_dict) == [2, 5]
+    fn, args = cfg.custom_loss["toLeftOf"]
+    for name in ("bos", "sharp"):
+        A = torch.from_numpy(g[f"{name}.A"]).cuda().requires_grad_(True)
+        text = torch.softmax(A[:, :, 1:-1] * 100, dim=-1)
+        v = fn.calc_loss(text, args)
+        np.testing.assert_allclose(v.detach().cpu().numpy(), g[f"{name}.loss"], rtol=2e-5, atol=1e-6)
+        (gA,) = torch.autograd.grad(v.sum(), [A], allow_unused=True)
+        ref = g[f"{name}.dA"]
+        got = gA.cpu().numpy() if gA is not None else np.zeros_like(ref)
+        assert np.abs(got - ref).max() <= 3e-5 * max(np.abs(ref).max(), 1e-12) + 1e-9
