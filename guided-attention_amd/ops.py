@@ -248,8 +248,10 @@ class LossPlan:
         """entries: list of dict(index, kind 'BOX'|'COOR', geom, subprompt)."""
         self.entries = list(entries)
         T = len(self.entries)
-        if T == 0:
-            raise GaError("no guided tokens")
+        self.T = T
+        if T == 0:  # only custom (Python) losses are active: nothing for the fused kernel to do
+            self.tokens, self.params, self.weights = None, None, []
+            return
         counts = OrderedDict()
         for e in self.entries:
             counts[e["subprompt"]] = counts.get(e["subprompt"], 0) + 1
@@ -278,6 +280,8 @@ class LossPlan:
 
 def smooth_loss_fwd(A, res, first, last, plan):
     require_cuda(A)
+    if plan.T == 0:
+        raise GaError("no guided tokens")
     if A.dtype != torch.float32:
         raise GaError("aggregated maps must be float32")
     A = A.contiguous()

@@ -224,7 +224,11 @@ class GuidedAttention:
             prompt = self.prompt[0] if isinstance(self.prompt, list) else self.prompt
             last_idx = len(self.tokenizer(prompt)["input_ids"]) - 1
         plan = self._loss_plan(smooth_attentions, sigma, kernel_size)
-        terms, loss = ops.SmoothLoss.apply(attention_maps.reshape(res * res, n_tok), res, 1, last_idx, plan)
+        if plan.T > 0:
+            terms, loss = ops.SmoothLoss.apply(attention_maps.reshape(res * res, n_tok), res, 1, last_idx, plan)
+        else:  # every annotated token is a KEYWORD of a custom loss (reference: no built-in term, :409-438)
+            terms = attention_maps.new_zeros((0, 8))
+            loss = attention_maps.new_zeros(1)
         custom = None
         if hasattr(state.config, "custom_loss") and state.config.custom_loss:
             text_maps = torch.softmax(attention_maps[:, :, 1:last_idx] * 100, dim=-1)
@@ -239,7 +243,7 @@ class GuidedAttention:
         `losses_dict` keys (one entry per guided token) plus the fused results."""
         self.unet_calls["loss_evals"] += 1
         host = packed.cpu()
-        host_terms = host[:-1].view(plan.T, -1)
+        host_terms = host[:-1].view(plan.T, 8)
         losses_dict = {k: [terms[t, c] for t in range(plan.T)] for k, c in TERM.items() if c < 5}
         losses_dict["_fused"] = {"loss": loss, "host_terms": host_terms, "host_loss": host[-1:], "plan": plan}
         if custom is not None:

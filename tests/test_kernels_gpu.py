@@ -313,7 +313,7 @@ def test_loss_errors(ops):
     with pytest.raises(ops.GaError):
         ops.LossPlan(ents, dict(oloss.DEFAULT_HYPER, strict=True))
     with pytest.raises(ops.GaError):
-        ops.LossPlan([], oloss.DEFAULT_HYPER)
+        ops.smooth_loss_fwd(A, 16, 1, 76, ops.LossPlan([], oloss.DEFAULT_HYPER))  # nothing to evaluate
 
 
 # ------------------------------------------------------------------------------------- latent ops (G8)

@@ -215,3 +215,32 @@ def test_custom_loss_plugin_against_reference_fixture():
         ref = g[f"{name}.dA"]
         got = gA.cpu().numpy() if gA is not None else np.zeros_like(ref)
         assert np.abs(got - ref).max() <= 3e-5 * max(np.abs(ref).max(), 1e-12) + 1e-9
+
+
+def test_pipeline_with_only_a_custom_loss():
+    """A prompt whose annotated tokens are all KEYWORDs of a custom loss: the fused kernel has nothing to do, the
+    plugin's loss alone drives the latent update (eager autograd path)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from guided_attention_amd import run
+    from guided_attention_amd.config import RunConfig
+    from guided_attention_amd.utils import helpers, ptp_utils, shared_state as state
+    meta = dict(G9[2], steps=2)
+    unet, embeds, lat0, noise, _ = g9_setup(meta)
+    pipe = build_product(unet, torch.float32)
+    cfg = RunConfig(meta_prompt="a [cat:.2,.5] and a [vase:.7,.5] [CustomLoss:toLeftOf (vase, cat)]", output_path="/tmp/ga_test_out")
+    cfg.stable = pipe
+    state.config = cfg
+    state.curHyperParams = dict(state.hyperParameterOverrides, thresholds={0: 0.0}, recurse_steps=1)
+    run.register_custom_loss("toLeftOf", run.ToLeftOf())
+    run.overrideConfig(cfg)
+    run.parseMetaPrompt(cfg)
+    helpers.log_clear()
+    ctrl = ptp_utils.AttentionStore()
+    ptp_utils.register_attention_control(pipe, ctrl)
+    out = pipe(prompt=None, prompt_embeds=embeds[1:2].cuda(), negative_prompt_embeds=embeds[0:1].cuda(),
+               attention_store=ctrl, num_inference_steps=2, thresholds=cfg.thresholds, latents=lat0.clone(),
+               renoise_noise=[n.clone() for n in noise], output_type="latent")
+    assert out.unet_calls["bwd"] >= 1 and torch.isfinite(out.latents).all()
+    plain, _ = run_product(pipe, dict(meta, hyper={"recurse_steps": 1}), embeds, lat0, noise, {0: 99.0})
+    assert (out.latents - plain.latents).abs().max() > 1e-4  # the custom loss moved the latents
