@@ -244,3 +244,57 @@ def test_pipeline_with_only_a_custom_loss():
     assert out.unet_calls["bwd"] >= 1 and torch.isfinite(out.latents).all()
     plain, _ = run_product(pipe, dict(meta, hyper={"recurse_steps": 1}), embeds, lat0, noise, {0: 99.0})
     assert (out.latents - plain.latents).abs().max() > 1e-4  # the custom loss moved the latents
+
+
+def test_sd21_768_shapes_one_guidance_step():
+    """BASELINE config 4 shapes (no reference oracle exists: the reference hard-codes 16): SD-2.1 layout
+    (linear projections, per-level head counts with head_dim 64, EOT-normalised text slice), 768^2 -> latent 96^2,
+    attention_res 24, three bounding boxes.  One guidance evaluation + latent update, HIP fp32 vs the CPU oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import copy
+    from guided_attention_amd import ops
+    from guided_attention_amd.pipeline_guided_attention import GuidedAttention
+    from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig
+    from guided_attention_amd.utils import ptp_utils, shared_state as state
+    from oracle import attention as oattn
+    from oracle.pipeline import install_processors
+    cfg = UNetConfig(sample_size=96, block_out_channels=(64, 64, 128, 128), attention_head_dim=(1, 1, 2, 2),
+                     cross_attention_dim=64, use_linear_projection=True)
+    unet = UNet2DConditionModel(cfg).init_weights_(seed=21).float()
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    embeds = torch.from_numpy(hashrand.normalish((1, 77, 64), 2101))
+    lat = torch.from_numpy(hashrand.normalish((1, 4, 96, 96), 2102))
+    entries = [{"index": 2, "kind": "BOX", "geom": (.6, .3, .4, .55), "subprompt": "robot"},
+               {"index": 5, "kind": "BOX", "geom": (.2, .3, .4, .55), "subprompt": "blue vase"},
+               {"index": 6, "kind": "BOX", "geom": (.2, .3, .4, .55), "subprompt": "blue vase"},
+               {"index": 9, "kind": "BOX", "geom": (.35, .05, .35, .35), "subprompt": "moon"}]
+    n_prompt_tokens = 11  # BOS + 9 words + first EOT -> text slice [1, 10)
+    # oracle
+    cpu_unet = copy.deepcopy(unet)
+    store = oattn.OracleStore()
+    install_processors(cpu_unet, store)
+    lat_c = lat.clone().requires_grad_(True)
+    cpu_unet(lat_c, 981, encoder_hidden_states=embeds)
+    A_ref = oattn.aggregate(store.attention_store, 24, ("up", "down", "mid"), True)
+    r = oloss.loss_torch(A_ref, oloss.TokenPlan(entries), normalize_eot=True, n_prompt_tokens=n_prompt_tokens)
+    (g_ref,) = torch.autograd.grad(r["loss"], [lat_c])
+    # product
+    pipe = GuidedAttention(unet).to("cuda", torch.float32)
+    state.curHyperParams = dict(state.hyperParameterOverrides)
+    ctrl = ptp_utils.AttentionStore(attention_res=24)
+    ptp_utils.register_attention_control(pipe, ctrl)
+    lat_g = lat.cuda().requires_grad_(True)
+    pipe.unet(lat_g, 981, encoder_hidden_states=embeds.cuda())
+    assert {k: len(v) for k, v in ctrl.attention_store.items() if v} == {"down_cross": 2, "up_cross": 3}
+    assert ctrl.attention_store["up_cross"][0].shape == (2, 576, 77)
+    A = ptp_utils.aggregate_attention(ctrl, 24, ("up", "down", "mid"), True, 0)
+    plan = ops.LossPlan(entries, state.curHyperParams)
+    terms, loss = ops.SmoothLoss.apply(A.reshape(576, 77), 24, 1, n_prompt_tokens - 1, plan)
+    (g_hip,) = torch.autograd.grad(loss, [lat_g])
+    assert np.abs(A.detach().cpu().numpy() - A_ref.detach().numpy()).max() < 1e-4 * A_ref.max().item()
+    np.testing.assert_allclose(loss.item(), float(r["loss"]), rtol=1e-4)
+    np.testing.assert_allclose(terms[:, 5].cpu().numpy(), [float(v) for v in r["token_loss"]], rtol=2e-4, atol=1e-6)
+    err = (g_hip.cpu() - g_ref).abs().max().item() / g_ref.abs().max().item()
+    assert err < 3e-3, err
