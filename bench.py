@@ -136,6 +136,19 @@ def kernel_work(key):
     return "mfma", flops * (1.0 if kind == "self_attn_fwd" else 2.5)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel's largest shape from the committed PMC run (FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc passes, gfx950 correction applied: profiles/r1_pmc_self_attn.json);
+    None when no PMC profile of that kernel is committed."""
+    try:
+        doc = json.loads((ROOT / "profiles" / "r1_pmc_self_attn.json").read_text())
+        k = doc["kernels"][kernel]
+        return {"hbm_bytes": k["hbm_bytes_corrected"], "algorithmic_bytes": k["algorithmic_bytes"], "shape": doc["shape"],
+                "source": "profiles/r1_pmc_self_attn.json"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def roofline_entry(census, ops):
     """Dominant hand-written kernel = the ga_* entry point with the largest total time over the timed region.
     achieved = sum of algorithmic work over its calls / sum of their durations; each shape's duration is measured by a
@@ -166,7 +179,7 @@ def roofline_entry(census, ops):
 
     kind, d = max(per_kind.items(), key=lambda kv: kv[1]["time_us"])
     out = summary(kind, d)
-    out["traffic"] = None
+    out["traffic"] = pmc_traffic("ga_" + kind)
     out["shapes"] = sorted(d["shapes"], key=lambda x: -x["calls"] * x["call_us"])[:6]
     out["other_kernels"] = [summary(k, v) for k, v in sorted(per_kind.items(), key=lambda kv: -kv[1]["time_us"]) if k != kind]
     return out
