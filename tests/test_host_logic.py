@@ -1,0 +1,220 @@
+"""CPU tests of the product's HOST layer (no kernels run): the reference-named mirrors under
+guided_attention_amd/ against the fixtures produced by the reference (tests/golden) and its documented defaults."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_json, load_npz
+from guided_attention_amd import run
+from guided_attention_amd.config import RunConfig
+from guided_attention_amd.pipeline_guided_attention import GuidedAttention, GuidedAttentionPipeline
+from guided_attention_amd.scheduler import DDIMScheduler
+from guided_attention_amd.text import WordTokenizer
+from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig
+from guided_attention_amd.utils import helpers, ptp_utils, shared_state as state
+
+
+class _Custom:
+    def subprompts_of_interest(self, args):
+        return [a.strip() for a in args.strip("()").split(",")]
+
+
+def _ser(meta_info):
+    out = []
+    for tok, typ, val in meta_info:
+        v = [val.x, val.y, val.width, val.height, val.size] if typ.name == "BOX" else (list(val) if typ.name == "COOR" else None)
+        out.append([tok, typ.name, v])
+    return out
+
+
+@pytest.mark.parametrize("case", load_json("g2_parse_prompt.json"), ids=lambda c: c["meta_prompt"][:28])
+def test_parse_prompt_matches_reference(case):
+    state.config = SimpleNamespace(registered_loss_functions={"toLeftOf": _Custom()})
+    prompt, meta, custom = helpers.parse_prompt(case["meta_prompt"])
+    assert prompt == case["prompt"]
+    assert _ser(meta) == case["meta_info"]
+    assert {k: v[1] for k, v in custom.items()} == case["custom_losses"]
+
+
+def test_parse_prompt_errors_like_the_reference():
+    state.config = SimpleNamespace(registered_loss_functions={})
+    with pytest.raises(ValueError):
+        helpers.parse_prompt("a [cat .2,.3]")          # no colon: str.index raises ValueError
+    with pytest.raises(KeyError):
+        helpers.parse_prompt("a [CustomLoss:nope (x)]")  # unregistered custom loss
+
+
+def test_inside_box_and_rect_match_reference():
+    cases = load_json("g3_inside_box.json")
+    arrs = load_npz("g3_inside_box.npz")
+    for c in cases:
+        state.curHyperParams = dict(state.hyperParameterOverrides, shrink_factor=c["shrink"])
+        rect = helpers.Rect(*c["rect"], 1).of_size(float(c["res"]))
+        assert [rect.x, rect.y, rect.width, rect.height] == c["scaled"]
+        assert list(helpers.Rect(*c["rect"], 1).center()) == c["center"]
+        mask = helpers.inside_mask(rect, c["res"]).numpy().astype(np.uint8)
+        assert np.array_equal(mask, arrs[f"mask{c['id']}"]), c
+
+
+def test_calculate_bounding_box_losses_cpu_tensor():
+    state.curHyperParams = dict(state.hyperParameterOverrides)
+    g = load_npz("g4_loss.npz")  # recompute inside/outside of one token from the reference's own smoothed map is not
+    P = torch.rand(16, 16)       # stored; check the defining identities instead
+    P = P / P.sum()
+    inside, outside = helpers.calculate_bounding_box_losses(helpers.Rect(.6, .3, .4, .55, 1).of_size(16.0), P)
+    mask = helpers.inside_mask(helpers.Rect(.6, .3, .4, .55, 1).of_size(16.0), 16)
+    assert mask.sum() == 24
+    np.testing.assert_allclose(float(inside), 1 - float(P[mask].sum()), rtol=1e-6)
+    np.testing.assert_allclose(float(inside), float(outside), rtol=1e-5)  # both equal 1 - mass inside
+    state.curHyperParams["strict"] = True
+    with pytest.raises(NotImplementedError):
+        helpers.calculate_bounding_box_losses(helpers.Rect(0, 0, 1, 1, 1).of_size(16.0), P)
+    state.curHyperParams["strict"] = False
+
+
+def test_meets_threshold_and_grouping_match_reference():
+    doc = load_json("g5_meets_threshold.json")
+    state.config = SimpleNamespace(token_dict={int(t): {"subprompt": s} for t, s in doc["token_subprompt"].items()},
+                                   sub_prompt_avg_within=False)
+    pipe = GuidedAttention.__new__(GuidedAttention)
+    for row in doc["rows"]:
+        thr = {int(k): v for k, v in doc["thr_sets"][row["thresholds"]].items()}
+        losses = [(t, torch.tensor([v], dtype=torch.float32)) for t, v in doc["loss_sets"][row["losses"]]]
+        assert pipe.meets_threshold(row["i"], thr, losses) == row["result"], row
+    total, per = GuidedAttention.group_losses_by_sumprompt([(2, torch.tensor([.5])), (5, torch.tensor([.25])), (6, torch.tensor([.25]))])
+    assert float(total) == 1.0 and {k: float(v) for k, v in per.items()} == {"robot": .5, "blue vase": .5}
+    state.config.sub_prompt_avg_within = True
+    total, per = GuidedAttention.group_losses_by_sumprompt([(2, torch.tensor([.5])), (5, torch.tensor([.25])), (6, torch.tensor([.75]))])
+    assert float(total) == 1.0 and float(per["blue vase"]) == 0.5
+
+
+def test_run_config_and_hyper_parameter_defaults():
+    cfg = RunConfig(meta_prompt="x", output_path="/tmp/ga_test_out")
+    assert (cfg.seeds, cfg.n_inference_steps, cfg.guidance_scale, cfg.max_iter_to_alter, cfg.attention_res) == ([42], 50, 7.5, 25, 16)
+    assert cfg.thresholds == {0: 0.1, 3: 0.8} and cfg.scale_factor == 20 and cfg.scale_range == (1.0, 0.5)
+    assert (cfg.smooth_attentions, cfg.sigma, cfg.kernel_size) == (True, 0.5, 3)
+    assert cfg.only_update_on_threshold_steps is True and cfg.sub_prompt_avg_within is False and cfg.sd_2_1 is False
+    assert state.hyperParameterOverrides == {"strict": False, "inside_loss_scale": .2, "outside_loss_scale": .2,
+                                             "shrink_factor": .15, "thresholds": {0: 1.}, "use_optimizer": False,
+                                             "recurse_until": 14, "recurse_steps": 3}
+    assert state.get_hyperparam_states() == [state.hyperParameterOverrides]
+    # overrideConfig: the hyper-parameter thresholds REPLACE the CLI ones (reference run.py:75-79)
+    state.curHyperParams = state.get_hyperparam_states()[0]
+    run.overrideConfig(cfg)
+    assert cfg.thresholds == {0: 1.0}
+    cli = run._parse_cli(["--meta_prompt", "a [cat:.1,.2]", "--seeds", "[3,4]", "--thresholds", "{0:0.2,5:0.7}",
+                          "--half_precision", "true", "--output_path", "/tmp/ga_test_out"])
+    assert cli.seeds == [3, 4] and cli.thresholds == {0: 0.2, 5: 0.7} and cli.half_precision is True
+
+
+def test_parse_meta_prompt_builds_the_token_dict():
+    cfg = RunConfig(meta_prompt="a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55]", output_path="/tmp/ga_test_out")
+    cfg.stable = SimpleNamespace(tokenizer=WordTokenizer())
+    run.parseMetaPrompt(cfg)
+    assert cfg.prompt == "a robot and a blue vase"
+    assert sorted(cfg.token_dict) == [2, 5, 6]  # robot = 2, blue = 5, vase = 6
+    assert cfg.token_dict[5]["subprompt"] == cfg.token_dict[6]["subprompt"] == "blue vase"
+    assert cfg.token_dict[2]["loss_type"] == helpers.AnnotationType.BOX and cfg.token_dict[2]["word"] == "robot"
+    bad = RunConfig(meta_prompt="a [unicorn horn:.1,.2] b", output_path="/tmp/ga_test_out")
+    bad.stable = SimpleNamespace(tokenizer=WordTokenizer())
+    bad.meta_prompt = "[zebra:.1,.2]"
+    run.parseMetaPrompt(bad)  # single word: found
+    bad.meta_prompt = "a [b c:.1,.2] d e"
+    run.parseMetaPrompt(bad)
+    assert sorted(bad.token_dict) == [2, 3]
+
+
+def test_attention_store_bookkeeping_without_kernels():
+    state.config = SimpleNamespace(save_individual_CA_maps=False)
+    for capture, kept in (("reference", 3), ("loss-only", 1)):
+        store = ptp_utils.AttentionStore(capture=capture)
+        store.num_att_layers = 4
+        assert store.wants_probs(True, 256) and (store.wants_probs(False, 1024) == (capture == "reference"))
+        assert not store.wants_probs(True, 4096)
+        calls = [(torch.zeros(8, 256, 77), True, "down"), (ptp_utils.ProbsNotCaptured((8, 4096, 77), torch.float16, "cpu"), True, "up"),
+                 (torch.zeros(8, 1024, 1024) if capture == "reference" else ptp_utils.ProbsNotCaptured((8, 1024, 1024), torch.float16, "cpu"), False, "up"),
+                 (torch.zeros(8, 64, 77) if capture == "reference" else ptp_utils.ProbsNotCaptured((8, 64, 77), torch.float16, "cpu"), True, "mid")]
+        for probs, is_cross, place in calls:
+            store(probs, is_cross, place)
+        assert store.cur_step == 1 and store.cur_att_layer == 0
+        assert sum(len(v) for v in store.attention_store.values()) == kept
+        assert store.step_store == ptp_utils.AttentionStore.get_empty_store()
+        store.reset()
+        assert store.attention_store == {} and store.cur_step == 0
+    with pytest.raises(ValueError):
+        ptp_utils.AttentionStore(capture="everything")
+    empty = ptp_utils.EmptyControl()
+    empty.num_att_layers = 1
+    empty(torch.zeros(1, 4, 4), True, "mid")
+    assert empty.cur_step == 1 and not empty.wants_probs(True, 256)
+
+
+def test_register_attention_control_names_and_places():
+    unet = UNet2DConditionModel(UNetConfig.tiny(32, 48))
+    model = SimpleNamespace(unet=unet)
+    store = ptp_utils.AttentionStore()
+    ptp_utils.register_attention_control(model, store)
+    assert store.num_att_layers == 32 == len(unet.attn_processors)
+    places = {n: p.place_in_unet for n, p in unet.attn_processors.items()}
+    assert places["down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor"] == "down"
+    assert places["mid_block.attentions.0.transformer_blocks.0.attn2.processor"] == "mid"
+    assert places["up_blocks.3.attentions.2.transformer_blocks.0.attn2.processor"] == "up"
+    with pytest.raises(ValueError):
+        unet.set_attn_processor({"only.one.processor": None})
+
+
+def test_unet_inventory_and_ddim_schedule():
+    with torch.device("meta"):
+        unet = UNet2DConditionModel(UNetConfig.sd15())
+    assert sum(p.numel() for p in unet.parameters()) == 859_520_964  # the SD-1.x UNet
+    names = dict(unet.named_parameters())
+    for key in ("conv_in.weight", "time_embedding.linear_1.weight", "down_blocks.0.resnets.0.time_emb_proj.bias",
+                "down_blocks.1.attentions.1.transformer_blocks.0.attn2.to_k.weight", "mid_block.attentions.0.proj_in.weight",
+                "up_blocks.1.attentions.2.transformer_blocks.0.ff.net.0.proj.weight", "up_blocks.2.upsamplers.0.conv.bias",
+                "down_blocks.2.downsamplers.0.conv.weight", "conv_norm_out.weight", "conv_out.bias"):
+        assert key in names, key
+    assert names["down_blocks.1.attentions.1.transformer_blocks.0.attn2.to_k.weight"].shape == (640, 768)
+    assert names["up_blocks.1.resnets.2.conv1.weight"].shape == (1280, 1920, 3, 3)
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    assert s.timesteps.tolist() == list(range(981, 0, -20))  # reference utils/shared_state.py:8
+    a_t, a_prev = s.alphas_for(1)
+    assert a_prev == float(s.alphas_cumprod[0]) and 0 < s.alphas_for(981)[0] < 0.01
+    x, eps = torch.randn(1, 4, 8, 8), torch.randn(1, 4, 8, 8)
+    out = s.step(eps, 501, x)
+    a, ap = s.alphas_for(501)
+    x0 = (x - (1 - a) ** .5 * eps) / a ** .5
+    torch.testing.assert_close(out.prev_sample, ap ** .5 * x0 + (1 - ap) ** .5 * eps)
+    with pytest.raises(NotImplementedError):
+        s.step(eps, 501, x, eta=0.5)
+
+
+def test_pipeline_surface_and_loud_failures():
+    assert GuidedAttentionPipeline is GuidedAttention
+    import inspect
+    params = inspect.signature(GuidedAttention.__call__).parameters
+    for kw in ("prompt", "attention_store", "attention_res", "height", "width", "num_inference_steps", "guidance_scale",
+               "negative_prompt", "num_images_per_prompt", "eta", "generator", "latents", "prompt_embeds",
+               "negative_prompt_embeds", "output_type", "return_dict", "callback", "callback_steps", "cross_attention_kwargs",
+               "max_iter_to_alter", "run_standard_sd", "thresholds", "scale_factor", "scale_range", "smooth_attentions",
+               "sigma", "kernel_size", "sd_2_1"):
+        assert kw in params, kw
+    assert params["thresholds"].default == {0: 0.05, 10: 0.5, 20: 0.8} and params["max_iter_to_alter"].default == 25
+    with pytest.raises(FileNotFoundError):
+        GuidedAttention.from_pretrained("CompVis/stable-diffusion-v1-4")  # no network, no silent random weights
+    pipe = GuidedAttention.from_pretrained("x", random_init=True, unet_config=UNetConfig.tiny(32, 48))
+    with pytest.raises(ValueError):
+        pipe.check_inputs("p", 100, 512, 1)
+    with pytest.raises(ValueError):
+        pipe.check_inputs(None, 512, 512, 1)
+    lat = pipe.prepare_latents(1, 4, 256, 256, torch.float32, "cpu", torch.Generator().manual_seed(3))
+    assert lat.shape == (1, 4, 32, 32)
+    with pytest.raises(ValueError):
+        pipe.prepare_latents(1, 4, 256, 256, torch.float32, "cpu", None, torch.zeros(1, 4, 8, 8))
+    # the default attention processor is the HIP one: a CPU forward must raise, not fall back
+    from guided_attention_amd._lib import GaError
+    state.curHyperParams = dict(state.hyperParameterOverrides)
+    with pytest.raises(GaError):
+        pipe.unet(torch.zeros(1, 4, 32, 32), 981, encoder_hidden_states=torch.zeros(1, 77, 48))
