@@ -110,6 +110,22 @@ class GroupNormAct(nn.GroupNorm):
         return F.silu(y) if self.act else y
 
 
+def pointwise_conv_tokens(x_tokens, conv):
+    """A 1x1 Conv2d applied to a (B, HW, C) token view as ONE GEMM with the bias in its epilogue: on channels-last
+    activations the token view is free, and the library GEMM beats the implicit-GEMM conv path at these sizes."""
+    return F.linear(x_tokens, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
+
+
+def nchw_to_tokens(x):
+    b, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(b, h * w, c)  # a view when x is channels-last
+
+
+def tokens_to_nchw(t, h, w):
+    b, _, c = t.shape
+    return t.reshape(b, h, w, c).permute(0, 3, 1, 2)   # channels-last strides, no copy
+
+
 class GEGLU(nn.Module):
     def __init__(self, dim_in, dim_out):
         super().__init__()
@@ -164,18 +180,12 @@ class Transformer2DModel(nn.Module):
     def forward(self, x, context):
         b, c, h, w = x.shape
         res = x
-        x = self.norm(x)
-        if self.use_linear_projection:
-            x = self.proj_in(x.permute(0, 2, 3, 1).reshape(b, h * w, c))
-        else:
-            x = self.proj_in(x).permute(0, 2, 3, 1).reshape(b, h * w, -1)
+        x = nchw_to_tokens(self.norm(x))
+        x = self.proj_in(x) if self.use_linear_projection else pointwise_conv_tokens(x, self.proj_in)
         for blk in self.transformer_blocks:
             x = blk(x, context)
-        if self.use_linear_projection:
-            x = self.proj_out(x).reshape(b, h, w, c).permute(0, 3, 1, 2)
-        else:
-            x = self.proj_out(x.reshape(b, h, w, -1).permute(0, 3, 1, 2))
-        return x + res
+        x = self.proj_out(x) if self.use_linear_projection else pointwise_conv_tokens(x, self.proj_out)
+        return tokens_to_nchw(x, h, w) + res
 
 
 class ResnetBlock2D(nn.Module):
@@ -191,12 +201,18 @@ class ResnetBlock2D(nn.Module):
     def forward(self, x, temb_act):
         """temb_act = SiLU(time embedding), computed once per UNet forward; or the dict the UNet prepared with this
         block's time_emb_proj(temb_act) already evaluated (all blocks in one GEMM)."""
-        h = self.conv1(self.norm1(x))  # norm1 / norm2 carry the SiLU
-        tproj = temb_act[id(self)] if isinstance(temb_act, dict) else self.time_emb_proj(temb_act)
+        # norm1 / norm2 carry the SiLU.  conv1's bias rides on the time projection (one add instead of two): the
+        # UNet's batched projection already contains it; the stand-alone path adds it here
+        h = F.conv2d(self.norm1(x), self.conv1.weight, None, padding=1)
+        if isinstance(temb_act, dict):
+            tproj = temb_act[id(self)]
+        else:
+            tproj = self.time_emb_proj(temb_act) + self.conv1.bias
         h = h + tproj[:, :, None, None]
         h = self.conv2(self.norm2(h))
         if self.conv_shortcut is not None:
-            x = self.conv_shortcut(x)
+            _, _, hh, ww = x.shape
+            x = tokens_to_nchw(pointwise_conv_tokens(nchw_to_tokens(x), self.conv_shortcut), hh, ww)
         return x + h
 
 
@@ -372,13 +388,13 @@ class UNet2DConditionModel(nn.Module):
         evaluated as ONE GEMM against the row-concatenated weights (built once; rebuilt if a weight changes) and
         handed to the blocks as views."""
         blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
-        key = tuple((b.time_emb_proj.weight.data_ptr(), b.time_emb_proj.weight._version, b.time_emb_proj.bias._version)
-                    for b in blocks)
+        key = tuple((b.time_emb_proj.weight.data_ptr(), b.time_emb_proj.weight._version, b.time_emb_proj.bias._version,
+                     b.conv1.bias._version) for b in blocks)
         cache = self.__dict__.get("_tproj_cache")
         if cache is None or cache[0] != key:
             with torch.no_grad():
                 w = torch.cat([b.time_emb_proj.weight for b in blocks], dim=0)
-                bias = torch.cat([b.time_emb_proj.bias for b in blocks], dim=0)
+                bias = torch.cat([b.time_emb_proj.bias + b.conv1.bias for b in blocks], dim=0)  # conv1's bias rides along
             cache = (key, w, bias, [b.time_emb_proj.out_features for b in blocks])
             self.__dict__["_tproj_cache"] = cache
         _, w, bias, sizes = cache
