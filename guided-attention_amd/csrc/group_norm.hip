@@ -31,6 +31,19 @@ struct Item {
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + __expf(-z)); }
 
+// optional per-(image, channel) bias added to x on load (the ResnetBlock's time-embedding term): normalising
+// x + bias[c] without a separate broadcast-add pass over the tensor
+template <typename T, int W>
+__device__ __forceinline__ void load_chan_bias(const T* __restrict__ cbias, int b, int CP, int cp, float (&cb)[W]) {
+#pragma unroll
+  for (int j = 0; j < W; ++j) cb[j] = 0.f;
+  if (cbias != nullptr) {
+    const Item<T, W> it = reinterpret_cast<const Item<T, W>*>(cbias)[(size_t)b * CP + cp];
+#pragma unroll
+    for (int j = 0; j < W; ++j) cb[j] = Traits<T>::to_f32(it.v[j]);
+  }
+}
+
 // sums over this workgroup's pixels of (v0, v1) per channel pair, folded to groups in fixed order
 template <int NPT>
 __device__ __forceinline__ void fold_to_groups(const float (&s0)[NPT], const float (&s1)[NPT], int CP, int cpg, int G,
@@ -56,8 +69,8 @@ __device__ __forceinline__ void fold_to_groups(const float (&s0)[NPT], const flo
 }
 
 template <typename T, int NPT, int W>
-__global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ partial,
-                                                            int HW, int C, int G, int PB) {
+__global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+                                                            float* __restrict__ partial, int HW, int C, int G, int PB) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.y, nb = blockIdx.x, CP = C / W, cpg = (C / G) / W;
   const int p0 = nb * PB, p1 = min(HW, p0 + PB);
@@ -69,6 +82,8 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict_
   for (int k = 0; k < NPT; ++k) {
     const int cp = threadIdx.x + k * kThreads;
     if (cp >= CP) continue;
+    float cb[W];
+    load_chan_bias<T, W>(cbias, b, CP, cp, cb);
     for (int p = p0; p < p1; p += kU) {  // kU independent loads in flight per lane, then the fixed-order adds
       Item<T, W> v[kU];
 #pragma unroll
@@ -79,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict_
         if (p + u < p1) {
 #pragma unroll
           for (int j = 0; j < W; ++j) {
-            const float a = Traits<T>::to_f32(v[u].v[j]);
+            const float a = Traits<T>::to_f32(v[u].v[j]) + cb[j];
             s0[k] += a;
             s1[k] += a * a;
           }
@@ -136,7 +151,8 @@ __global__ __launch_bounds__(kThreads) void gn_finalize_kernel(const float* __re
 }
 
 template <typename T, bool ACT, int NPT, int W>
-__global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+__global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+                                                            const T* __restrict__ gamma,
                                                             const T* __restrict__ beta, T* __restrict__ y,
                                                             const float* __restrict__ stats, int HW, int C, int G,
                                                             int PB) {
@@ -150,10 +166,12 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict_
       const int g = cp / cpg;
       const Item<T, W> ga_ = reinterpret_cast<const Item<T, W>*>(gamma)[cp];
       const Item<T, W> be = reinterpret_cast<const Item<T, W>*>(beta)[cp];
+      float cb[W];
+      load_chan_bias<T, W>(cbias, b, CP, cp, cb);
 #pragma unroll
       for (int j = 0; j < W; ++j) {
         sc[k][j] = Traits<T>::to_f32(ga_.v[j]) * mu_rs[2 * g + 1];
-        sh[k][j] = Traits<T>::to_f32(be.v[j]) - mu_rs[2 * g] * sc[k][j];
+        sh[k][j] = Traits<T>::to_f32(be.v[j]) - (mu_rs[2 * g] - cb[j]) * sc[k][j];  // (x + cb - mean) * scale + beta
       }
     }
   }
@@ -198,7 +216,8 @@ __device__ __forceinline__ float dyhat_of(float yhat, float dy, float gam, float
 }
 
 template <typename T, bool ACT, int NPT, int W>
-__global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+__global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+                                                                const T* __restrict__ dy,
                                                                 const T* __restrict__ gamma,
                                                                 const T* __restrict__ beta,
                                                                 const float* __restrict__ stats,
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(const T* __restr
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.y, nb = blockIdx.x, CP = C / W, cpg = (C / G) / W;
   const int p0 = nb * PB, p1 = min(HW, p0 + PB);
-  float s0[NPT], s1[NPT], mu[NPT], rs[NPT], g0[NPT][W], b0[NPT][W];
+  float s0[NPT], s1[NPT], mu[NPT], rs[NPT], g0[NPT][W], b0[NPT][W], cbk[NPT][W];
 #pragma unroll
   for (int k = 0; k < NPT; ++k) {
     s0[k] = s1[k] = 0.f;
@@ -218,6 +237,7 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(const T* __restr
       rs[k] = stats[((size_t)b * G + g) * 2 + 1];
       const Item<T, W> ga_ = reinterpret_cast<const Item<T, W>*>(gamma)[cp];
       const Item<T, W> be = reinterpret_cast<const Item<T, W>*>(beta)[cp];
+      load_chan_bias<T, W>(cbias, b, CP, cp, cbk[k]);
 #pragma unroll
       for (int j = 0; j < W; ++j) {
         g0[k][j] = Traits<T>::to_f32(ga_.v[j]);
@@ -244,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(const T* __restr
         if (p + u < p1) {
 #pragma unroll
           for (int j = 0; j < W; ++j) {
-            const float yh = (Traits<T>::to_f32(v[u].v[j]) - mu[k]) * rs[k];
+            const float yh = (Traits<T>::to_f32(v[u].v[j]) + cbk[k][j] - mu[k]) * rs[k];
             const float dh = dyhat_of<ACT>(yh, Traits<T>::to_f32(d[u].v[j]), g0[k][j], b0[k][j]);
             s0[k] += dh;
             s1[k] += dh * yh;
@@ -256,14 +276,15 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(const T* __restr
 }
 
 template <typename T, bool ACT, int NPT, int W>
-__global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+__global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+                                                                const T* __restrict__ dy,
                                                                 const T* __restrict__ gamma,
                                                                 const T* __restrict__ beta,
                                                                 const float* __restrict__ stats,
                                                                 const float* __restrict__ fin, T* __restrict__ dx,
                                                                 int HW, int C, int G, int PB) {
   const int b = blockIdx.y, CP = C / W, cpg = (C / G) / W;
-  float mu[NPT], rs[NPT], a1[NPT], a2[NPT], g0[NPT][W], b0[NPT][W];
+  float mu[NPT], rs[NPT], a1[NPT], a2[NPT], g0[NPT][W], b0[NPT][W], cbk[NPT][W];
 #pragma unroll
   for (int k = 0; k < NPT; ++k) {
     const int cp = threadIdx.x + k * kThreads;
@@ -275,6 +296,7 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
       a2[k] = fin[((size_t)b * G + g) * 2 + 1];
       const Item<T, W> ga_ = reinterpret_cast<const Item<T, W>*>(gamma)[cp];
       const Item<T, W> be = reinterpret_cast<const Item<T, W>*>(beta)[cp];
+      load_chan_bias<T, W>(cbias, b, CP, cp, cbk[k]);
 #pragma unroll
       for (int j = 0; j < W; ++j) {
         g0[k][j] = Traits<T>::to_f32(ga_.v[j]);
@@ -304,7 +326,7 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
           Item<T, W> o;
 #pragma unroll
           for (int j = 0; j < W; ++j) {
-            const float yh = (Traits<T>::to_f32(v[u].v[j]) - mu[k]) * rs[k];
+            const float yh = (Traits<T>::to_f32(v[u].v[j]) + cbk[k][j] - mu[k]) * rs[k];
             const float dh = dyhat_of<ACT>(yh, Traits<T>::to_f32(d[u].v[j]), g0[k][j], b0[k][j]);
             o.v[j] = Traits<T>::from_f32(rs[k] * (dh - a1[k] - yh * a2[k]));
           }
@@ -335,27 +357,27 @@ int geometry(int B, int HW, int C, int G, Geom& g) {
 }
 
 template <typename T, bool ACT, int NPT, int W>
-int launch_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float* stats, float* ws, int B, int HW,
-                 int C, int G, float eps, const Geom& g, hipStream_t s) {
+int launch_fwd_t(const void* x, const void* cbias, const void* gamma, const void* beta, void* y, float* stats, float* ws,
+                 int B, int HW, int C, int G, float eps, const Geom& g, hipStream_t s) {
   const float inv_n = 1.0f / ((float)HW * (float)(C / G));
-  hipLaunchKernelGGL((gn_stats_kernel<T, NPT, W>), dim3(g.NB, B), dim3(kThreads), g.lds, s, (const T*)x, ws, HW, C, G,
-                     g.PBs);
+  hipLaunchKernelGGL((gn_stats_kernel<T, NPT, W>), dim3(g.NB, B), dim3(kThreads), g.lds, s, (const T*)x,
+                     (const T*)cbias, ws, HW, C, G, g.PBs);
   hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(B), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, eps, stats);
   hipLaunchKernelGGL((gn_apply_kernel<T, ACT, NPT, W>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
-                     (const T*)gamma, (const T*)beta, (T*)y, stats, HW, C, G, g.PBa);
+                     (const T*)cbias, (const T*)gamma, (const T*)beta, (T*)y, stats, HW, C, G, g.PBa);
   return check_launch();
 }
 
 template <typename T, bool ACT, int NPT, int W>
-int launch_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta, const float* stats, void* dx,
-                 float* ws, int B, int HW, int C, int G, const Geom& g, hipStream_t s) {
+int launch_bwd_t(const void* x, const void* cbias, const void* dy, const void* gamma, const void* beta,
+                 const float* stats, void* dx, float* ws, int B, int HW, int C, int G, const Geom& g, hipStream_t s) {
   const float inv_n = 1.0f / ((float)HW * (float)(C / G));
   float* fin = ws + (size_t)B * kMaxNB * G * 2;  // [B][G][2] behind the partials
   hipLaunchKernelGGL((gn_bwd_stats_kernel<T, ACT, NPT, W>), dim3(g.NB, B), dim3(kThreads), g.lds, s, (const T*)x,
-                     (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, HW, C, G, g.PBs);
+                     (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, HW, C, G, g.PBs);
   hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(B), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, 0.0f, fin);
   hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT, NPT, W>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
-                     (const T*)dy, (const T*)gamma, (const T*)beta, stats, fin, (T*)dx, HW, C, G, g.PBa);
+                     (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, fin, (T*)dx, HW, C, G, g.PBa);
   return check_launch();
 }
 
@@ -383,53 +405,53 @@ int launch_bwd_t(const void* x, const void* dy, const void* gamma, const void* b
   }
 
 template <typename T>
-int fwd_dtype(const void* x, const void* gamma, const void* beta, void* y, float* stats, float* ws, int B, int HW, int C,
-              int G, float eps, int act, const Geom& g, hipStream_t s) {
+int fwd_dtype(const void* x, const void* cbias, const void* gamma, const void* beta, void* y, float* stats, float* ws, int B,
+              int HW, int C, int G, float eps, int act, const Geom& g, hipStream_t s) {
   if (act) {
-    GA_GN_NPT(launch_fwd_t, T, true, x, gamma, beta, y, stats, ws, B, HW, C, G, eps, g, s)
+    GA_GN_NPT(launch_fwd_t, T, true, x, cbias, gamma, beta, y, stats, ws, B, HW, C, G, eps, g, s)
   }
-  GA_GN_NPT(launch_fwd_t, T, false, x, gamma, beta, y, stats, ws, B, HW, C, G, eps, g, s)
+  GA_GN_NPT(launch_fwd_t, T, false, x, cbias, gamma, beta, y, stats, ws, B, HW, C, G, eps, g, s)
 }
 
 template <typename T>
-int bwd_dtype(const void* x, const void* dy, const void* gamma, const void* beta, const float* stats, void* dx,
-              float* ws, int B, int HW, int C, int G, int act, const Geom& g, hipStream_t s) {
+int bwd_dtype(const void* x, const void* cbias, const void* dy, const void* gamma, const void* beta, const float* stats,
+              void* dx, float* ws, int B, int HW, int C, int G, int act, const Geom& g, hipStream_t s) {
   if (act) {
-    GA_GN_NPT(launch_bwd_t, T, true, x, dy, gamma, beta, stats, dx, ws, B, HW, C, G, g, s)
+    GA_GN_NPT(launch_bwd_t, T, true, x, cbias, dy, gamma, beta, stats, dx, ws, B, HW, C, G, g, s)
   }
-  GA_GN_NPT(launch_bwd_t, T, false, x, dy, gamma, beta, stats, dx, ws, B, HW, C, G, g, s)
+  GA_GN_NPT(launch_bwd_t, T, false, x, cbias, dy, gamma, beta, stats, dx, ws, B, HW, C, G, g, s)
 }
 
 }  // namespace
 
-extern "C" int ga_group_norm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* stats,
-                                 float* workspace, int B, int HW, int C, int G, float eps, int act_silu, int dtype,
-                                 ga_stream_t stream) {
+extern "C" int ga_group_norm_fwd(const void* x, const void* chan_bias, const void* gamma, const void* beta, void* y,
+                                 float* stats, float* workspace, int B, int HW, int C, int G, float eps, int act_silu,
+                                 int dtype, ga_stream_t stream) {
   if (!x || !gamma || !beta || !y || !stats || !workspace) return GA_ERR_NULL;
   Geom g;
   int rc = geometry(B, HW, C, G, g);
   if (rc != GA_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case GA_F16: return fwd_dtype<_Float16>(x, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
-    case GA_BF16: return fwd_dtype<bf16_t>(x, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
-    case GA_F32: return fwd_dtype<float>(x, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
+    case GA_F16: return fwd_dtype<_Float16>(x, chan_bias, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
+    case GA_BF16: return fwd_dtype<bf16_t>(x, chan_bias, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
+    case GA_F32: return fwd_dtype<float>(x, chan_bias, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
     default: return GA_ERR_DTYPE;
   }
 }
 
-extern "C" int ga_group_norm_bwd(const void* x, const void* dy, const void* gamma, const void* beta,
-                                 const float* stats, void* dx, float* workspace, int B, int HW, int C, int G,
-                                 int act_silu, int dtype, ga_stream_t stream) {
+extern "C" int ga_group_norm_bwd(const void* x, const void* chan_bias, const void* dy, const void* gamma,
+                                 const void* beta, const float* stats, void* dx, float* workspace, int B, int HW, int C,
+                                 int G, int act_silu, int dtype, ga_stream_t stream) {
   if (!x || !dy || !gamma || !beta || !stats || !dx || !workspace) return GA_ERR_NULL;
   Geom g;
   int rc = geometry(B, HW, C, G, g);
   if (rc != GA_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case GA_F16: return bwd_dtype<_Float16>(x, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
-    case GA_BF16: return bwd_dtype<bf16_t>(x, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
-    case GA_F32: return bwd_dtype<float>(x, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
+    case GA_F16: return bwd_dtype<_Float16>(x, chan_bias, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
+    case GA_BF16: return bwd_dtype<bf16_t>(x, chan_bias, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
+    case GA_F32: return bwd_dtype<float>(x, chan_bias, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
     default: return GA_ERR_DTYPE;
   }
 }

@@ -75,16 +75,16 @@ def replay_launch_us(key, iters=100):
         stats = torch.empty(B, groups, 2, device=dev, dtype=torch.float32)
         ws = torch.empty(B * 257 * groups * 2, device=dev, dtype=torch.float32)
         code = dtype_code(x)
-        check(lib.ga_group_norm_fwd(_ptr(x), _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(ws), B, HW, C, groups, 1e-5,
-                                    int(flag), code, stream_ptr()), "replay gn")
+        check(lib.ga_group_norm_fwd(_ptr(x), None, _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(ws), B, HW, C, groups,
+                                    1e-5, int(flag), code, stream_ptr()), "replay gn")
         if kind == "group_norm_fwd":
             def fn():
-                check(lib.ga_group_norm_fwd(_ptr(x), _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(ws), B, HW, C, groups,
-                                            1e-5, int(flag), code, stream_ptr()), "replay gn fwd")
+                check(lib.ga_group_norm_fwd(_ptr(x), None, _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(ws), B, HW, C,
+                                            groups, 1e-5, int(flag), code, stream_ptr()), "replay gn fwd")
         else:
             def fn():
-                check(lib.ga_group_norm_bwd(_ptr(x), _ptr(dy), _ptr(w), _ptr(b_), _ptr(stats), _ptr(y), _ptr(ws), B, HW, C,
-                                            groups, int(flag), code, stream_ptr()), "replay gn bwd")
+                check(lib.ga_group_norm_bwd(_ptr(x), None, _ptr(dy), _ptr(w), _ptr(b_), _ptr(stats), _ptr(y), _ptr(ws), B,
+                                            HW, C, groups, int(flag), code, stream_ptr()), "replay gn bwd")
     else:
         q = torch.randn(B, N, H * D, device=dev, dtype=dtype)
         k = torch.randn(B, Kt, H * D, device=dev, dtype=dtype)
@@ -370,23 +370,30 @@ def _nhwc(x):
 
 
 class GroupNormAct(torch.autograd.Function):
-    """y = [silu](group_norm(x)) on channels-last (B, C, H, W) tensors; differentiable w.r.t. x only."""
+    """y = [silu](group_norm(x [+ chan_bias[:, :, None, None]])) on channels-last (B, C, H, W) tensors;
+    differentiable w.r.t. x only (chan_bias is the time-embedding term: it carries no gradient on this path)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, act):
-        require_cuda(x, weight, bias)
+    def forward(ctx, x, weight, bias, groups, eps, act, chan_bias):
+        require_cuda(x, weight, bias, chan_bias)
         if x.dim() != 4:
             raise GaError("GroupNormAct expects a (B, C, H, W) tensor")
         x = _nhwc(x)
         B, C, H, W = x.shape
+        if chan_bias is not None:
+            if chan_bias.requires_grad:
+                raise GaError("the channel bias of the fused GroupNorm carries no gradient on this path")
+            chan_bias = chan_bias.to(x.dtype).contiguous()
+            if tuple(chan_bias.shape) != (B, C):
+                raise GaError(f"chan_bias must be (B, C) = {(B, C)}, got {tuple(chan_bias.shape)}")
         y = torch.empty_like(x, memory_format=torch.channels_last)
         stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
         ws = torch.empty((B * 257 * groups * 2,), dtype=torch.float32, device=x.device)
         _count(("group_norm_fwd", B, groups, H * W, 0, C, bool(act), str(x.dtype)))
-        check(load().ga_group_norm_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(stats), _ptr(ws), B, H * W, C,
-                                       groups, float(eps), int(bool(act)), dtype_code(x), stream_ptr()),
+        check(load().ga_group_norm_fwd(_ptr(x), _ptr(chan_bias), _ptr(weight), _ptr(bias), _ptr(y), _ptr(stats), _ptr(ws),
+                                       B, H * W, C, groups, float(eps), int(bool(act)), dtype_code(x), stream_ptr()),
               "ga_group_norm_fwd")
-        ctx.save_for_backward(x, weight, bias, stats)
+        ctx.save_for_backward(x, weight, bias, stats, chan_bias)
         ctx.meta = (groups, bool(act))
         return y
 
@@ -394,20 +401,21 @@ class GroupNormAct(torch.autograd.Function):
     def backward(ctx, dy):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise GaError("GroupNorm weight gradients are not part of the guided-attention path (frozen UNet)")
-        x, weight, bias, stats = ctx.saved_tensors
+        x, weight, bias, stats, chan_bias = ctx.saved_tensors
         groups, act = ctx.meta
         B, C, H, W = x.shape
         dy = _nhwc(dy)
         dx = torch.empty_like(x, memory_format=torch.channels_last)
         ws = torch.empty((B * 257 * groups * 2,), dtype=torch.float32, device=x.device)
         _count(("group_norm_bwd", B, groups, H * W, 0, C, bool(act), str(x.dtype)))
-        check(load().ga_group_norm_bwd(_ptr(x), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(stats), _ptr(dx), _ptr(ws), B,
-                                       H * W, C, groups, int(act), dtype_code(x), stream_ptr()), "ga_group_norm_bwd")
-        return dx, None, None, None, None, None
+        check(load().ga_group_norm_bwd(_ptr(x), _ptr(chan_bias), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(stats), _ptr(dx),
+                                       _ptr(ws), B, H * W, C, groups, int(act), dtype_code(x), stream_ptr()),
+              "ga_group_norm_bwd")
+        return dx, None, None, None, None, None, None
 
 
-def group_norm_act(x, weight, bias, groups, eps, act):
-    return GroupNormAct.apply(x, weight, bias, groups, eps, act)
+def group_norm_act(x, weight, bias, groups, eps, act, chan_bias=None):
+    return GroupNormAct.apply(x, weight, bias, groups, eps, act, chan_bias)
 
 
 # --------------------------------------------------------------------------------------- tiled self-attention

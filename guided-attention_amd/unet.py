@@ -103,9 +103,12 @@ class GroupNormAct(nn.GroupNorm):
         self.act = act
         self.impl = None
 
-    def forward(self, x):
+    def forward(self, x, chan_bias=None):
+        """chan_bias (B, C), optional: normalise x + chan_bias[:, :, None, None] (folded into the kernels)."""
         if self.impl is not None:
-            return self.impl(x, self.weight, self.bias, self.num_groups, self.eps, self.act)
+            return self.impl(x, self.weight, self.bias, self.num_groups, self.eps, self.act, chan_bias)
+        if chan_bias is not None:
+            x = x + chan_bias[:, :, None, None]
         y = super().forward(x)
         return F.silu(y) if self.act else y
 
@@ -208,8 +211,7 @@ class ResnetBlock2D(nn.Module):
             tproj = temb_act[id(self)]
         else:
             tproj = self.time_emb_proj(temb_act) + self.conv1.bias
-        h = h + tproj[:, :, None, None]
-        h = self.conv2(self.norm2(h))
+        h = self.conv2(self.norm2(h, chan_bias=tproj))  # the time term is added inside the norm's loads
         if self.conv_shortcut is not None:
             _, _, hh, ww = x.shape
             x = tokens_to_nchw(pointwise_conv_tokens(nchw_to_tokens(x), self.conv_shortcut), hh, ww)

@@ -171,14 +171,17 @@ int ga_self_attn_bwd(const void* Q, const void* K, const void* V, const void* O,
  * pipeline_guided_attention.py:583-743 (diffusers 0.12.1 ResnetBlock2D / Transformer2DModel).
  *   x, y, dy, dx [B][HW][C] T (NHWC); gamma, beta [C] T; stats [B][G][2] f32 (mean, rstd), written by the
  *   forward and read by the backward; workspace GA_GN_WORKSPACE_FLOATS(B, G) f32 scratch.  C/G must be even, G <= 64,
- *   C <= 2560.  gamma/beta gradients are not produced (weights are frozen on this path).
+ *   C <= 2560.  chan_bias (optional, [B][C] T): the layer normalises x + chan_bias[b][c] — the ResnetBlock's
+ *   time-embedding term folded into the norm instead of a separate broadcast-add pass; it receives no gradient.
+ *   gamma/beta gradients are not produced (weights are frozen on this path).
  */
 #define GA_GN_WORKSPACE_FLOATS(B, G) ((B) * 257 * (G) * 2)
-int ga_group_norm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* stats, float* workspace,
-                      int B, int HW, int C, int G, float eps, int act_silu, int dtype, ga_stream_t stream);
-int ga_group_norm_bwd(const void* x, const void* dy, const void* gamma, const void* beta, const float* stats,
-                      void* dx, float* workspace, int B, int HW, int C, int G, int act_silu, int dtype,
+int ga_group_norm_fwd(const void* x, const void* chan_bias, const void* gamma, const void* beta, void* y, float* stats,
+                      float* workspace, int B, int HW, int C, int G, float eps, int act_silu, int dtype,
                       ga_stream_t stream);
+int ga_group_norm_bwd(const void* x, const void* chan_bias, const void* dy, const void* gamma, const void* beta,
+                      const float* stats, void* dx, float* workspace, int B, int HW, int C, int G, int act_silu,
+                      int dtype, ga_stream_t stream);
 
 #ifdef __cplusplus
 }

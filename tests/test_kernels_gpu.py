@@ -372,6 +372,18 @@ def test_group_norm_act(ops, shape, act, dt):
     stride_input = x.contiguous()  # NCHW input is accepted and converted
     y2 = ops.group_norm_act(stride_input, w, b, 32, 1e-5, act)
     assert torch.equal(y2, y.detach())
+    # per-(image, channel) bias folded into the norm == normalising x + bias
+    cb = dev(hashrand.normalish((B, C), 11) * 0.7, DT[dt])
+    xb = x.clone().requires_grad_(True)
+    y3 = ops.group_norm_act(xb, w, b, 32, 1e-5, act, cb)
+    y3.backward(g)
+    xr2 = (x.double().cpu() + cb.double().cpu()[:, :, None, None]).requires_grad_(True)
+    yr2 = torch.nn.functional.group_norm(xr2, 32, w.double().cpu(), b.double().cpu(), 1e-5)
+    if act:
+        yr2 = torch.nn.functional.silu(yr2)
+    yr2.backward(g.double().cpu())
+    close(y3, yr2.detach().numpy(), TOL[dt] * 2, "y with channel bias")
+    close(xb.grad, xr2.grad.numpy(), TOL[dt] * 3, "dx with channel bias")
 
 
 # ------------------------------------------------------------------------------------- tiled self-attention
