@@ -11,7 +11,7 @@
 // Backward recomputes the normalised value and the SiLU derivative, reduces (sum dyhat, sum dyhat*yhat) the same
 // way and writes dx; gamma/beta gradients are not produced (the UNet weights are frozen on this path).
 // HBM-bound: forward moves 2 reads + 1 write of the tensor (the second read hits L2/MALL at these sizes).
-#include "ga_common.h"
+#include "attn_common.h"
 
 using namespace ga;
 
@@ -336,6 +336,130 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
   }
 }
 
+// ---- small tensors (<= 256 pixels: the 16x16 and 8x8 levels): one launch, one workgroup per (image, group).
+// The group's slab (HW pixels x C/G channels, <= 20 480 elements) is read once into LDS while the sums are taken,
+// reduced in-block, then normalised from LDS: a single ~4 us latency chain instead of three launches.
+constexpr int kSmallMaxElems = 20480;
+
+__device__ __forceinline__ void block_sum2(float& a, float& c, float* red) {
+  a = wave_reduce_sum(a);
+  c = wave_reduce_sum(c);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[wave] = a;
+    red[4 + wave] = c;
+  }
+  __syncthreads();
+  a = (red[0] + red[1]) + (red[2] + red[3]);
+  c = (red[4] + red[5]) + (red[6] + red[7]);
+  __syncthreads();
+}
+
+template <typename T, bool ACT>
+__global__ __launch_bounds__(kThreads) void gn_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+                                                                const T* __restrict__ gamma,
+                                                                const T* __restrict__ beta, T* __restrict__ y,
+                                                                float* __restrict__ stats, int HW, int C, int G,
+                                                                float eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem_small[];
+  float* red = reinterpret_cast<float*>(smem_small);
+  float* slab = red + 8;  // [HW][Cg] f32: x + channel bias
+  const int g = blockIdx.x, b = blockIdx.y, Cg = C / G, hp = Cg >> 1, n2 = HW * hp;  // pairs
+  const Item<T, 2>* xb = reinterpret_cast<const Item<T, 2>*>(x + ((size_t)b * HW * C + (size_t)g * Cg));
+  const int rowp = C >> 1;  // pairs per pixel row of the tensor
+  float sa = 0.f, sc = 0.f;
+  for (int e = threadIdx.x; e < n2; e += kThreads) {
+    const int p = e / hp, j = e - p * hp;
+    const Item<T, 2> v = xb[(size_t)p * rowp + j];
+    float a0 = Traits<T>::to_f32(v.v[0]), a1 = Traits<T>::to_f32(v.v[1]);
+    if (cbias != nullptr) {
+      a0 += Traits<T>::to_f32(cbias[(size_t)b * C + g * Cg + 2 * j]);
+      a1 += Traits<T>::to_f32(cbias[(size_t)b * C + g * Cg + 2 * j + 1]);
+    }
+    slab[2 * e] = a0;
+    slab[2 * e + 1] = a1;
+    sa += a0 + a1;
+    sc += a0 * a0 + a1 * a1;
+  }
+  block_sum2(sa, sc, red);
+  const float inv_n = 1.0f / ((float)HW * (float)Cg);
+  const double mean_d = (double)sa * inv_n;
+  const float mean = (float)mean_d;
+  const float rstd = rsqrtf((float)fmax((double)sc * inv_n - mean_d * mean_d, 0.0) + eps);
+  if (threadIdx.x == 0) {
+    stats[((size_t)b * G + g) * 2] = mean;
+    stats[((size_t)b * G + g) * 2 + 1] = rstd;
+  }
+  Item<T, 2>* yb = reinterpret_cast<Item<T, 2>*>(y + ((size_t)b * HW * C + (size_t)g * Cg));
+  for (int e = threadIdx.x; e < n2; e += kThreads) {
+    const int p = e / hp, j = e - p * hp;
+    const int ch = g * Cg + 2 * j;
+    float z0 = (slab[2 * e] - mean) * rstd * Traits<T>::to_f32(gamma[ch]) + Traits<T>::to_f32(beta[ch]);
+    float z1 = (slab[2 * e + 1] - mean) * rstd * Traits<T>::to_f32(gamma[ch + 1]) + Traits<T>::to_f32(beta[ch + 1]);
+    if (ACT) {
+      z0 *= sigmoidf_(z0);
+      z1 *= sigmoidf_(z1);
+    }
+    Item<T, 2> o;
+    o.v[0] = Traits<T>::from_f32(z0);
+    o.v[1] = Traits<T>::from_f32(z1);
+    yb[(size_t)p * rowp + j] = o;
+  }
+}
+
+template <typename T, bool ACT>
+__global__ __launch_bounds__(kThreads) void gn_small_bwd_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+                                                                const T* __restrict__ dy,
+                                                                const T* __restrict__ gamma,
+                                                                const T* __restrict__ beta,
+                                                                const float* __restrict__ stats, T* __restrict__ dx,
+                                                                int HW, int C, int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem_small[];
+  float* red = reinterpret_cast<float*>(smem_small);
+  float* yh = red + 8;                     // [n] normalised values
+  const int g = blockIdx.x, b = blockIdx.y, Cg = C / G, hp = Cg >> 1, n2 = HW * hp;
+  float* dh = yh + 2 * n2;                 // [n] dL/dyhat
+  const size_t base = (size_t)b * HW * C + (size_t)g * Cg;
+  const Item<T, 2>* xb = reinterpret_cast<const Item<T, 2>*>(x + base);
+  const Item<T, 2>* db = reinterpret_cast<const Item<T, 2>*>(dy + base);
+  const int rowp = C >> 1;
+  const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
+  float s0 = 0.f, s1 = 0.f;
+  for (int e = threadIdx.x; e < n2; e += kThreads) {
+    const int p = e / hp, j = e - p * hp;
+    const int ch = g * Cg + 2 * j;
+    const Item<T, 2> v = xb[(size_t)p * rowp + j], d = db[(size_t)p * rowp + j];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float xv = Traits<T>::to_f32(v.v[t]);
+      if (cbias != nullptr) xv += Traits<T>::to_f32(cbias[(size_t)b * C + ch + t]);
+      const float yv = (xv - mean) * rstd;
+      const float dv = dyhat_of<ACT>(yv, Traits<T>::to_f32(d.v[t]), Traits<T>::to_f32(gamma[ch + t]),
+                                     Traits<T>::to_f32(beta[ch + t]));
+      yh[2 * e + t] = yv;
+      dh[2 * e + t] = dv;
+      s0 += dv;
+      s1 += dv * yv;
+    }
+  }
+  block_sum2(s0, s1, red);
+  const float inv_n = 1.0f / ((float)HW * (float)Cg);
+  const float m1 = s0 * inv_n, m2 = s1 * inv_n;
+  Item<T, 2>* ob = reinterpret_cast<Item<T, 2>*>(dx + base);
+  for (int e = threadIdx.x; e < n2; e += kThreads) {
+    const int p = e / hp, j = e - p * hp;
+    Item<T, 2> o;
+    o.v[0] = Traits<T>::from_f32(rstd * (dh[2 * e] - m1 - yh[2 * e] * m2));
+    o.v[1] = Traits<T>::from_f32(rstd * (dh[2 * e + 1] - m1 - yh[2 * e + 1] * m2));
+    ob[(size_t)p * rowp + j] = o;
+  }
+}
+
+bool small_path(int HW, int C, int G) {
+  const int Cg = C / G;
+  return HW <= 256 && (Cg & 1) == 0 && HW * Cg <= kSmallMaxElems;
+}
+
 struct Geom {
   int NB, PBs, NBa, PBa, NPT, W;
   size_t lds;
@@ -432,6 +556,32 @@ extern "C" int ga_group_norm_fwd(const void* x, const void* chan_bias, const voi
   int rc = geometry(B, HW, C, G, g);
   if (rc != GA_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (small_path(HW, C, G)) {
+    const size_t lds = sizeof(float) * (8 + (size_t)HW * (C / G));
+    const dim3 grid(G, B);
+#define GA_GN_SMALL(TT)                                                                                              \
+  do {                                                                                                              \
+    if (act_silu) {                                                                                                 \
+      auto k = gn_small_fwd_kernel<TT, true>;                                                                       \
+      if ((rc = set_dyn_lds(k, lds)) != GA_OK) return rc;                                                           \
+      hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, s, (const TT*)x, (const TT*)chan_bias, (const TT*)gamma,     \
+                         (const TT*)beta, (TT*)y, stats, HW, C, G, eps);                                            \
+    } else {                                                                                                        \
+      auto k = gn_small_fwd_kernel<TT, false>;                                                                      \
+      if ((rc = set_dyn_lds(k, lds)) != GA_OK) return rc;                                                           \
+      hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, s, (const TT*)x, (const TT*)chan_bias, (const TT*)gamma,     \
+                         (const TT*)beta, (TT*)y, stats, HW, C, G, eps);                                            \
+    }                                                                                                               \
+    return check_launch();                                                                                          \
+  } while (0)
+    switch (dtype) {
+      case GA_F16: GA_GN_SMALL(_Float16);
+      case GA_BF16: GA_GN_SMALL(bf16_t);
+      case GA_F32: GA_GN_SMALL(float);
+      default: return GA_ERR_DTYPE;
+    }
+#undef GA_GN_SMALL
+  }
   switch (dtype) {
     case GA_F16: return fwd_dtype<_Float16>(x, chan_bias, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
     case GA_BF16: return fwd_dtype<bf16_t>(x, chan_bias, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
@@ -448,6 +598,32 @@ extern "C" int ga_group_norm_bwd(const void* x, const void* chan_bias, const voi
   int rc = geometry(B, HW, C, G, g);
   if (rc != GA_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (small_path(HW, C, G)) {
+    const size_t lds = sizeof(float) * (8 + 2 * (size_t)HW * (C / G));
+    const dim3 grid(G, B);
+#define GA_GN_SMALL(TT)                                                                                              \
+  do {                                                                                                              \
+    if (act_silu) {                                                                                                 \
+      auto k = gn_small_bwd_kernel<TT, true>;                                                                       \
+      if ((rc = set_dyn_lds(k, lds)) != GA_OK) return rc;                                                           \
+      hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, s, (const TT*)x, (const TT*)chan_bias, (const TT*)dy,        \
+                         (const TT*)gamma, (const TT*)beta, stats, (TT*)dx, HW, C, G);                              \
+    } else {                                                                                                        \
+      auto k = gn_small_bwd_kernel<TT, false>;                                                                      \
+      if ((rc = set_dyn_lds(k, lds)) != GA_OK) return rc;                                                           \
+      hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, s, (const TT*)x, (const TT*)chan_bias, (const TT*)dy,        \
+                         (const TT*)gamma, (const TT*)beta, stats, (TT*)dx, HW, C, G);                              \
+    }                                                                                                               \
+    return check_launch();                                                                                          \
+  } while (0)
+    switch (dtype) {
+      case GA_F16: GA_GN_SMALL(_Float16);
+      case GA_BF16: GA_GN_SMALL(bf16_t);
+      case GA_F32: GA_GN_SMALL(float);
+      default: return GA_ERR_DTYPE;
+    }
+#undef GA_GN_SMALL
+  }
   switch (dtype) {
     case GA_F16: return bwd_dtype<_Float16>(x, chan_bias, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
     case GA_BF16: return bwd_dtype<bf16_t>(x, chan_bias, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
