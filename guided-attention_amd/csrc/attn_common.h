@@ -45,6 +45,8 @@ __device__ __forceinline__ void load_row_frags(const T* __restrict__ xrow, bool 
 
 // Raise a kernel's dynamic-LDS limit above the 64 KB default; remembered per kernel so that the runtime call
 // happens on the first (eager, warm-up) launch only and never inside a stream capture.
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+
 template <typename KernelT>
 inline int set_dyn_lds(KernelT kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return GA_OK;
@@ -54,9 +56,11 @@ inline int set_dyn_lds(KernelT kernel, size_t bytes) {
   std::lock_guard<std::mutex> lock(mu);
   auto it = granted.find(fn);
   if (it != granted.end() && it->second >= bytes) return GA_OK;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (bytes > kMaxLdsBytes) return GA_ERR_SHAPE;
+  // ask for the whole 160 KB once, so that a later, larger shape never needs a second runtime call mid-capture
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes);
   if (e != hipSuccess) return GA_ERR_LAUNCH;
-  granted[fn] = bytes;
+  granted[fn] = kMaxLdsBytes;
   return GA_OK;
 }
 

@@ -341,47 +341,60 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
 // reduced in-block, then normalised from LDS: a single ~4 us latency chain instead of three launches.
 constexpr int kSmallMaxElems = 20480;
 
+template <int NT>
 __device__ __forceinline__ void block_sum2(float& a, float& c, float* red) {
+  constexpr int NW = NT / 64;
   a = wave_reduce_sum(a);
   c = wave_reduce_sum(c);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     red[wave] = a;
-    red[4 + wave] = c;
+    red[NW + wave] = c;
   }
   __syncthreads();
-  a = (red[0] + red[1]) + (red[2] + red[3]);
-  c = (red[4] + red[5]) + (red[6] + red[7]);
+  float ta = 0.f, tc = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    ta += red[w];
+    tc += red[NW + w];
+  }
+  a = ta;
+  c = tc;
   __syncthreads();
 }
 
-template <typename T, bool ACT>
-__global__ __launch_bounds__(kThreads) void gn_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
-                                                                const T* __restrict__ gamma,
-                                                                const T* __restrict__ beta, T* __restrict__ y,
-                                                                float* __restrict__ stats, int HW, int C, int G,
-                                                                float eps) {
+// Thread t owns channel pair j = t % (Cg/2) of the group for pixels p0, p0 + rows, ... (rows = NT / (Cg/2)), so the
+// per-channel gamma / beta / bias are loaded once and the loops carry no integer division.
+template <typename T, bool ACT, int NT>
+__global__ __launch_bounds__(NT) void gn_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+                                                          const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                          T* __restrict__ y, float* __restrict__ stats, int HW,
+                                                          int C, int G, float eps) {
   extern __shared__ __attribute__((aligned(16))) char smem_small[];
   float* red = reinterpret_cast<float*>(smem_small);
-  float* slab = red + 8;  // [HW][Cg] f32: x + channel bias
-  const int g = blockIdx.x, b = blockIdx.y, Cg = C / G, hp = Cg >> 1, n2 = HW * hp;  // pairs
-  const Item<T, 2>* xb = reinterpret_cast<const Item<T, 2>*>(x + ((size_t)b * HW * C + (size_t)g * Cg));
-  const int rowp = C >> 1;  // pairs per pixel row of the tensor
-  float sa = 0.f, sc = 0.f;
-  for (int e = threadIdx.x; e < n2; e += kThreads) {
-    const int p = e / hp, j = e - p * hp;
-    const Item<T, 2> v = xb[(size_t)p * rowp + j];
-    float a0 = Traits<T>::to_f32(v.v[0]), a1 = Traits<T>::to_f32(v.v[1]);
-    if (cbias != nullptr) {
-      a0 += Traits<T>::to_f32(cbias[(size_t)b * C + g * Cg + 2 * j]);
-      a1 += Traits<T>::to_f32(cbias[(size_t)b * C + g * Cg + 2 * j + 1]);
-    }
-    slab[2 * e] = a0;
-    slab[2 * e + 1] = a1;
-    sa += a0 + a1;
-    sc += a0 * a0 + a1 * a1;
+  float2* slab = reinterpret_cast<float2*>(red + 32);  // [HW][Cg/2]: x + channel bias
+  const int g = blockIdx.x, b = blockIdx.y, Cg = C / G, hp = Cg >> 1;
+  const int rows = NT / hp, p0 = threadIdx.x / hp, j = threadIdx.x - p0 * hp;
+  const bool active = p0 < rows;
+  const int ch = g * Cg + 2 * j;
+  const size_t base = (size_t)b * HW * C + ch;
+  float cb0 = 0.f, cb1 = 0.f;
+  if (active && cbias != nullptr) {
+    cb0 = Traits<T>::to_f32(cbias[(size_t)b * C + ch]);
+    cb1 = Traits<T>::to_f32(cbias[(size_t)b * C + ch + 1]);
   }
-  block_sum2(sa, sc, red);
+  float sa = 0.f, sc = 0.f;
+  if (active) {
+#pragma unroll 4
+    for (int p = p0; p < HW; p += rows) {
+      const Item<T, 2> v = *reinterpret_cast<const Item<T, 2>*>(x + base + (size_t)p * C);
+      const float a0 = Traits<T>::to_f32(v.v[0]) + cb0, a1 = Traits<T>::to_f32(v.v[1]) + cb1;
+      slab[p * hp + j] = make_float2(a0, a1);
+      sa += a0 + a1;
+      sc += a0 * a0 + a1 * a1;
+    }
+  }
+  block_sum2<NT>(sa, sc, red);
   const float inv_n = 1.0f / ((float)HW * (float)Cg);
   const double mean_d = (double)sa * inv_n;
   const float mean = (float)mean_d;
@@ -390,12 +403,13 @@ __global__ __launch_bounds__(kThreads) void gn_small_fwd_kernel(const T* __restr
     stats[((size_t)b * G + g) * 2] = mean;
     stats[((size_t)b * G + g) * 2 + 1] = rstd;
   }
-  Item<T, 2>* yb = reinterpret_cast<Item<T, 2>*>(y + ((size_t)b * HW * C + (size_t)g * Cg));
-  for (int e = threadIdx.x; e < n2; e += kThreads) {
-    const int p = e / hp, j = e - p * hp;
-    const int ch = g * Cg + 2 * j;
-    float z0 = (slab[2 * e] - mean) * rstd * Traits<T>::to_f32(gamma[ch]) + Traits<T>::to_f32(beta[ch]);
-    float z1 = (slab[2 * e + 1] - mean) * rstd * Traits<T>::to_f32(gamma[ch + 1]) + Traits<T>::to_f32(beta[ch + 1]);
+  if (!active) return;
+  const float g0 = Traits<T>::to_f32(gamma[ch]) * rstd, g1 = Traits<T>::to_f32(gamma[ch + 1]) * rstd;
+  const float b0 = Traits<T>::to_f32(beta[ch]) - mean * g0, b1 = Traits<T>::to_f32(beta[ch + 1]) - mean * g1;
+#pragma unroll 4
+  for (int p = p0; p < HW; p += rows) {
+    const float2 a = slab[p * hp + j];
+    float z0 = a.x * g0 + b0, z1 = a.y * g1 + b1;
     if (ACT) {
       z0 *= sigmoidf_(z0);
       z1 *= sigmoidf_(z1);
@@ -403,62 +417,121 @@ __global__ __launch_bounds__(kThreads) void gn_small_fwd_kernel(const T* __restr
     Item<T, 2> o;
     o.v[0] = Traits<T>::from_f32(z0);
     o.v[1] = Traits<T>::from_f32(z1);
-    yb[(size_t)p * rowp + j] = o;
+    *reinterpret_cast<Item<T, 2>*>(y + base + (size_t)p * C) = o;
   }
 }
 
-template <typename T, bool ACT>
-__global__ __launch_bounds__(kThreads) void gn_small_bwd_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
-                                                                const T* __restrict__ dy,
-                                                                const T* __restrict__ gamma,
-                                                                const T* __restrict__ beta,
-                                                                const float* __restrict__ stats, T* __restrict__ dx,
-                                                                int HW, int C, int G) {
+template <typename T, bool ACT, int NT>
+__global__ __launch_bounds__(NT) void gn_small_bwd_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+                                                          const T* __restrict__ dy, const T* __restrict__ gamma,
+                                                          const T* __restrict__ beta,
+                                                          const float* __restrict__ stats, T* __restrict__ dx,
+                                                          int HW, int C, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem_small[];
   float* red = reinterpret_cast<float*>(smem_small);
-  float* yh = red + 8;                     // [n] normalised values
-  const int g = blockIdx.x, b = blockIdx.y, Cg = C / G, hp = Cg >> 1, n2 = HW * hp;
-  float* dh = yh + 2 * n2;                 // [n] dL/dyhat
-  const size_t base = (size_t)b * HW * C + (size_t)g * Cg;
-  const Item<T, 2>* xb = reinterpret_cast<const Item<T, 2>*>(x + base);
-  const Item<T, 2>* db = reinterpret_cast<const Item<T, 2>*>(dy + base);
-  const int rowp = C >> 1;
+  float2* dh = reinterpret_cast<float2*>(red + 32);  // [HW][Cg/2] dL/dyhat
+  const int g = blockIdx.x, b = blockIdx.y, Cg = C / G, hp = Cg >> 1;
+  Item<T, 2>* xs = reinterpret_cast<Item<T, 2>*>(dh + HW * hp);  // [HW][Cg/2] x as read (yhat is recomputed)
+  const int rows = NT / hp, p0 = threadIdx.x / hp, j = threadIdx.x - p0 * hp;
+  const bool active = p0 < rows;
+  const int ch = g * Cg + 2 * j;
+  const size_t base = (size_t)b * HW * C + ch;
   const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
-  float s0 = 0.f, s1 = 0.f;
-  for (int e = threadIdx.x; e < n2; e += kThreads) {
-    const int p = e / hp, j = e - p * hp;
-    const int ch = g * Cg + 2 * j;
-    const Item<T, 2> v = xb[(size_t)p * rowp + j], d = db[(size_t)p * rowp + j];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float xv = Traits<T>::to_f32(v.v[t]);
-      if (cbias != nullptr) xv += Traits<T>::to_f32(cbias[(size_t)b * C + ch + t]);
-      const float yv = (xv - mean) * rstd;
-      const float dv = dyhat_of<ACT>(yv, Traits<T>::to_f32(d.v[t]), Traits<T>::to_f32(gamma[ch + t]),
-                                     Traits<T>::to_f32(beta[ch + t]));
-      yh[2 * e + t] = yv;
-      dh[2 * e + t] = dv;
-      s0 += dv;
-      s1 += dv * yv;
+  float s0 = 0.f, s1 = 0.f, cb0 = 0.f, cb1 = 0.f;
+  if (active) {
+    if (cbias != nullptr) {
+      cb0 = Traits<T>::to_f32(cbias[(size_t)b * C + ch]);
+      cb1 = Traits<T>::to_f32(cbias[(size_t)b * C + ch + 1]);
+    }
+    cb0 -= mean;
+    cb1 -= mean;
+    const float g0 = Traits<T>::to_f32(gamma[ch]), g1 = Traits<T>::to_f32(gamma[ch + 1]);
+    const float b0 = Traits<T>::to_f32(beta[ch]), b1 = Traits<T>::to_f32(beta[ch + 1]);
+#pragma unroll 4
+    for (int p = p0; p < HW; p += rows) {
+      const Item<T, 2> v = *reinterpret_cast<const Item<T, 2>*>(x + base + (size_t)p * C);
+      const Item<T, 2> d = *reinterpret_cast<const Item<T, 2>*>(dy + base + (size_t)p * C);
+      const float y0 = (Traits<T>::to_f32(v.v[0]) + cb0) * rstd;
+      const float y1 = (Traits<T>::to_f32(v.v[1]) + cb1) * rstd;
+      const float d0 = dyhat_of<ACT>(y0, Traits<T>::to_f32(d.v[0]), g0, b0);
+      const float d1 = dyhat_of<ACT>(y1, Traits<T>::to_f32(d.v[1]), g1, b1);
+      dh[p * hp + j] = make_float2(d0, d1);
+      xs[p * hp + j] = v;
+      s0 += d0 + d1;
+      s1 += d0 * y0 + d1 * y1;
     }
   }
-  block_sum2(s0, s1, red);
+  block_sum2<NT>(s0, s1, red);
+  if (!active) return;
   const float inv_n = 1.0f / ((float)HW * (float)Cg);
   const float m1 = s0 * inv_n, m2 = s1 * inv_n;
-  Item<T, 2>* ob = reinterpret_cast<Item<T, 2>*>(dx + base);
-  for (int e = threadIdx.x; e < n2; e += kThreads) {
-    const int p = e / hp, j = e - p * hp;
+#pragma unroll 4
+  for (int p = p0; p < HW; p += rows) {
+    const float2 a = dh[p * hp + j];
+    const Item<T, 2> v = xs[p * hp + j];
+    const float y0 = (Traits<T>::to_f32(v.v[0]) + cb0) * rstd;
+    const float y1 = (Traits<T>::to_f32(v.v[1]) + cb1) * rstd;
     Item<T, 2> o;
-    o.v[0] = Traits<T>::from_f32(rstd * (dh[2 * e] - m1 - yh[2 * e] * m2));
-    o.v[1] = Traits<T>::from_f32(rstd * (dh[2 * e + 1] - m1 - yh[2 * e + 1] * m2));
-    ob[(size_t)p * rowp + j] = o;
+    o.v[0] = Traits<T>::from_f32(rstd * (a.x - m1 - y0 * m2));
+    o.v[1] = Traits<T>::from_f32(rstd * (a.y - m1 - y1 * m2));
+    *reinterpret_cast<Item<T, 2>*>(dx + base + (size_t)p * C) = o;
   }
 }
 
-bool small_path(int HW, int C, int G) {
-  const int Cg = C / G;
-  return HW <= 256 && (Cg & 1) == 0 && HW * Cg <= kSmallMaxElems;
+constexpr size_t kSmallHeader = 32 * sizeof(float);
+inline bool small_wide(int HW, int C, int G) { return (C / G) / 2 > 256 || HW * ((C / G) / 2) >= 2048; }
+
+template <typename T, bool ACT, int NT>
+int small_fwd_launch(const void* x, const void* cb, const void* gamma, const void* beta, void* y, float* stats, int B,
+                     int HW, int C, int G, float eps, hipStream_t s) {
+  const size_t lds = kSmallHeader + sizeof(float) * (size_t)HW * (C / G);
+  auto k = gn_small_fwd_kernel<T, ACT, NT>;
+  const int rc = set_dyn_lds(k, lds);
+  if (rc != GA_OK) return rc;
+  hipLaunchKernelGGL(k, dim3(G, B), dim3(NT), lds, s, (const T*)x, (const T*)cb, (const T*)gamma, (const T*)beta,
+                     (T*)y, stats, HW, C, G, eps);
+  return check_launch();
 }
+
+template <typename T>
+int small_fwd(const void* x, const void* cb, const void* gamma, const void* beta, void* y, float* stats, int B, int HW,
+              int C, int G, float eps, int act, hipStream_t s) {
+  if (small_wide(HW, C, G))
+    return act ? small_fwd_launch<T, true, 1024>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s)
+               : small_fwd_launch<T, false, 1024>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
+  return act ? small_fwd_launch<T, true, 256>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s)
+             : small_fwd_launch<T, false, 256>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
+}
+
+template <typename T, bool ACT, int NT>
+int small_bwd_launch(const void* x, const void* cb, const void* dy, const void* gamma, const void* beta,
+                     const float* stats, void* dx, int B, int HW, int C, int G, hipStream_t s) {
+  const size_t lds = kSmallHeader + (sizeof(float) + sizeof(T)) * (size_t)HW * (C / G);
+  auto k = gn_small_bwd_kernel<T, ACT, NT>;
+  const int rc = set_dyn_lds(k, lds);
+  if (rc != GA_OK) return rc;
+  hipLaunchKernelGGL(k, dim3(G, B), dim3(NT), lds, s, (const T*)x, (const T*)cb, (const T*)dy, (const T*)gamma,
+                     (const T*)beta, stats, (T*)dx, HW, C, G);
+  return check_launch();
+}
+
+template <typename T>
+int small_bwd(const void* x, const void* cb, const void* dy, const void* gamma, const void* beta, const float* stats,
+              void* dx, int B, int HW, int C, int G, int act, hipStream_t s) {
+  if (small_wide(HW, C, G))
+    return act ? small_bwd_launch<T, true, 1024>(x, cb, dy, gamma, beta, stats, dx, B, HW, C, G, s)
+               : small_bwd_launch<T, false, 1024>(x, cb, dy, gamma, beta, stats, dx, B, HW, C, G, s);
+  return act ? small_bwd_launch<T, true, 256>(x, cb, dy, gamma, beta, stats, dx, B, HW, C, G, s)
+             : small_bwd_launch<T, false, 256>(x, cb, dy, gamma, beta, stats, dx, B, HW, C, G, s);
+}
+
+bool small_path(int HW, int C, int G, size_t slab_bytes_per_elem) {
+  const int Cg = C / G;
+  return HW <= 256 && (Cg & 1) == 0 && Cg <= 2048 && HW * Cg <= kSmallMaxElems &&
+         kSmallHeader + slab_bytes_per_elem * (size_t)HW * Cg <= kMaxLdsBytes;
+}
+
+inline size_t elem_bytes(int dtype) { return dtype == GA_F32 ? 4 : 2; }
 
 struct Geom {
   int NB, PBs, NBa, PBa, NPT, W;
@@ -556,31 +629,13 @@ extern "C" int ga_group_norm_fwd(const void* x, const void* chan_bias, const voi
   int rc = geometry(B, HW, C, G, g);
   if (rc != GA_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (small_path(HW, C, G)) {
-    const size_t lds = sizeof(float) * (8 + (size_t)HW * (C / G));
-    const dim3 grid(G, B);
-#define GA_GN_SMALL(TT)                                                                                              \
-  do {                                                                                                              \
-    if (act_silu) {                                                                                                 \
-      auto k = gn_small_fwd_kernel<TT, true>;                                                                       \
-      if ((rc = set_dyn_lds(k, lds)) != GA_OK) return rc;                                                           \
-      hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, s, (const TT*)x, (const TT*)chan_bias, (const TT*)gamma,     \
-                         (const TT*)beta, (TT*)y, stats, HW, C, G, eps);                                            \
-    } else {                                                                                                        \
-      auto k = gn_small_fwd_kernel<TT, false>;                                                                      \
-      if ((rc = set_dyn_lds(k, lds)) != GA_OK) return rc;                                                           \
-      hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, s, (const TT*)x, (const TT*)chan_bias, (const TT*)gamma,     \
-                         (const TT*)beta, (TT*)y, stats, HW, C, G, eps);                                            \
-    }                                                                                                               \
-    return check_launch();                                                                                          \
-  } while (0)
+  if (small_path(HW, C, G, sizeof(float))) {
     switch (dtype) {
-      case GA_F16: GA_GN_SMALL(_Float16);
-      case GA_BF16: GA_GN_SMALL(bf16_t);
-      case GA_F32: GA_GN_SMALL(float);
+      case GA_F16: return small_fwd<_Float16>(x, chan_bias, gamma, beta, y, stats, B, HW, C, G, eps, act_silu, s);
+      case GA_BF16: return small_fwd<bf16_t>(x, chan_bias, gamma, beta, y, stats, B, HW, C, G, eps, act_silu, s);
+      case GA_F32: return small_fwd<float>(x, chan_bias, gamma, beta, y, stats, B, HW, C, G, eps, act_silu, s);
       default: return GA_ERR_DTYPE;
     }
-#undef GA_GN_SMALL
   }
   switch (dtype) {
     case GA_F16: return fwd_dtype<_Float16>(x, chan_bias, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
@@ -598,31 +653,13 @@ extern "C" int ga_group_norm_bwd(const void* x, const void* chan_bias, const voi
   int rc = geometry(B, HW, C, G, g);
   if (rc != GA_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (small_path(HW, C, G)) {
-    const size_t lds = sizeof(float) * (8 + 2 * (size_t)HW * (C / G));
-    const dim3 grid(G, B);
-#define GA_GN_SMALL(TT)                                                                                              \
-  do {                                                                                                              \
-    if (act_silu) {                                                                                                 \
-      auto k = gn_small_bwd_kernel<TT, true>;                                                                       \
-      if ((rc = set_dyn_lds(k, lds)) != GA_OK) return rc;                                                           \
-      hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, s, (const TT*)x, (const TT*)chan_bias, (const TT*)dy,        \
-                         (const TT*)gamma, (const TT*)beta, stats, (TT*)dx, HW, C, G);                              \
-    } else {                                                                                                        \
-      auto k = gn_small_bwd_kernel<TT, false>;                                                                      \
-      if ((rc = set_dyn_lds(k, lds)) != GA_OK) return rc;                                                           \
-      hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, s, (const TT*)x, (const TT*)chan_bias, (const TT*)dy,        \
-                         (const TT*)gamma, (const TT*)beta, stats, (TT*)dx, HW, C, G);                              \
-    }                                                                                                               \
-    return check_launch();                                                                                          \
-  } while (0)
+  if (small_path(HW, C, G, sizeof(float) + elem_bytes(dtype))) {
     switch (dtype) {
-      case GA_F16: GA_GN_SMALL(_Float16);
-      case GA_BF16: GA_GN_SMALL(bf16_t);
-      case GA_F32: GA_GN_SMALL(float);
+      case GA_F16: return small_bwd<_Float16>(x, chan_bias, dy, gamma, beta, stats, dx, B, HW, C, G, act_silu, s);
+      case GA_BF16: return small_bwd<bf16_t>(x, chan_bias, dy, gamma, beta, stats, dx, B, HW, C, G, act_silu, s);
+      case GA_F32: return small_bwd<float>(x, chan_bias, dy, gamma, beta, stats, dx, B, HW, C, G, act_silu, s);
       default: return GA_ERR_DTYPE;
     }
-#undef GA_GN_SMALL
   }
   switch (dtype) {
     case GA_F16: return bwd_dtype<_Float16>(x, chan_bias, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
