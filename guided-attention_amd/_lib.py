@@ -55,6 +55,9 @@ PROTOTYPES = {
     "ga_self_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ga_group_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ga_group_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ga_geglu_fwd": [_vp, _vp, _i64, _i, _i, _vp],
+    "ga_geglu_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
+    "ga_bias_residual_add": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
 }
 
 _lib = None

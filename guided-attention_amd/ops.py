@@ -418,6 +418,62 @@ def group_norm_act(x, weight, bias, groups, eps, act, chan_bias=None):
     return GroupNormAct.apply(x, weight, bias, groups, eps, act, chan_bias)
 
 
+# --------------------------------------------------------------------------------------- feed-forward / residual epilogues
+class Geglu(torch.autograd.Function):
+    """y = x[..., :F] * gelu(x[..., F:]) on the GEGLU projection's output (diffusers 0.12.1 GEGLU.forward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        require_cuda(x)
+        x = x.contiguous()
+        F2 = x.shape[-1]
+        rows = x.numel() // F2
+        y = torch.empty(x.shape[:-1] + (F2 // 2,), dtype=x.dtype, device=x.device)
+        check(load().ga_geglu_fwd(_ptr(x), _ptr(y), rows, F2 // 2, dtype_code(x), stream_ptr()), "ga_geglu_fwd")
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        F2 = x.shape[-1]
+        dx = torch.empty_like(x)
+        check(load().ga_geglu_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.numel() // F2, F2 // 2, dtype_code(x), stream_ptr()),
+              "ga_geglu_bwd")
+        return dx
+
+
+def geglu(x):
+    return Geglu.apply(x)
+
+
+class BiasResidualAdd(torch.autograd.Function):
+    """out = y + bias[c] + residual on channels-last activations (ResnetBlock2D: conv2's bias and the skip
+    connection in one pass).  bias receives no gradient (frozen UNet)."""
+
+    @staticmethod
+    def forward(ctx, y, bias, residual):
+        require_cuda(y, residual)
+        if ctx.needs_input_grad[1]:
+            raise GaError("bias gradients are not part of the guided-attention path (frozen UNet)")
+        y, residual = _nhwc(y), _nhwc(residual)
+        B, C, H, W = y.shape
+        out = torch.empty_like(y, memory_format=torch.channels_last)
+        check(load().ga_bias_residual_add(_ptr(y), _ptr(bias), _ptr(residual), _ptr(out), B * H * W, C, dtype_code(y),
+                                          stream_ptr()), "ga_bias_residual_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, g
+
+
+def bias_residual_add(y, bias, residual):
+    return BiasResidualAdd.apply(y, bias, residual)
+
+
 # --------------------------------------------------------------------------------------- tiled self-attention
 def _sub_ptr(t, elem_offset):
     return ctypes.c_void_p(t.data_ptr() + elem_offset * t.element_size())

@@ -134,8 +134,13 @@ class GEGLU(nn.Module):
         super().__init__()
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
+    impl = None  # fused h * gelu(gate) (ops.geglu), installed by UNet2DConditionModel.set_fused_impl
+
     def forward(self, x):
-        h, gate = self.proj(x).chunk(2, dim=-1)
+        x = self.proj(x)
+        if self.impl is not None and x.shape[-1] % 16 == 0:
+            return self.impl(x)
+        h, gate = x.chunk(2, dim=-1)
         return h * F.gelu(gate)
 
 
@@ -201,6 +206,8 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
+    add_impl = None  # fused conv2-bias + residual add (ops.bias_residual_add)
+
     def forward(self, x, temb_act):
         """temb_act = SiLU(time embedding), computed once per UNet forward; or the dict the UNet prepared with this
         block's time_emb_proj(temb_act) already evaluated (all blocks in one GEMM)."""
@@ -211,11 +218,14 @@ class ResnetBlock2D(nn.Module):
             tproj = temb_act[id(self)]
         else:
             tproj = self.time_emb_proj(temb_act) + self.conv1.bias
-        h = self.conv2(self.norm2(h, chan_bias=tproj))  # the time term is added inside the norm's loads
+        h = self.norm2(h, chan_bias=tproj)  # the time term is added inside the norm's loads
         if self.conv_shortcut is not None:
             _, _, hh, ww = x.shape
             x = tokens_to_nchw(pointwise_conv_tokens(nchw_to_tokens(x), self.conv_shortcut), hh, ww)
-        return x + h
+        if self.add_impl is not None and self.conv2.out_channels % 8 == 0:
+            # conv2's bias and the skip connection in one pass (the library conv adds its bias as a separate kernel)
+            return self.add_impl(F.conv2d(h, self.conv2.weight, None, padding=1), self.conv2.bias, x)
+        return x + self.conv2(h)
 
 
 class Downsample2D(nn.Module):
@@ -408,6 +418,14 @@ class UNet2DConditionModel(nn.Module):
         for m in self.modules():
             if isinstance(m, GroupNormAct):
                 m.impl = impl
+
+    def set_fused_impl(self, geglu=None, bias_residual_add=None):
+        """Install (or with None remove) the fused element-wise epilogues: GEGLU and conv-bias + residual."""
+        for m in self.modules():
+            if isinstance(m, GEGLU):
+                m.impl = geglu
+            elif isinstance(m, ResnetBlock2D):
+                m.add_impl = bias_residual_add
 
     @property
     def dtype(self):

@@ -183,6 +183,21 @@ int ga_group_norm_bwd(const void* x, const void* chan_bias, const void* dy, cons
                       const float* stats, void* dx, float* workspace, int B, int HW, int C, int G, int act_silu,
                       int dtype, ga_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * UNet host helpers: element-wise epilogues of the transformer feed-forward and the ResnetBlock (diffusers 0.12.1
+ * GEGLU.forward / ResnetBlock2D.forward, run by the reference inside pipeline_guided_attention.py:583-743).
+ *   ga_geglu_fwd : x [rows][2F] T (the GEGLU projection output: h = x[:, :F], gate = x[:, F:]) -> y [rows][F] T,
+ *                  y = h * gelu(gate), exact (erf) GELU evaluated in f32.
+ *   ga_geglu_bwd : dx [rows][2F] = (dy * gelu(gate) | dy * h * gelu'(gate)).
+ *   ga_bias_residual_add : out = y + bias[c] + residual, rows x C, bias [C] optional (NULL); out may alias y or
+ *                  residual.
+ * F (C) must be a multiple of 16 / sizeof(T); pointers 16-byte aligned.
+ */
+int ga_geglu_fwd(const void* x, void* y, int64_t rows, int F, int dtype, ga_stream_t stream);
+int ga_geglu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int F, int dtype, ga_stream_t stream);
+int ga_bias_residual_add(const void* y, const void* bias, const void* residual, void* out, int64_t rows, int C,
+                         int dtype, ga_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

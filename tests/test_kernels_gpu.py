@@ -386,6 +386,45 @@ def test_group_norm_act(ops, shape, act, dt):
     close(xb.grad, xr2.grad.numpy(), TOL[dt] * 3, "dx with channel bias")
 
 
+# ------------------------------------------------------------------------------------- GEGLU, bias + residual
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 4096, 1280), (2, 256, 5120), (1, 64, 5120), (3, 7, 64), (1, 1, 16)])
+def test_geglu(ops, shape, dt):
+    """y = h * gelu(gate) and its gradient vs PyTorch's chunk / gelu / mul in fp64 on the CPU."""
+    B, N, F = shape
+    x = dev(hashrand.normalish((B, N, 2 * F), 21 + F) * 1.5, DT[dt])
+    g = dev(hashrand.normalish((B, N, F), 22 + F), DT[dt])
+    xa = x.clone().requires_grad_(True)
+    y = ops.geglu(xa)
+    y.backward(g)
+    xr = x.double().cpu().requires_grad_(True)
+    h, gate = xr.chunk(2, dim=-1)
+    yr = h * torch.nn.functional.gelu(gate)
+    yr.backward(g.double().cpu())
+    close(y, yr.detach().numpy(), TOL[dt], "geglu")
+    close(xa.grad, xr.grad.numpy(), TOL[dt] * 2, "geglu dx")
+    with pytest.raises(Exception):
+        ops.geglu(dev(hashrand.normalish((2, 6), 1), DT[dt]))  # F = 3: not a whole 16-byte vector
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 320, 64, 64), (2, 1280, 8, 8), (1, 64, 3, 5), (1, 8, 1, 1)])
+def test_bias_residual_add(ops, shape, dt):
+    B, C, H, W = shape
+    y = dev(hashrand.normalish(shape, 31 + C), DT[dt]).contiguous(memory_format=torch.channels_last)
+    r = dev(hashrand.normalish(shape, 32 + C), DT[dt])  # NCHW input is accepted and converted
+    bias = dev(hashrand.normalish((C,), 33), DT[dt])
+    ya, ra = y.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    out = ops.bias_residual_add(ya, bias, ra)
+    assert out.is_contiguous(memory_format=torch.channels_last)
+    ref = y.double().cpu() + bias.double().cpu()[None, :, None, None] + r.double().cpu()
+    close(out, ref.numpy(), TOL[dt], "y + bias + residual")
+    close(ops.bias_residual_add(y, None, r), (y.double().cpu() + r.double().cpu()).numpy(), TOL[dt], "no bias")
+    g = dev(hashrand.normalish(shape, 34), DT[dt])
+    out.backward(g)
+    assert torch.equal(ya.grad, g) and torch.equal(ra.grad, g)
+
+
 # ------------------------------------------------------------------------------------- tiled self-attention
 SA_SHAPES = [  # B, H, N, D
     (1, 8, 4096, 40), (1, 8, 1024, 80), (1, 8, 256, 160), (1, 8, 64, 160), (2, 8, 1024, 80),  # SD-1.x layers
