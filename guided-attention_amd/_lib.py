@@ -58,6 +58,8 @@ PROTOTYPES = {
     "ga_geglu_fwd": [_vp, _vp, _i64, _i, _i, _vp],
     "ga_geglu_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "ga_bias_residual_add": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "ga_add_layer_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp],
+    "ga_add_layer_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
 }
 
 _lib = None

@@ -474,6 +474,82 @@ def bias_residual_add(y, bias, residual):
     return BiasResidualAdd.apply(y, bias, residual)
 
 
+def _ln_fwd(a, x, weight, bias, eps, need_stats):
+    require_cuda(x, weight, bias)
+    x = x.contiguous()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device) if need_stats else None
+    xnew = None
+    if a is not None:
+        a = a.contiguous()
+        xnew = torch.empty_like(x)
+    check(load().ga_add_layer_norm_fwd(_ptr(a), _ptr(x), _ptr(weight), _ptr(bias), _ptr(xnew), _ptr(y), _ptr(stats), rows,
+                                       C, float(eps), dtype_code(x), stream_ptr()), "ga_add_layer_norm_fwd")
+    return (x if a is None else xnew), y, stats
+
+
+def _ln_bwd(row, stats, weight, g_y, g_res):
+    C = row.shape[-1]
+    g_y = g_y.contiguous()
+    g_res = g_res.contiguous() if g_res is not None else None
+    d = torch.empty_like(row)
+    check(load().ga_add_layer_norm_bwd(_ptr(row), _ptr(stats), _ptr(weight), _ptr(g_y), _ptr(g_res), _ptr(d),
+                                       row.numel() // C, C, dtype_code(row), stream_ptr()), "ga_add_layer_norm_bwd")
+    return d
+
+
+def _frozen(ctx, first):
+    if ctx.needs_input_grad[first] or ctx.needs_input_grad[first + 1]:
+        raise GaError("LayerNorm weight gradients are not part of the guided-attention path (frozen UNet)")
+
+
+class LayerNorm(torch.autograd.Function):
+    """y = LayerNorm(x) over the last dimension (one wave per row)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _frozen(ctx, 1)
+        row, y, stats = _ln_fwd(None, x, weight, bias, eps, ctx.needs_input_grad[0])
+        if stats is not None:
+            ctx.save_for_backward(row, stats, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        row, stats, weight = ctx.saved_tensors
+        return _ln_bwd(row, stats, weight, g_y, None), None, None, None
+
+
+class AddLayerNorm(torch.autograd.Function):
+    """(x_new, y) = (a + x, LayerNorm(a + x)).  The backward folds the gradient arriving at x_new from its other
+    consumer (the next residual add) into the same launch."""
+
+    @staticmethod
+    def forward(ctx, a, x, weight, bias, eps):
+        _frozen(ctx, 2)
+        xnew, y, stats = _ln_fwd(a, x, weight, bias, eps, ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        if stats is not None:
+            ctx.save_for_backward(xnew, stats, weight)
+        return xnew, y
+
+    @staticmethod
+    def backward(ctx, g_xnew, g_y):
+        xnew, stats, weight = ctx.saved_tensors
+        d = g_xnew if g_y is None else _ln_bwd(xnew, stats, weight, g_y, g_xnew)
+        return d, d, None, None, None
+
+
+def layer_norm(x, weight, bias, eps):
+    return LayerNorm.apply(x, weight, bias, eps)
+
+
+def add_layer_norm(a, x, weight, bias, eps):
+    """-> (a + x, LayerNorm(a + x))"""
+    return AddLayerNorm.apply(a, x, weight, bias, eps)
+
+
 # --------------------------------------------------------------------------------------- tiled self-attention
 def _sub_ptr(t, elem_offset):
     return ctypes.c_void_p(t.data_ptr() + elem_offset * t.element_size())

@@ -114,7 +114,7 @@ class GuidedAttention:
             # transposes) and the fused NHWC GroupNorm(+SiLU) HIP kernels in every norm layer
             self.unet.to(memory_format=torch.channels_last)
             self.unet.set_norm_impl(ops.group_norm_act)
-            self.unet.set_fused_impl(ops.geglu, ops.bias_residual_add)
+            self.unet.set_fused_impl(ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm))
             torch.backends.cudnn.benchmark = True  # MIOpen: benchmark the candidate conv kernels once per shape
         return self
 

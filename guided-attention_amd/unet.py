@@ -165,7 +165,16 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.ff = FeedForward(dim)
 
+    ln_impl = None  # (layer_norm, add_layer_norm) from ops: residual add + next LayerNorm in one launch
+
     def forward(self, x, context):
+        if self.ln_impl is not None and x.shape[-1] % 8 == 0:
+            ln, add_ln = self.ln_impl
+            h = self.attn1(ln(x, self.norm1.weight, self.norm1.bias, self.norm1.eps))
+            x, n = add_ln(h, x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            h = self.attn2(n, encoder_hidden_states=context)
+            x, n = add_ln(h, x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+            return self.ff(n) + x
         x = self.attn1(self.norm1(x)) + x
         x = self.attn2(self.norm2(x), encoder_hidden_states=context) + x
         return self.ff(self.norm3(x)) + x
@@ -419,13 +428,16 @@ class UNet2DConditionModel(nn.Module):
             if isinstance(m, GroupNormAct):
                 m.impl = impl
 
-    def set_fused_impl(self, geglu=None, bias_residual_add=None):
-        """Install (or with None remove) the fused element-wise epilogues: GEGLU and conv-bias + residual."""
+    def set_fused_impl(self, geglu=None, bias_residual_add=None, layer_norms=None):
+        """Install (or with None remove) the fused element-wise epilogues: GEGLU, conv-bias + residual, and
+        (layer_norm, add_layer_norm) for the transformer blocks."""
         for m in self.modules():
             if isinstance(m, GEGLU):
                 m.impl = geglu
             elif isinstance(m, ResnetBlock2D):
                 m.add_impl = bias_residual_add
+            elif isinstance(m, BasicTransformerBlock):
+                m.ln_impl = layer_norms
 
     @property
     def dtype(self):

@@ -198,6 +198,19 @@ int ga_geglu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int F, i
 int ga_bias_residual_add(const void* y, const void* bias, const void* residual, void* out, int64_t rows, int C,
                          int dtype, ga_stream_t stream);
 
+/* Residual add + LayerNorm (diffusers 0.12.1 BasicTransformerBlock.forward: x = attn(norm(x)) + x; norm_next(x)):
+ *   fwd: x_new = a + x (rounded to T), y = LayerNorm(x_new) * gamma + beta, stats [rows][2] f32 = (mean, rstd).
+ *        a == NULL: plain LayerNorm of x (x_new is not written and may be NULL).  stats may be NULL (inference).
+ *   bwd: dx = LayerNorm-backward(dy; x, stats, gamma) + g_res, where x is the row the forward normalised (x_new, or x
+ *        in the plain mode) and g_res (optional) is the gradient arriving at x_new from its other consumer — the
+ *        accumulation autograd would run as a separate add.  gamma / beta gradients are not produced (frozen UNet).
+ * rows x C row-major, C a multiple of 16 / sizeof(T), C <= 4096 (f32: 2048); pointers 16-byte aligned.
+ */
+int ga_add_layer_norm_fwd(const void* a, const void* x, const void* gamma, const void* beta, void* x_new, void* y,
+                          float* stats, int64_t rows, int C, float eps, int dtype, ga_stream_t stream);
+int ga_add_layer_norm_bwd(const void* x, const float* stats, const void* gamma, const void* dy, const void* g_res,
+                          void* dx, int64_t rows, int C, int dtype, ga_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

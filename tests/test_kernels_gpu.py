@@ -425,6 +425,43 @@ def test_bias_residual_add(ops, shape, dt):
     assert torch.equal(ya.grad, g) and torch.equal(ra.grad, g)
 
 
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 4096, 320), (2, 1024, 640), (1, 256, 1280), (2, 64, 1280), (3, 5, 64), (1, 1, 8),
+                                   (1, 3, 2048)])
+def test_add_layer_norm(ops, shape, dt):
+    """(a + x, LayerNorm(a + x)) and the plain LayerNorm, forward and backward, vs PyTorch in fp64 on the CPU
+    (the reference sum is rounded to the storage type first, as the separate add kernel would)."""
+    B, N, C = shape
+    a = dev(hashrand.normalish(shape, 41 + C) * 0.7, DT[dt])
+    x = dev(hashrand.normalish(shape, 42 + C) * 1.3 + 0.2, DT[dt])
+    w = dev(hashrand.normalish((C,), 43) * 0.4 + 1.0, DT[dt])
+    b = dev(hashrand.normalish((C,), 44) * 0.2, DT[dt])
+    gy = dev(hashrand.normalish(shape, 45), DT[dt])
+    gx = dev(hashrand.normalish(shape, 46), DT[dt])
+    aa, xa = a.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    xnew, y = ops.add_layer_norm(aa, xa, w, b, 1e-5)
+    assert torch.equal(xnew.detach(), a + x)
+    torch.autograd.backward([xnew, y], [gx, gy])
+    sr = (a + x).double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(sr, (C,), w.double().cpu(), b.double().cpu(), 1e-5)
+    torch.autograd.backward([sr * 1.0, yr], [gx.double().cpu(), gy.double().cpu()])
+    close(y, yr.detach().numpy(), TOL[dt] * 2, "y")
+    close(aa.grad, sr.grad.numpy(), TOL[dt] * 3, "d a")
+    assert torch.equal(aa.grad, xa.grad)
+    # plain mode
+    xp = x.clone().requires_grad_(True)
+    yp = ops.layer_norm(xp, w, b, 1e-5)
+    yp.backward(gy)
+    xr = x.double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (C,), w.double().cpu(), b.double().cpu(), 1e-5)
+    yr.backward(gy.double().cpu())
+    close(yp, yr.detach().numpy(), TOL[dt] * 2, "plain y")
+    close(xp.grad, xr.grad.numpy(), TOL[dt] * 3, "plain dx")
+    # inference: no statistics kept
+    with torch.no_grad():
+        assert torch.equal(ops.layer_norm(x, w, b, 1e-5), yp.detach())
+
+
 # ------------------------------------------------------------------------------------- tiled self-attention
 SA_SHAPES = [  # B, H, N, D
     (1, 8, 4096, 40), (1, 8, 1024, 80), (1, 8, 256, 160), (1, 8, 64, 160), (2, 8, 1024, 80),  # SD-1.x layers
