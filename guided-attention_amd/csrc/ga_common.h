@@ -10,6 +10,8 @@ namespace ga {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct bf16_t {
   uint16_t bits;
@@ -37,6 +39,13 @@ struct Traits<_Float16> {
   __device__ static __forceinline__ f32x4 mma16(frag a, frag b, f32x4 acc) {
     return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc, 0, 0, 0);
   }
+  // two k-chunks in one v_mfma_f32_16x16x32_f16 (same cycles as ONE 16x16x16 on gfx950, measured): lane g's
+  // eight k-values are chunk 0's 4g..4g+3 followed by chunk 1's 4g..4g+3 — any k order works as long as A and B agree
+  __device__ static __forceinline__ f32x4 mma16x2(frag a0, frag a1, frag b0, frag b1, f32x4 acc) {
+    const f16x8 a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const f16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+  }
 };
 
 template <>
@@ -56,6 +65,14 @@ struct Traits<bf16_t> {
     s16x4 bv = {(short)b.v[0].bits, (short)b.v[1].bits, (short)b.v[2].bits, (short)b.v[3].bits};
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc, 0, 0, 0);
   }
+  __device__ static __forceinline__ f32x4 mma16x2(frag a0, frag a1, frag b0, frag b1, f32x4 acc) {
+    struct Pair {
+      frag lo, hi;
+    };
+    const bf16x8 a = __builtin_bit_cast(bf16x8, Pair{a0, a1});
+    const bf16x8 b = __builtin_bit_cast(bf16x8, Pair{b0, b1});
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  }
 };
 
 template <>
@@ -73,6 +90,9 @@ struct Traits<float> {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
     return acc;
+  }
+  __device__ static __forceinline__ f32x4 mma16x2(frag a0, frag a1, frag b0, frag b1, f32x4 acc) {
+    return mma16(a1, b1, mma16(a0, b0, acc));
   }
 };
 

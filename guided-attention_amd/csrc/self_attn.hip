@@ -93,6 +93,16 @@ struct Stage {
       }
     }
   }
+  template <int STRIDE>
+  __device__ __forceinline__ void store_rows(T* img) const {  // row-major image with an explicit row stride
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int idx = u * kThreads + threadIdx.x;
+      if (idx >= TOTAL) continue;
+      const int r = idx / VPR, d = (idx - r * VPR) * VEC;
+      *reinterpret_cast<uint4*>(img + r * STRIDE + d) = v[u];
+    }
+  }
   __device__ __forceinline__ void store(T* rowmaj, T* transposed) const {
     constexpr int KS = DP + VEC;
 #pragma unroll
@@ -117,35 +127,94 @@ __host__ __device__ constexpr int tr_img() {
   return NK * 16 * TL<T, KT>::VS + TL<T, KT>::ROT * (NK * 16 / TL<T, KT>::VEC);
 }
 
+// 16-bit tiles whose rows are the contraction index of a product (V in P.V, K in dS.K, Q / dO in the dK / dV sums)
+// stay ROW-major in LDS and are read with gfx950's transposing ds_read_b64_tr_b16: no second, transposed image, no
+// 2-byte scatter stores.  Row stride TRS = DP rounded up to an odd multiple of 16 elements (8 dwords): the 8 rows x
+// 8 dwords a 32-lane half touches per read then tile the 64 banks exactly.
+template <int NK>
+__host__ __device__ constexpr int trs() { return NK * 16 + ((NK & 1) ? 0 : 16); }
+template <typename T>
+constexpr bool kTrRead = sizeof(T) == 2;
+
+template <typename T>
+__device__ __forceinline__ typename Traits<T>::frag tr_read(const T* p) {
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  return __builtin_bit_cast(typename Traits<T>::frag, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p));
+}
+
 // acc[rb][cb] += Img[rb*16 + .][:] . X[cb][:]   (rows of the LDS image on accumulator rows, this lane's column
-// fragments X in registers);  NRB row blocks of 16, CB column blocks
+// fragments X in registers);  NRB row blocks of 16, CB column blocks.  k-chunks go through the MFMA in pairs
+// (16x16x32: twice the work of a 16x16x16 in the same cycles).
 template <typename T, int NK, int NRB, int CB>
 __device__ __forceinline__ void rows_times_cols(const T* img, const typename Traits<T>::frag (&x)[CB][NK], int c, int g,
                                                 f32x4 (&acc)[NRB][CB]) {
   constexpr int KS = NK * 16 + TileLds<T, 64>::VEC;
 #pragma unroll
-  for (int rb = 0; rb < NRB; ++rb)
+  for (int rb = 0; rb < NRB; ++rb) {
+    const T* row = img + (rb * 16 + c) * KS + 4 * g;
 #pragma unroll
-    for (int kc = 0; kc < NK; ++kc) {
-      const typename Traits<T>::frag a = load_frag<T>(img + (rb * 16 + c) * KS + kc * 16 + 4 * g);
+    for (int kc = 0; kc + 1 < NK; kc += 2) {
+      const typename Traits<T>::frag a0 = load_frag<T>(row + kc * 16), a1 = load_frag<T>(row + kc * 16 + 16);
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = Traits<T>::mma16(a, x[cb][kc], acc[rb][cb]);
+      for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = Traits<T>::mma16x2(a0, a1, x[cb][kc], x[cb][kc + 1], acc[rb][cb]);
     }
+    if (NK & 1) {
+      // odd chunk: the same 16x16x32 with a zero upper half (costs what a 16x16x16 costs).  Do NOT chain a legacy
+      // v_mfma_f32_16x16x16_f16 onto a 16x16x32's accumulator: hipcc (ROCm 7.2) emits the pair back-to-back without
+      // the wait states the differing pass counts need, and the second MFMA reads a stale SrcC (wrong results).
+      const typename Traits<T>::frag a = load_frag<T>(row + (NK - 1) * 16), z = zero_frag<T>();
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        if constexpr (sizeof(T) == 2) acc[rb][cb] = Traits<T>::mma16x2(a, z, x[cb][NK - 1], z, acc[rb][cb]);
+        else acc[rb][cb] = Traits<T>::mma16(a, x[cb][NK - 1], acc[rb][cb]);
+      }
+    }
+  }
 }
 
-// out[dt][cb] += ImgT[dt*16 + .][rows] . F[rb][cb]   (transposed image rows = feature d; contraction over the 64
+// out[dt][cb] += ImgT[dt*16 + .][rows] . F[rb][cb]   (transposed image rows = feature d; contraction over the
 // tile rows; F = accumulator tiles converted to operand fragments)
 template <typename T, int NK, int NRB, int CB>
 __device__ __forceinline__ void featT_times_frags(const T* imgT, const typename Traits<T>::frag (&f)[NRB][CB], int c,
                                                   int g, f32x4 (&out)[NK][CB]) {
+  static_assert(NRB % 2 == 0, "row blocks are consumed in pairs");
+#pragma unroll
+  for (int dt = 0; dt < NK; ++dt) {
+    const T* row = imgT + TL<T, NRB * 16>::tr(dt * 16 + c) + 4 * g;
+#pragma unroll
+    for (int rb = 0; rb < NRB; rb += 2) {
+      const typename Traits<T>::frag a0 = load_frag<T>(row + rb * 16), a1 = load_frag<T>(row + rb * 16 + 16);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) out[dt][cb] = Traits<T>::mma16x2(a0, a1, f[rb][cb], f[rb + 1][cb], out[dt][cb]);
+    }
+  }
+}
+
+// The same product from a ROW-major [tile row][TRS] image through the transposing read (16-bit types): lane
+// 16 grp + 4 q + p addresses row 4 grp + q of the 16-row block, columns 4p..4p+3 of the 16-feature block, and
+// receives feature (lane & 15) of rows 4 grp .. 4 grp + 3 — the A fragment of the MFMA.  EXEC must be all ones.
+template <typename T, int NK, int NRB, int CB>
+__device__ __forceinline__ void rowsT_times_frags(const T* img, const typename Traits<T>::frag (&f)[NRB][CB], int lane,
+                                                  f32x4 (&out)[NK][CB]) {
+  static_assert(NRB % 2 == 0, "row blocks are consumed in pairs");
+  constexpr int S = trs<NK>();
+  const int i = lane & 15;
+  const T* base = img + (4 * (lane >> 4) + (i >> 2)) * S + 4 * (i & 3);
 #pragma unroll
   for (int dt = 0; dt < NK; ++dt)
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) {
-      const typename Traits<T>::frag a = load_frag<T>(imgT + TL<T, NRB * 16>::tr(dt * 16 + c) + rb * 16 + 4 * g);
+    for (int rb = 0; rb < NRB; rb += 2) {
+      const typename Traits<T>::frag a0 = tr_read<T>(base + rb * 16 * S + dt * 16);
+      const typename Traits<T>::frag a1 = tr_read<T>(base + (rb + 1) * 16 * S + dt * 16);
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) out[dt][cb] = Traits<T>::mma16(a, f[rb][cb], out[dt][cb]);
+      for (int cb = 0; cb < CB; ++cb) out[dt][cb] = Traits<T>::mma16x2(a0, a1, f[rb][cb], f[rb + 1][cb], out[dt][cb]);
     }
+}
+
+// elements of the image that feeds rowsT / featT products
+template <typename T, int NK, int KT>
+__host__ __device__ constexpr int col_img() {
+  return kTrRead<T> ? KT * trs<NK>() : tr_img<T, NK, KT>();
 }
 
 template <typename T, int NK, int CB>
@@ -229,7 +298,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
   // one buffer = [K row-major | V transposed]; buffers are addressed as base + cur * kBuf so that the compiler
   // keeps the LDS address space (a local array of pointers decays to generic pointers -> flat_load + vmcnt(0))
   T* const lds = reinterpret_cast<T*>(smem);
-  constexpr int kBuf = NBUF == 2 ? row_img<T, NK, KT>() + tr_img<T, NK, KT>() : 0;
+  constexpr int kBuf = NBUF == 2 ? row_img<T, NK, KT>() + col_img<T, NK, KT>() : 0;
   constexpr int kVoff = row_img<T, NK, KT>();
 
   const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
@@ -251,7 +320,8 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
   sk.load(0, N, rs);
   sv.load(0, N, rs);
   sk.store(lds, nullptr);
-  sv.store(nullptr, lds + kVoff);
+  if constexpr (kTrRead<T>) sv.template store_rows<trs<NK>()>(lds + kVoff);
+  else sv.store(nullptr, lds + kVoff);
   __syncthreads();
 
   f32x4 o[NK][QB];
@@ -316,12 +386,14 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[dt][qb][r] *= alpha;
     }
-    featT_times_frags<T, NK, KT / 16, QB>(vimg, pf, c, g, o);
+    if constexpr (kTrRead<T>) rowsT_times_frags<T, NK, KT / 16, QB>(vimg, pf, lane, o);
+    else featT_times_frags<T, NK, KT / 16, QB>(vimg, pf, c, g, o);
     if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before it is overwritten
     if (kt + 1 < ntiles) {
       T* nxt = lds + (cur ^ 1) * kBuf;
       sk.store(nxt, nullptr);
-      sv.store(nullptr, nxt + kVoff);
+      if constexpr (kTrRead<T>) sv.template store_rows<trs<NK>()>(nxt + kVoff);
+      else sv.store(nullptr, nxt + kVoff);
     }
     __syncthreads();
   }
@@ -602,7 +674,7 @@ struct Bufs {
   static constexpr int value = (sizeof(T) == 2 && NK <= 5) ? 2 : 1;
 };
 template <typename T, int NK, int KT>
-size_t fwd_lds() { return sizeof(T) * Bufs<T, NK>::value * (row_img<T, NK, KT>() + tr_img<T, NK, KT>()); }
+size_t fwd_lds() { return sizeof(T) * Bufs<T, NK>::value * (row_img<T, NK, KT>() + col_img<T, NK, KT>()); }
 template <typename T, int NK, int KT>
 size_t dq_lds() { return sizeof(T) * Bufs<T, NK>::value * (2 * row_img<T, NK, KT>() + tr_img<T, NK, KT>()); }
 template <typename T, int NK, int KT>
