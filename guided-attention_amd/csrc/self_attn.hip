@@ -217,6 +217,25 @@ __host__ __device__ constexpr int col_img() {
   return kTrRead<T> ? KT * trs<NK>() : tr_img<T, NK, KT>();
 }
 
+// stage one tile into the image read by rows (may be null) and the image read by columns
+template <typename T, int NK, int KT, bool PRE>
+__device__ __forceinline__ void store_tile(const Stage<T, NK, KT, PRE>& st, T* row_image, T* col_image) {
+  if constexpr (kTrRead<T>) {
+    if (row_image) st.store(row_image, nullptr);
+    st.template store_rows<trs<NK>()>(col_image);
+  } else {
+    st.store(row_image, col_image);
+  }
+}
+
+// out[dt][cb] += (tile rows as the contraction index) ^T . F[rb][cb], from whichever column image the type uses
+template <typename T, int NK, int NRB, int CB>
+__device__ __forceinline__ void tileT_times_frags(const T* col_image, const typename Traits<T>::frag (&f)[NRB][CB],
+                                                  int lane, f32x4 (&out)[NK][CB]) {
+  if constexpr (kTrRead<T>) rowsT_times_frags<T, NK, NRB, CB>(col_image, f, lane, out);
+  else featT_times_frags<T, NK, NRB, CB>(col_image, f, lane & 15, lane >> 4, out);
+}
+
 template <typename T, int NK, int CB>
 __device__ __forceinline__ void load_col_frags(const T* __restrict__ base, size_t row_stride, int row0, int N, int D,
                                                int c, int g, typename Traits<T>::frag (&x)[CB][NK]) {
@@ -320,8 +339,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
   sk.load(0, N, rs);
   sv.load(0, N, rs);
   sk.store(lds, nullptr);
-  if constexpr (kTrRead<T>) sv.template store_rows<trs<NK>()>(lds + kVoff);
-  else sv.store(nullptr, lds + kVoff);
+  store_tile<T, NK, KT, true>(sv, nullptr, lds + kVoff);
   __syncthreads();
 
   f32x4 o[NK][QB];
@@ -386,14 +404,12 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[dt][qb][r] *= alpha;
     }
-    if constexpr (kTrRead<T>) rowsT_times_frags<T, NK, KT / 16, QB>(vimg, pf, lane, o);
-    else featT_times_frags<T, NK, KT / 16, QB>(vimg, pf, c, g, o);
+    tileT_times_frags<T, NK, KT / 16, QB>(vimg, pf, lane, o);
     if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before it is overwritten
     if (kt + 1 < ntiles) {
       T* nxt = lds + (cur ^ 1) * kBuf;
       sk.store(nxt, nullptr);
-      if constexpr (kTrRead<T>) sv.template store_rows<trs<NK>()>(nxt + kVoff);
-      else sv.store(nullptr, nxt + kVoff);
+      store_tile<T, NK, KT, true>(sv, nullptr, nxt + kVoff);
     }
     __syncthreads();
   }
@@ -437,10 +453,10 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
                                                                     int ldq, float scale) {
   using Tr = Traits<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // one buffer = [K row-major | V row-major | K transposed]
+  // one buffer = [K row-major | V row-major | K column image (transposed, or row-major for the transposing read)]
   T* const lds = reinterpret_cast<T*>(smem);
   constexpr int kVoff = row_img<T, NK, KT>(), kToff = 2 * row_img<T, NK, KT>();
-  constexpr int kBuf = NBUF == 2 ? 2 * row_img<T, NK, KT>() + tr_img<T, NK, KT>() : 0;
+  constexpr int kBuf = NBUF == 2 ? 2 * row_img<T, NK, KT>() + col_img<T, NK, KT>() : 0;
   const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq, rso = (size_t)H * D;
@@ -464,7 +480,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
   sv.init(V + off, D, rs);
   sk.load(0, N, rs);
   sv.load(0, N, rs);
-  sk.store(lds, lds + kToff);
+  store_tile<T, NK, KT, false>(sk, lds, lds + kToff);
   sv.store(lds + kVoff, nullptr);
   __syncthreads();
 
@@ -521,11 +537,11 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r) dsf[kb][qb][r] = Tr::from_f32(s[kb][qb][r] * f);
     }
-    featT_times_frags<T, NK, KT / 16, QB>(buf + kToff, dsf, c, g, acc);
+    tileT_times_frags<T, NK, KT / 16, QB>(buf + kToff, dsf, lane, acc);
     if (NBUF == 1) __syncthreads();
     if (kt + 1 < ntiles) {
       T* nxt = lds + (cur ^ 1) * kBuf;
-      sk.store(nxt, nxt + kToff);
+      store_tile<T, NK, KT, false>(sk, nxt, nxt + kToff);
       sv.store(nxt + kVoff, nullptr);
     }
     __syncthreads();
@@ -548,10 +564,10 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
                                                                       int N, int D, int nkt, int ldq, float scale) {
   using Tr = Traits<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // one buffer = [Q row-major | Q transposed | dO row-major | dO transposed]; then the per-query LSE / delta rows
+  // one buffer = [Q row-major | Q column image | dO row-major | dO column image]; then the per-query LSE / delta rows
   T* const lds = reinterpret_cast<T*>(smem);
-  constexpr int kQt = row_img<T, NK, KT>(), kDr = kQt + tr_img<T, NK, KT>(), kDt = kDr + row_img<T, NK, KT>();
-  constexpr int kOne = 2 * row_img<T, NK, KT>() + 2 * tr_img<T, NK, KT>();
+  constexpr int kQt = row_img<T, NK, KT>(), kDr = kQt + col_img<T, NK, KT>(), kDt = kDr + row_img<T, NK, KT>();
+  constexpr int kOne = 2 * row_img<T, NK, KT>() + 2 * col_img<T, NK, KT>();
   constexpr int kBuf = NBUF == 2 ? kOne : 0;
   float* const stats = reinterpret_cast<float*>(lds + NBUF * kOne);  // [2][2][KT]: (LSE, delta) per buffer
   constexpr int kSbuf = 2 * KT;
@@ -582,8 +598,8 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
   sq.load(0, N, rs);
   sd.load(0, N, rso);
   load_stats(0);
-  sq.store(lds, lds + kQt);
-  sd.store(lds + kDr, lds + kDt);
+  store_tile<T, NK, KT, false>(sq, lds, lds + kQt);
+  store_tile<T, NK, KT, false>(sd, lds + kDr, lds + kDt);
   if (threadIdx.x < KT) {
     stats[threadIdx.x] = pl;
     stats[KT + threadIdx.x] = pd;
@@ -642,13 +658,13 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
 #pragma unroll
         for (int r = 0; r < 4; ++r) dsf[qb][kb][r] = Tr::from_f32(s[qb][kb][r] * f);
     }
-    featT_times_frags<T, NK, KT / 16, KB>(buf + kDt, pf, c, g, dv);  // dV^T += dO^T P
-    featT_times_frags<T, NK, KT / 16, KB>(buf + kQt, dsf, c, g, dk);  // dK^T += Q^T dS
+    tileT_times_frags<T, NK, KT / 16, KB>(buf + kDt, pf, lane, dv);  // dV^T += dO^T P
+    tileT_times_frags<T, NK, KT / 16, KB>(buf + kQt, dsf, lane, dk);  // dK^T += Q^T dS
     if (NBUF == 1) __syncthreads();
     if (qt + 1 < ntiles) {
       T* nxt = lds + (cur ^ 1) * kBuf;
-      sq.store(nxt, nxt + kQt);
-      sd.store(nxt + kDr, nxt + kDt);
+      store_tile<T, NK, KT, false>(sq, nxt, nxt + kQt);
+      store_tile<T, NK, KT, false>(sd, nxt + kDr, nxt + kDt);
       if (threadIdx.x < KT) {
         stats[(cur ^ 1) * kSbuf + threadIdx.x] = pl;
         stats[(cur ^ 1) * kSbuf + KT + threadIdx.x] = pd;
@@ -676,10 +692,10 @@ struct Bufs {
 template <typename T, int NK, int KT>
 size_t fwd_lds() { return sizeof(T) * Bufs<T, NK>::value * (row_img<T, NK, KT>() + col_img<T, NK, KT>()); }
 template <typename T, int NK, int KT>
-size_t dq_lds() { return sizeof(T) * Bufs<T, NK>::value * (2 * row_img<T, NK, KT>() + tr_img<T, NK, KT>()); }
+size_t dq_lds() { return sizeof(T) * Bufs<T, NK>::value * (2 * row_img<T, NK, KT>() + col_img<T, NK, KT>()); }
 template <typename T, int NK, int KT>
 size_t dkdv_lds() {
-  return sizeof(T) * Bufs<T, NK>::value * (2 * row_img<T, NK, KT>() + 2 * tr_img<T, NK, KT>()) + sizeof(float) * 4 * KT;
+  return sizeof(T) * Bufs<T, NK>::value * (2 * row_img<T, NK, KT>() + 2 * col_img<T, NK, KT>()) + sizeof(float) * 4 * KT;
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;
