@@ -18,6 +18,8 @@
 // layout: no LDS round trip between chained MFMAs.  Tensors stay in the projection layout [B][N][H][D].
 // Workgroup ids run head-fastest so that, with 8 heads and round-robin XCD dispatch, the workgroups that sweep one
 // head's K/V share an XCD L2.   MFMA-bound for N >= 1024 (4 N^2 D flops per head forward), latency-bound below.
+#include <stdlib.h>
+
 #include "attn_common.h"
 
 using namespace ga;
@@ -52,7 +54,7 @@ struct Stage {
     if (PRE) {
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
-        const int idx = u * kThreads + threadIdx.x;
+        const int idx = u * kThreads + (threadIdx.x & (kThreads - 1));
         const int r = idx / VPR, d = (idx - r * VPR) * VEC;
         const bool live = idx < TOTAL && d < D;
         row[u < NP ? u : 0] = live ? r : -1;
@@ -66,12 +68,15 @@ struct Stage {
   __device__ __forceinline__ void load(int row0, int N, size_t row_stride) {
     if (PRE) {
       const size_t adv = (size_t)row0 * row_stride;
-      if (row0 + KT <= N) {  // full tile: unconditional loads, idle lanes zeroed by a select
+      if (row0 + KT <= N) {
+        // full tile: unconditional loads (idle lanes re-read their clamped address) and NOTHING that consumes the
+        // data here — a select on the loaded value in this block makes the compiler wait for the load on the spot
+        // (s_waitcnt vmcnt(0) before the tile's math: the prefetch is then no prefetch).  Idle lanes are zeroed
+        // when the registers go to LDS, after the math.
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
           const int i = u < NP ? u : 0;
-          const uint4 x = *reinterpret_cast<const uint4*>(gp[i] + (row[i] >= 0 ? adv : 0));
-          v[u] = row[i] >= 0 ? x : uint4{0, 0, 0, 0};
+          v[u] = *reinterpret_cast<const uint4*>(gp[i] + (row[i] >= 0 ? adv : 0));
         }
       } else {  // the last, partial tile
 #pragma unroll
@@ -85,7 +90,7 @@ struct Stage {
       const int D = row[0];
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
-        const int idx = u * kThreads + threadIdx.x;
+        const int idx = u * kThreads + (threadIdx.x & (kThreads - 1));
         const int r = idx / VPR, d = (idx - r * VPR) * VEC;
         v[u] = uint4{0, 0, 0, 0};
         if (idx < TOTAL && row0 + r < N && d < D)
@@ -93,26 +98,32 @@ struct Stage {
       }
     }
   }
+  // the value that goes to LDS: idle lanes of the resident-address path (columns D..DP of a row) store zeros
+  __device__ __forceinline__ uint4 value(int u) const {
+    if (PRE) return row[u < NP ? u : 0] >= 0 ? v[u] : uint4{0, 0, 0, 0};
+    return v[u];
+  }
   template <int STRIDE>
   __device__ __forceinline__ void store_rows(T* img) const {  // row-major image with an explicit row stride
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int idx = u * kThreads + threadIdx.x;
+      const int idx = u * kThreads + (threadIdx.x & (kThreads - 1));
       if (idx >= TOTAL) continue;
       const int r = idx / VPR, d = (idx - r * VPR) * VEC;
-      *reinterpret_cast<uint4*>(img + r * STRIDE + d) = v[u];
+      *reinterpret_cast<uint4*>(img + r * STRIDE + d) = value(u);
     }
   }
   __device__ __forceinline__ void store(T* rowmaj, T* transposed) const {
     constexpr int KS = DP + VEC;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int idx = u * kThreads + threadIdx.x;
+      const int idx = u * kThreads + (threadIdx.x & (kThreads - 1));
       if (idx >= TOTAL) continue;
       const int r = idx / VPR, d = (idx - r * VPR) * VEC;
-      if (rowmaj) *reinterpret_cast<uint4*>(rowmaj + r * KS + d) = v[u];
+      const uint4 val = value(u);
+      if (rowmaj) *reinterpret_cast<uint4*>(rowmaj + r * KS + d) = val;
       if (transposed) {
-        const T* e = reinterpret_cast<const T*>(&v[u]);
+        const T* e = reinterpret_cast<const T*>(&val);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) transposed[TL<T, KT>::tr(d + i) + r] = e[i];
       }
@@ -145,28 +156,67 @@ __device__ __forceinline__ typename Traits<T>::frag tr_read(const T* p) {
 // acc[rb][cb] += Img[rb*16 + .][:] . X[cb][:]   (rows of the LDS image on accumulator rows, this lane's column
 // fragments X in registers);  NRB row blocks of 16, CB column blocks.  k-chunks go through the MFMA in pairs
 // (16x16x32: twice the work of a 16x16x16 in the same cycles).
+// 8-byte LDS fragment read the compiler may not fuse with its neighbours.  Left alone, hipcc pairs adjacent 8-byte
+// reads into ds_read2_b64 across UNRELATED fragments: half the LDS rate (128 B/clk, 32-bank rule -> the padded rows
+// conflict 2-way), an address add per row block (8-bit offsets) and two v_mov per MFMA to reassemble the operands —
+// a quarter of the forward loop's VALU instructions.  A volatile access is never merged; ds_read_b64 runs at
+// 256 B/clk, conflict-free on these images, with a 16-bit immediate offset, straight into the operand registers.
+template <typename T>
+__device__ __forceinline__ typename Traits<T>::frag lds_frag(const T* p) {
+  if constexpr (sizeof(T) == 2) {
+    typedef const volatile __attribute__((address_space(3))) unsigned long long* lds_ptr;  // keep it a ds_ access
+    const unsigned long long v = *(lds_ptr)p;
+    return __builtin_bit_cast(typename Traits<T>::frag, v);
+  } else {
+    return load_frag<T>(p);
+  }
+}
+
+// One row block's fragments: NK chunks, plus (16-bit types, odd NK) the chunk-0 fragment once more as the finite
+// filler that pairs with the odd chunk.
+template <typename T, int NK>
+struct RowFrags {
+  static constexpr int NF = (sizeof(T) == 2 && (NK & 1)) ? NK + 1 : NK;
+  typename Traits<T>::frag a[NF];
+  __device__ __forceinline__ void load(const T* row) {
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) a[kc] = lds_frag<T>(row + kc * 16);
+    if (NF > NK) a[NF - 1] = lds_frag<T>(row);
+  }
+};
+
 template <typename T, int NK, int NRB, int CB>
 __device__ __forceinline__ void rows_times_cols(const T* img, const typename Traits<T>::frag (&x)[CB][NK], int c, int g,
                                                 f32x4 (&acc)[NRB][CB]) {
   constexpr int KS = NK * 16 + TileLds<T, 64>::VEC;
+  const typename Traits<T>::frag z = zero_frag<T>();
+  const T* row0 = img + c * KS + 4 * g;
+  // software pipeline, depth 2: the reads of row block rb + 1 are in flight while rb's MFMAs issue (the compiler,
+  // left alone, reuses one register set and exposes the LDS latency once per row block)
+  RowFrags<T, NK> fr[2];
+  fr[0].load(row0);
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb) {
-    const T* row = img + (rb * 16 + c) * KS + 4 * g;
+    if (rb + 1 < NRB) fr[(rb + 1) & 1].load(row0 + (rb + 1) * 16 * KS);
+    const RowFrags<T, NK>& f = fr[rb & 1];
 #pragma unroll
-    for (int kc = 0; kc + 1 < NK; kc += 2) {
-      const typename Traits<T>::frag a0 = load_frag<T>(row + kc * 16), a1 = load_frag<T>(row + kc * 16 + 16);
+    for (int kc = 0; kc + 1 < NK; kc += 2)
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = Traits<T>::mma16x2(a0, a1, x[cb][kc], x[cb][kc + 1], acc[rb][cb]);
-    }
+      for (int cb = 0; cb < CB; ++cb)
+        acc[rb][cb] = Traits<T>::mma16x2(f.a[kc], f.a[kc + 1], x[cb][kc], x[cb][kc + 1], acc[rb][cb]);
     if (NK & 1) {
-      // odd chunk: the same 16x16x32 with a zero upper half (costs what a 16x16x16 costs).  Do NOT chain a legacy
-      // v_mfma_f32_16x16x16_f16 onto a 16x16x32's accumulator: hipcc (ROCm 7.2) emits the pair back-to-back without
-      // the wait states the differing pass counts need, and the second MFMA reads a stale SrcC (wrong results).
-      const typename Traits<T>::frag a = load_frag<T>(row + (NK - 1) * 16), z = zero_frag<T>();
+      if constexpr (sizeof(T) == 2) {
+        // odd chunk: the same 16x16x32 with the column operand's upper half zero (loop-invariant registers) and, on
+        // the row side, the chunk-0 fragment once more as a finite filler — no zeroing moves in the loop.  Do NOT
+        // chain a legacy v_mfma_f32_16x16x16_f16 onto a 16x16x32's accumulator: hipcc (ROCm 7.2) emits the pair
+        // back-to-back without the wait states the differing pass counts need, and the second MFMA reads a stale
+        // SrcC (wrong results).
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        if constexpr (sizeof(T) == 2) acc[rb][cb] = Traits<T>::mma16x2(a, z, x[cb][NK - 1], z, acc[rb][cb]);
-        else acc[rb][cb] = Traits<T>::mma16(a, x[cb][NK - 1], acc[rb][cb]);
+        for (int cb = 0; cb < CB; ++cb)
+          acc[rb][cb] = Traits<T>::mma16x2(f.a[NK - 1], f.a[NK], x[cb][NK - 1], z, acc[rb][cb]);
+      } else {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = Traits<T>::mma16(f.a[NK - 1], x[cb][NK - 1], acc[rb][cb]);
       }
     }
   }
@@ -200,15 +250,29 @@ __device__ __forceinline__ void rowsT_times_frags(const T* img, const typename T
   constexpr int S = trs<NK>();
   const int i = lane & 15;
   const T* base = img + (4 * (lane >> 4) + (i >> 2)) * S + 4 * (i & 3);
+  // depth-2 pipeline over pairs of row blocks; inside a stage the NK feature blocks are independent accumulator
+  // chains, so consecutive MFMAs never wait on each other
+  typename Traits<T>::frag a[2][NK][2];
+  auto load = [&](int st, int rb) {
 #pragma unroll
-  for (int dt = 0; dt < NK; ++dt)
-#pragma unroll
-    for (int rb = 0; rb < NRB; rb += 2) {
-      const typename Traits<T>::frag a0 = tr_read<T>(base + rb * 16 * S + dt * 16);
-      const typename Traits<T>::frag a1 = tr_read<T>(base + (rb + 1) * 16 * S + dt * 16);
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) out[dt][cb] = Traits<T>::mma16x2(a0, a1, f[rb][cb], f[rb + 1][cb], out[dt][cb]);
+    for (int dt = 0; dt < NK; ++dt) {
+      a[st][dt][0] = tr_read<T>(base + rb * 16 * S + dt * 16);
+      a[st][dt][1] = tr_read<T>(base + (rb + 1) * 16 * S + dt * 16);
     }
+  };
+  load(0, 0);
+#pragma unroll
+  for (int rb = 0; rb < NRB; rb += 2) {
+    const int st = (rb >> 1) & 1;
+    if (rb + 2 < NRB) load(st ^ 1, rb + 2);
+    __builtin_amdgcn_sched_barrier(0);  // keep the next stage's reads ahead of this stage's MFMAs
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        out[dt][cb] = Traits<T>::mma16x2(a[st][dt][0], a[st][dt][1], f[rb][cb], f[rb + 1][cb], out[dt][cb]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // elements of the image that feeds rowsT / featT products
@@ -305,23 +369,29 @@ __device__ __forceinline__ void rescale_running(float amax, int cb, int& E, f32x
 }
 
 constexpr int kNoExp = 100;  // "no data yet" exponent (2^100 * 0 = 0)
+constexpr float kLazy = 8.0f;  // forward: the running maximum is only raised when a score tops it by > 2^kLazy
 
 // =================================================================================================== forward
-template <typename T, int NK, int QB, int NBUF, int KT>
-__global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
-                                                                 const T* __restrict__ V, T* __restrict__ O,
-                                                                 float* __restrict__ LSE, int H, int N, int D, int nqt,
-                                                                 int ldq, float scale) {
+// SPLIT = 2: the workgroup has two 4-wave halves that sweep the even / the odd key tiles of the same 64 x QB queries
+// through their own LDS buffers and merge (m, l, O) at the end.  At batch 1-2 the 64x64 layer only has 2048 query
+// waves (2 per SIMD); the split doubles the waves in flight so that one wave's softmax VALU work overlaps another's
+// MFMAs and LDS reads.
+template <typename T, int NK, int QB, int NBUF, int KT, int SPLIT>
+__device__ __forceinline__ void self_attn_fwd_body(const T* __restrict__ Q, const T* __restrict__ K,
+                                                   const T* __restrict__ V, T* __restrict__ O, float* __restrict__ LSE,
+                                                   int H, int N, int D, int nqt, int ldq, float scale) {
   using Tr = Traits<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // one buffer = [K row-major | V transposed]; buffers are addressed as base + cur * kBuf so that the compiler
+  // one buffer = [K row-major | V column image]; buffers are addressed as base + cur * kBuf so that the compiler
   // keeps the LDS address space (a local array of pointers decays to generic pointers -> flat_load + vmcnt(0))
-  T* const lds = reinterpret_cast<T*>(smem);
-  constexpr int kBuf = NBUF == 2 ? row_img<T, NK, KT>() + col_img<T, NK, KT>() : 0;
+  constexpr int kOne = row_img<T, NK, KT>() + col_img<T, NK, KT>();
+  constexpr int kBuf = NBUF == 2 ? kOne : 0;
   constexpr int kVoff = row_img<T, NK, KT>();
+  const int half = SPLIT == 2 ? (int)(threadIdx.x >> 8) : 0;
+  T* const lds = reinterpret_cast<T*>(smem) + half * (NBUF * kOne);
 
   const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq;     // row stride of Q / K / V (H*D, or 3*H*D when they are slices of a fused QKV)
   const size_t rso = (size_t)H * D;  // row stride of O
   const T* Qb = Q + (size_t)b * N * rs + (size_t)head * D;
@@ -333,13 +403,17 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
   typename Tr::frag qf[QB][NK];
   load_col_frags<T, NK, QB>(Qb, rs, q0, N, D, c, g, qf);
 
+  const int ntiles = (N + KT - 1) / KT;
+  const int nit = (ntiles + SPLIT - 1) / SPLIT;  // both halves run the same number of barriers
   Stage<T, NK, KT, true> sk, sv;
   sk.init(Kb, D, rs);
   sv.init(Vb, D, rs);
-  sk.load(0, N, rs);
-  sv.load(0, N, rs);
-  sk.store(lds, nullptr);
-  store_tile<T, NK, KT, true>(sv, nullptr, lds + kVoff);
+  if (half < ntiles) {
+    sk.load(half * KT, N, rs);
+    sv.load(half * KT, N, rs);
+    sk.store(lds, nullptr);
+    store_tile<T, NK, KT, true>(sv, nullptr, lds + kVoff);
+  }
   __syncthreads();
 
   f32x4 o[NK][QB];
@@ -351,76 +425,154 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
 #pragma unroll
     for (int dt = 0; dt < NK; ++dt) o[dt][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int ntiles = (N + KT - 1) / KT;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < ntiles) {  // prefetch the next tile into registers; it lands in LDS after this tile's math
-      sk.load((kt + 1) * KT, N, rs);
-      sv.load((kt + 1) * KT, N, rs);
+  // Everything loaded so far (the Q fragments) has landed by now; say so.  Without this the compiler cannot prove it
+  // on every path into the loop and parks an s_waitcnt vmcnt(0) in front of the tile's first MFMA — which in steady
+  // state waits for the NEXT tile's prefetch, issued a few instructions earlier.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+  for (int it = 0; it < nit; ++it) {
+    const int kt = it * SPLIT + half, cur = it & 1;
+    const bool more = kt + SPLIT < ntiles;
+    if (more) {  // prefetch this half's next tile into registers; it lands in LDS after this tile's math
+      sk.load((kt + SPLIT) * KT, N, rs);
+      sv.load((kt + SPLIT) * KT, N, rs);
     }
-    f32x4 s[KT / 16][QB];
+    if (kt < ntiles) {  // wave-uniform: only the odd half can run out one tile early
+      f32x4 s[KT / 16][QB];
 #pragma unroll
-    for (int kb = 0; kb < KT / 16; ++kb)
+      for (int kb = 0; kb < KT / 16; ++kb)
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) s[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const T* kimg = lds + cur * kBuf;
-    const T* vimg = kimg + kVoff;
-    rows_times_cols<T, NK, KT / 16, QB>(kimg, qf, c, g, s);
-    const int key0 = kt * KT;
-    if (key0 + KT > N) {  // only the last, partial tile needs the key mask (uniform branch)
+        for (int qb = 0; qb < QB; ++qb) s[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const T* kimg = lds + cur * kBuf;
+      const T* vimg = kimg + kVoff;
+      rows_times_cols<T, NK, KT / 16, QB>(kimg, qf, c, g, s);
+      const int key0 = kt * KT;
+      if (key0 + KT > N) {  // only the last, partial tile needs the key mask (uniform branch)
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int kb = 0; kb < KT / 16; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (key0 + kb * 16 + 4 * g + r >= N) s[kb][qb][r] = -INFINITY;
+      }
+      typename Tr::frag pf[KT / 16][QB];
+      // Lazy running maximum: the reference exponent m[] (log2 domain, identical on the 4 lanes of a column) only
+      // moves when some score of the tile would exceed it by more than 2^kLazy; otherwise the tile needs no
+      // cross-lane traffic at all (each lane keeps its own partial row sum, reduced once after the sweep) and no
+      // rescale of O.  p <= 2^kLazy = 256 stays well inside fp16 / bf16 range; the sums are f32.
+      float lmax[QB];
+      bool grow = false;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < KT / 16; ++kb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (key0 + kb * 16 + 4 * g + r >= N) s[kb][qb][r] = -INFINITY;
-    }
-    typename Tr::frag pf[KT / 16][QB];
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
+        lmax[qb] = mx * c1;
+        grow |= lmax[qb] > m[qb] + kLazy;
+      }
+      if (__builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform; typically the first tile or two only
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      float mx = -INFINITY;
+        for (int qb = 0; qb < QB; ++qb) {
+          const float mn = fmaxf(m[qb], quad_max(lmax[qb]));
+          const float alpha = fast_exp2(m[qb] - mn);  // exp2(-inf) = 0 on the first tile
+          const f32x2 av = {alpha, alpha};
+          l[qb] *= alpha;
+          m[qb] = mn;
 #pragma unroll
-      for (int kb = 0; kb < KT / 16; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
-      mx = quad_max(mx);
-      const float mn = fmaxf(m[qb], mx);
-      const float mc = mn * c1;
-      const float alpha = fast_exp2(m[qb] * c1 - mc);  // exp2(-inf) = 0 on the first tile
-      float sum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < KT / 16; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = fast_exp2(s[kb][qb][r] * c1 - mc);
-          sum += p;
-          pf[kb][qb][r] = Tr::from_f32(p);
+          for (int dt = 0; dt < NK; ++dt) {
+            o[dt][qb].xy *= av;
+            o[dt][qb].zw *= av;
+          }
         }
-      l[qb] = l[qb] * alpha + quad_sum(sum);
-      m[qb] = mn;
+      }
 #pragma unroll
-      for (int dt = 0; dt < NK; ++dt)
+      for (int qb = 0; qb < QB; ++qb) {
+        // two scores per VALU instruction where the ISA has packed f32 forms (v_pk_fma_f32, v_pk_add_f32)
+        const f32x2 c1v = {c1, c1}, mcv = {m[qb], m[qb]};
+        f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[dt][qb][r] *= alpha;
+        for (int kb = 0; kb < KT / 16; ++kb) {
+          const f32x2 t0 = s[kb][qb].xy * c1v - mcv, t1 = s[kb][qb].zw * c1v - mcv;
+          const f32x2 p0 = {fast_exp2(t0.x), fast_exp2(t0.y)}, p1 = {fast_exp2(t1.x), fast_exp2(t1.y)};
+          sum2 += p0;
+          sum2 += p1;
+          pf[kb][qb][0] = Tr::from_f32(p0.x);
+          pf[kb][qb][1] = Tr::from_f32(p0.y);
+          pf[kb][qb][2] = Tr::from_f32(p1.x);
+          pf[kb][qb][3] = Tr::from_f32(p1.y);
+        }
+        l[qb] += sum2.x + sum2.y;  // this lane's share of the row sum
+      }
+      tileT_times_frags<T, NK, KT / 16, QB>(vimg, pf, lane, o);
     }
-    tileT_times_frags<T, NK, KT / 16, QB>(vimg, pf, lane, o);
     if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before it is overwritten
-    if (kt + 1 < ntiles) {
+    if (more) {
       T* nxt = lds + (cur ^ 1) * kBuf;
       sk.store(nxt, nullptr);
       store_tile<T, NK, KT, true>(sv, nullptr, nxt + kVoff);
     }
     __syncthreads();
   }
+  if constexpr (SPLIT == 2) {
+    // merge the odd half's (m, l, O) into the even half's; the tile buffers are free after the loop's last barrier
+    float* xch = reinterpret_cast<float*>(smem);  // [NK*QB*4 + 2*QB][256]
+    const int t = threadIdx.x & (kThreads - 1);
+    if (half == 1) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        xch[(2 * qb) * kThreads + t] = m[qb];
+        xch[(2 * qb + 1) * kThreads + t] = l[qb];
+#pragma unroll
+        for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xch[(2 * QB + (qb * NK + dt) * 4 + r) * kThreads + t] = o[dt][qb][r];
+      }
+    }
+    __syncthreads();
+    if (half == 1) return;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const float m1 = xch[(2 * qb) * kThreads + t], l1 = xch[(2 * qb + 1) * kThreads + t];
+      const float mn = fmaxf(m[qb], m1);  // the even half always has a tile, so mn is finite
+      const float a0 = fast_exp2(m[qb] - mn), a1 = fast_exp2(m1 - mn);
+      l[qb] = l[qb] * a0 + l1 * a1;
+      m[qb] = mn;
+#pragma unroll
+      for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          o[dt][qb][r] = o[dt][qb][r] * a0 + xch[(2 * QB + (qb * NK + dt) * 4 + r) * kThreads + t] * a1;
+    }
+  }
   float inv[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    inv[qb] = 1.0f / l[qb];
+    const float lsum = quad_sum(l[qb]);  // the 4 lanes of a column each hold a share
+    inv[qb] = 1.0f / lsum;
     const int q = q0 + qb * 16 + c;
-    if (LSE != nullptr && g == 0 && q < N) LSE[((size_t)b * H + head) * N + q] = m[qb] * c1 + log2f(l[qb]);
+    if (LSE != nullptr && g == 0 && q < N) LSE[((size_t)b * H + head) * N + q] = m[qb] + log2f(lsum);
   }
   store_colsT<T, NK, QB>(O + ((size_t)b * N * H + head) * D, rso, q0, N, D, c, g, o, inv);
+}
+
+template <typename T, int NK, int QB, int NBUF, int KT>
+__global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                                 const T* __restrict__ V, T* __restrict__ O,
+                                                                 float* __restrict__ LSE, int H, int N, int D, int nqt,
+                                                                 int ldq, float scale) {
+  self_attn_fwd_body<T, NK, QB, NBUF, KT, 1>(Q, K, V, O, LSE, H, N, D, nqt, ldq, scale);
+}
+
+// 8 waves, at most 128 VGPRs each, so that two workgroups (16 waves) fit a CU
+template <typename T, int NK, int QB, int NBUF, int KT>
+__global__ __launch_bounds__(2 * kThreads, 4) void self_attn_fwd_split_kernel(const T* __restrict__ Q,
+                                                                              const T* __restrict__ K,
+                                                                              const T* __restrict__ V, T* __restrict__ O,
+                                                                              float* __restrict__ LSE, int H, int N,
+                                                                              int D, int nqt, int ldq, float scale) {
+  self_attn_fwd_body<T, NK, QB, NBUF, KT, 2>(Q, K, V, O, LSE, H, N, D, nqt, ldq, scale);
 }
 
 // =================================================================================================== backward prep
@@ -710,6 +862,32 @@ bool wide_columns(int B, int H, int N) {
   return NK <= 5 && (long long)B * H * ((N + 127) / 128) >= 512;
 }
 
+// split-key forward (8 waves): 64-key tiles, double-buffered per half
+template <typename T, int NK, int QB>
+int launch_fwd_split(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D,
+                     int ldq, float scale, hipStream_t s) {
+  constexpr int KT = 64, NBUF = 2;
+  const size_t tiles = sizeof(T) * 2 * NBUF * (row_img<T, NK, KT>() + col_img<T, NK, KT>());
+  const size_t xch = sizeof(float) * kThreads * (NK * QB * 4 + 2 * QB);
+  const size_t lds = tiles > xch ? tiles : xch;
+  if (lds > kLdsLimit) return GA_ERR_SHAPE;
+  const int nqt = (N + 64 * QB - 1) / (64 * QB);
+  auto k = self_attn_fwd_split_kernel<T, NK, QB, NBUF, KT>;
+  int rc = set_dyn_lds(k, lds);
+  if (rc != GA_OK) return rc;
+  hipLaunchKernelGGL(k, dim3((unsigned)(B * H * nqt)), dim3(2 * kThreads), lds, s, (const T*)Q, (const T*)K,
+                     (const T*)V, (T*)O, LSE, H, N, D, nqt, ldq, scale);
+  return check_launch();
+}
+
+inline int fwd_variant() {  // experiment switch: GA_SA_FWD = 0 default heuristics, 1 split QB=1, 2 split QB=2
+  static const int v = [] {
+    const char* e = getenv("GA_SA_FWD");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 template <typename T, int NK, int QB>
 int launch_fwd_cb(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D,
                   int ldq, float scale, hipStream_t s) {
@@ -729,6 +907,10 @@ int launch_fwd_cb(const void* Q, const void* K, const void* V, void* O, float* L
 template <typename T, int NK>
 int launch_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D, int ldq,
                float scale, hipStream_t s) {
+  if constexpr (NK <= 5 && sizeof(T) == 2) {
+    if (fwd_variant() == 1) return launch_fwd_split<T, NK, 1>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
+    if (fwd_variant() == 2) return launch_fwd_split<T, NK, 2>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
+  }
   if constexpr (NK <= 5) {
     if (wide_columns<NK>(B, H, N)) return launch_fwd_cb<T, NK, 2>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
   }
