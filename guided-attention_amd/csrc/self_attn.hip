@@ -47,62 +47,70 @@ struct Stage {
   static constexpr int PER = (TOTAL + kThreads - 1) / kThreads;           // vectors per thread
   static constexpr int NP = PRE ? PER : 1;
   uint4 v[PER];
-  const T* gp[NP];  // PRE: this lane's vector u of tile 0 (clamped when idle); else gp[0] = slice base
-  int row[NP];      // PRE: row inside the tile, -1 = idle lane; else row[0] = D
+  const T* base;      // the [rows][D] slice (wave-uniform: the loads take it as their scalar base)
+  unsigned off[NP];   // PRE: byte offset of this lane's vector u inside tile 0, clamped in-bounds for idle lanes
+  int aux[NP];        // PRE: row inside the tile, -1 = idle lane; else aux[0] = D
 
-  __device__ __forceinline__ void init(const T* __restrict__ base, int D, size_t row_stride) {
+  __device__ __forceinline__ void init(const T* __restrict__ slice, int D, size_t row_stride) {
+    base = slice;
     if (PRE) {
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const int idx = u * kThreads + (threadIdx.x & (kThreads - 1));
         const int r = idx / VPR, d = (idx - r * VPR) * VEC;
         const bool live = idx < TOTAL && d < D;
-        row[u < NP ? u : 0] = live ? r : -1;
-        gp[u < NP ? u : 0] = live ? base + (size_t)r * row_stride + d : base;
+        // Idle lanes (the columns D..DP of a row, or beyond the tile) read a valid vector of the same tile instead:
+        // no select on the address, and what they put into the pad columns is finite data that only ever meets the
+        // zero pad of the other MFMA operand or lands in output columns that are never stored.
+        const int rc = r < KT ? r : KT - 1, dc = d < D ? d : D - VEC;
+        aux[u < NP ? u : 0] = live ? r : -1;
+        off[u < NP ? u : 0] = (unsigned)(((size_t)rc * row_stride + dc) * sizeof(T));
       }
     } else {
-      gp[0] = base;
-      row[0] = D;
+      aux[0] = D;
     }
   }
   __device__ __forceinline__ void load(int row0, int N, size_t row_stride) {
     if (PRE) {
-      const size_t adv = (size_t)row0 * row_stride;
+      // buffer loads: descriptor (slice base) and tile offset in scalar registers, the lane's 32-bit offset in one
+      // VGPR — no 64-bit address arithmetic per load
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, 0x7FFFFFFF, 0x00020000);
+      const unsigned tile = (unsigned)((size_t)row0 * row_stride * sizeof(T));  // scalar
       if (row0 + KT <= N) {
-        // full tile: unconditional loads (idle lanes re-read their clamped address) and NOTHING that consumes the
-        // data here — a select on the loaded value in this block makes the compiler wait for the load on the spot
-        // (s_waitcnt vmcnt(0) before the tile's math: the prefetch is then no prefetch).  Idle lanes are zeroed
-        // when the registers go to LDS, after the math.
+        // full tile: unconditional loads and NOTHING that consumes the data here — a select on the loaded value in
+        // this block makes the compiler wait for the load on the spot (s_waitcnt vmcnt(0) before the tile's math:
+        // the prefetch is then no prefetch)
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-          const int i = u < NP ? u : 0;
-          v[u] = *reinterpret_cast<const uint4*>(gp[i] + (row[i] >= 0 ? adv : 0));
+          const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[u < NP ? u : 0], tile, 0);
+          v[u] = uint4{x[0], x[1], x[2], x[3]};
         }
-      } else {  // the last, partial tile
+      } else {  // the last, partial tile: rows beyond N must be zero (V rows meet live P columns)
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
           const int i = u < NP ? u : 0;
           v[u] = uint4{0, 0, 0, 0};
-          if (row[i] >= 0 && row0 + row[i] < N) v[u] = *reinterpret_cast<const uint4*>(gp[i] + adv);
+          if (aux[i] >= 0 && row0 + aux[i] < N) {
+            const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], tile, 0);
+            v[u] = uint4{x[0], x[1], x[2], x[3]};
+          }
         }
       }
     } else {
-      const int D = row[0];
+      const int D = aux[0];
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const int idx = u * kThreads + (threadIdx.x & (kThreads - 1));
         const int r = idx / VPR, d = (idx - r * VPR) * VEC;
         v[u] = uint4{0, 0, 0, 0};
         if (idx < TOTAL && row0 + r < N && d < D)
-          v[u] = *reinterpret_cast<const uint4*>(gp[0] + (size_t)(row0 + r) * row_stride + d);
+          v[u] = *reinterpret_cast<const uint4*>(base + (size_t)(row0 + r) * row_stride + d);
       }
     }
   }
-  // the value that goes to LDS: idle lanes of the resident-address path (columns D..DP of a row) store zeros
-  __device__ __forceinline__ uint4 value(int u) const {
-    if (PRE) return row[u < NP ? u : 0] >= 0 ? v[u] : uint4{0, 0, 0, 0};
-    return v[u];
-  }
+  __device__ __forceinline__ uint4 value(int u) const { return v[u]; }
   template <int STRIDE>
   __device__ __forceinline__ void store_rows(T* img) const {  // row-major image with an explicit row stride
 #pragma unroll
@@ -185,20 +193,24 @@ struct RowFrags {
   }
 };
 
-template <typename T, int NK, int NRB, int CB>
+// AHEAD = how many row blocks' reads are in flight before the first MFMA: 1 = depth-2 software pipeline (the reads of
+// row block rb + 1 fly while rb's MFMAs issue; cheap in registers), NRB = the whole tile up front (the LDS latency
+// is paid once per tile instead of once per row block; 2 VGPRs per fragment).  The compiler, left alone, reuses one
+// register set and exposes the latency every row block.
+template <typename T, int NK, int NRB, int CB, int AHEAD = 1>
 __device__ __forceinline__ void rows_times_cols(const T* img, const typename Traits<T>::frag (&x)[CB][NK], int c, int g,
                                                 f32x4 (&acc)[NRB][CB]) {
   constexpr int KS = NK * 16 + TileLds<T, 64>::VEC;
+  constexpr int NS = AHEAD + 1 < NRB ? AHEAD + 1 : NRB;  // fragment register sets
   const typename Traits<T>::frag z = zero_frag<T>();
   const T* row0 = img + c * KS + 4 * g;
-  // software pipeline, depth 2: the reads of row block rb + 1 are in flight while rb's MFMAs issue (the compiler,
-  // left alone, reuses one register set and exposes the LDS latency once per row block)
-  RowFrags<T, NK> fr[2];
-  fr[0].load(row0);
+  RowFrags<T, NK> fr[NS];
+#pragma unroll
+  for (int rb = 0; rb < AHEAD && rb < NRB; ++rb) fr[rb % NS].load(row0 + rb * 16 * KS);
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb) {
-    if (rb + 1 < NRB) fr[(rb + 1) & 1].load(row0 + (rb + 1) * 16 * KS);
-    const RowFrags<T, NK>& f = fr[rb & 1];
+    if (rb + AHEAD < NRB) fr[(rb + AHEAD) % NS].load(row0 + (rb + AHEAD) * 16 * KS);
+    const RowFrags<T, NK>& f = fr[rb % NS];
 #pragma unroll
     for (int kc = 0; kc + 1 < NK; kc += 2)
 #pragma unroll
@@ -274,6 +286,36 @@ __device__ __forceinline__ void rowsT_times_frags(const T* img, const typename T
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+// The same product with ALL of the tile's transposing reads issued first (load) and the MFMAs later (apply): the
+// forward puts its softmax between the two, so the reads land under VALU work instead of in front of the MFMAs.
+template <typename T, int NK, int NRB>
+struct ColFrags {
+  typename Traits<T>::frag a[NRB / 2][NK][2];
+  __device__ __forceinline__ void load(const T* img, int lane) {
+    constexpr int S = trs<NK>();
+    const int i = lane & 15;
+    const T* base = img + (4 * (lane >> 4) + (i >> 2)) * S + 4 * (i & 3);
+#pragma unroll
+    for (int rb = 0; rb < NRB; rb += 2)
+#pragma unroll
+      for (int dt = 0; dt < NK; ++dt) {
+        a[rb >> 1][dt][0] = tr_read<T>(base + rb * 16 * S + dt * 16);
+        a[rb >> 1][dt][1] = tr_read<T>(base + (rb + 1) * 16 * S + dt * 16);
+      }
+    __builtin_amdgcn_sched_barrier(0);  // the reads stay here, ahead of whatever follows
+  }
+  template <int CB>
+  __device__ __forceinline__ void apply(const typename Traits<T>::frag (&f)[NRB][CB], f32x4 (&out)[NK][CB]) const {
+#pragma unroll
+    for (int rb = 0; rb < NRB; rb += 2)
+#pragma unroll
+      for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+          out[dt][cb] = Traits<T>::mma16x2(a[rb >> 1][dt][0], a[rb >> 1][dt][1], f[rb][cb], f[rb + 1][cb], out[dt][cb]);
+  }
+};
 
 // elements of the image that feeds rowsT / featT products
 template <typename T, int NK, int KT>
@@ -444,7 +486,12 @@ __device__ __forceinline__ void self_attn_fwd_body(const T* __restrict__ Q, cons
         for (int qb = 0; qb < QB; ++qb) s[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
       const T* kimg = lds + cur * kBuf;
       const T* vimg = kimg + kVoff;
-      rows_times_cols<T, NK, KT / 16, QB>(kimg, qf, c, g, s);
+      // 16 queries per wave leave the registers for whole-tile read-ahead (K before the score MFMAs, V under the
+      // softmax); the 32-query variant keeps the depth-2 pipelines
+      constexpr bool kAhead = kTrRead<T> && QB == 1 && NK <= 5;
+      rows_times_cols<T, NK, KT / 16, QB, kAhead ? KT / 16 : 1>(kimg, qf, c, g, s);
+      ColFrags<T, NK, kAhead ? KT / 16 : 2> vfr;
+      if constexpr (kAhead) vfr.load(vimg, lane);
       const int key0 = kt * KT;
       if (key0 + KT > N) {  // only the last, partial tile needs the key mask (uniform branch)
 #pragma unroll
@@ -505,7 +552,8 @@ __device__ __forceinline__ void self_attn_fwd_body(const T* __restrict__ Q, cons
         }
         l[qb] += sum2.x + sum2.y;  // this lane's share of the row sum
       }
-      tileT_times_frags<T, NK, KT / 16, QB>(vimg, pf, lane, o);
+      if constexpr (kAhead) vfr.template apply<QB>(pf, o);
+      else tileT_times_frags<T, NK, KT / 16, QB>(vimg, pf, lane, o);
     }
     if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before it is overwritten
     if (more) {
