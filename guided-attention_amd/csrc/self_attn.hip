@@ -399,7 +399,7 @@ __device__ __forceinline__ void rescale_running(float amax, int cb, int& E, f32x
   if (!(amax > 0.f) || amax == INFINITY) return;
   int e;
   (void)frexpf(amax, &e);  // amax = m * 2^e, m in [0.5, 1)
-  const int want = -e;
+  const int want = -e < -120 ? -120 : (-e > 99 ? 99 : -e);  // keeps 2^E and 2^-E finite f32 (scale_of)
   if (want < E) {
     const float f = ldexpf(1.0f, want - E);
 #pragma unroll
@@ -411,6 +411,8 @@ __device__ __forceinline__ void rescale_running(float amax, int cb, int& E, f32x
 }
 
 constexpr int kNoExp = 100;  // "no data yet" exponent (2^100 * 0 = 0)
+constexpr float kGrow = 16.0f;  // backward: |dS| * 2^E may reach this before the scale is renewed (fp16 max 65504)
+__device__ __forceinline__ float scale_of(int E) { return __uint_as_float((unsigned)(127 + E) << 23); }  // 2^E
 constexpr float kLazy = 8.0f;  // forward: the running maximum is only raised when a score tops it by > 2^kLazy
 
 // =================================================================================================== forward
@@ -718,24 +720,44 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
             if (key0 + kb * 16 + 4 * g + r >= N) s[kb][qb][r] = -INFINITY;
     }
     typename Tr::frag dsf[KT / 16][QB];
+    float amax[QB];
+    bool grow = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      float amax = 0.f;
+      // dS = P o (dP - delta), two scores per packed f32 instruction
+      const f32x2 c1v = {c1, c1}, lv = {lse[qb], lse[qb]}, dv = {dl[qb], dl[qb]};
+      float am = 0.f;
 #pragma unroll
-      for (int kb = 0; kb < KT / 16; ++kb)
+      for (int kb = 0; kb < KT / 16; ++kb) {
+        const f32x2 t0 = s[kb][qb].xy * c1v - lv, t1 = s[kb][qb].zw * c1v - lv;
+        const f32x2 p0 = {fast_exp2(t0.x), fast_exp2(t0.y)}, p1 = {fast_exp2(t1.x), fast_exp2(t1.y)};
+        const f32x2 d0 = p0 * (dp[kb][qb].xy - dv), d1 = p1 * (dp[kb][qb].zw - dv);
+        s[kb][qb].xy = d0;
+        s[kb][qb].zw = d1;
+        am = fmaxf(am, fmaxf(fabsf(d0.x), fabsf(d0.y)));
+        am = fmaxf(am, fmaxf(fabsf(d1.x), fabsf(d1.y)));
+      }
+      amax[qb] = am;
+      grow |= am * scale_of(E[qb]) > kGrow;
+    }
+    // lazy power-of-two scale (16-bit operands): only when some |dS| outgrows the current scale by 2^4 does the
+    // wave reduce the column maxima across lanes and rescale its accumulators
+    if (sizeof(T) == 2 && __builtin_amdgcn_ballot_w64(grow) != 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = fast_exp2(s[kb][qb][r] * c1 - lse[qb]);
-          const float ds = p * (dp[kb][qb][r] - dl[qb]);
-          s[kb][qb][r] = ds;
-          amax = fmaxf(amax, fabsf(ds));
-        }
-      if (sizeof(T) == 2) rescale_running<NK, QB>(quad_max(amax), qb, E[qb], acc);
-      const float f = (sizeof(T) == 2 && E[qb] != kNoExp) ? ldexpf(1.0f, E[qb]) : 1.0f;
+      for (int qb = 0; qb < QB; ++qb) rescale_running<NK, QB>(quad_max(amax[qb]), qb, E[qb], acc);
+    }
 #pragma unroll
-      for (int kb = 0; kb < KT / 16; ++kb)
+    for (int qb = 0; qb < QB; ++qb) {
+      const float f = sizeof(T) == 2 ? scale_of(E[qb]) : 1.0f;
+      const f32x2 fv = {f, f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dsf[kb][qb][r] = Tr::from_f32(s[kb][qb][r] * f);
+      for (int kb = 0; kb < KT / 16; ++kb) {
+        const f32x2 a = s[kb][qb].xy * fv, b = s[kb][qb].zw * fv;
+        dsf[kb][qb][0] = Tr::from_f32(a.x);
+        dsf[kb][qb][1] = Tr::from_f32(a.y);
+        dsf[kb][qb][2] = Tr::from_f32(b.x);
+        dsf[kb][qb][3] = Tr::from_f32(b.y);
+      }
     }
     tileT_times_frags<T, NK, KT / 16, QB>(buf + kToff, dsf, lane, acc);
     if (NBUF == 1) __syncthreads();
@@ -835,28 +857,55 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
     rows_times_cols<T, NK, KT / 16, KB>(buf + kDr, vf, c, g, dp);
     const int q0t = qt * KT;
     typename Tr::frag pf[KT / 16][KB], dsf[KT / 16][KB];
+    const bool edge = q0t + KT > N;  // wave-uniform: only the last query tile has dead rows
+    float amax[KB];
+    bool grow = false;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const bool key_live = k0 + kb * 16 + c < N;
-      float amax = 0.f;
+      const f32x2 c1v = {c1, c1};
+      float am = 0.f;
 #pragma unroll
-      for (int qb = 0; qb < KT / 16; ++qb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qi = qb * 16 + 4 * g + r;
-          const bool live = key_live && (q0t + qi < N);
-          const float p = live ? fast_exp2(s[qb][kb][r] * c1 - Lq[qi]) : 0.f;
-          const float ds = p * (dp[qb][kb][r] - Dq[qi]);
-          pf[qb][kb][r] = Tr::from_f32(p);
-          s[qb][kb][r] = ds;
-          amax = fmaxf(amax, fabsf(ds));
+      for (int qb = 0; qb < KT / 16; ++qb) {
+        const int qi = qb * 16 + 4 * g;
+        const f32x4 L = *reinterpret_cast<const f32x4*>(Lq + qi), Dl = *reinterpret_cast<const f32x4*>(Dq + qi);
+        const f32x2 t0 = s[qb][kb].xy * c1v - L.xy, t1 = s[qb][kb].zw * c1v - L.zw;
+        f32x2 p0 = {fast_exp2(t0.x), fast_exp2(t0.y)}, p1 = {fast_exp2(t1.x), fast_exp2(t1.y)};
+        if (edge || !key_live) {  // dead query rows / dead key columns contribute nothing
+          p0.x = (key_live && q0t + qi + 0 < N) ? p0.x : 0.f;
+          p0.y = (key_live && q0t + qi + 1 < N) ? p0.y : 0.f;
+          p1.x = (key_live && q0t + qi + 2 < N) ? p1.x : 0.f;
+          p1.y = (key_live && q0t + qi + 3 < N) ? p1.y : 0.f;
         }
-      if (sizeof(T) == 2) rescale_running<NK, KB>(quad_max(amax), kb, E[kb], dk);
-      const float f = (sizeof(T) == 2 && E[kb] != kNoExp) ? ldexpf(1.0f, E[kb]) : 1.0f;
+        const f32x2 d0 = p0 * (dp[qb][kb].xy - Dl.xy), d1 = p1 * (dp[qb][kb].zw - Dl.zw);
+        pf[qb][kb][0] = Tr::from_f32(p0.x);
+        pf[qb][kb][1] = Tr::from_f32(p0.y);
+        pf[qb][kb][2] = Tr::from_f32(p1.x);
+        pf[qb][kb][3] = Tr::from_f32(p1.y);
+        s[qb][kb].xy = d0;
+        s[qb][kb].zw = d1;
+        am = fmaxf(am, fmaxf(fabsf(d0.x), fabsf(d0.y)));
+        am = fmaxf(am, fmaxf(fabsf(d1.x), fabsf(d1.y)));
+      }
+      amax[kb] = am;
+      grow |= am * scale_of(E[kb]) > kGrow;
+    }
+    if (sizeof(T) == 2 && __builtin_amdgcn_ballot_w64(grow) != 0) {
 #pragma unroll
-      for (int qb = 0; qb < KT / 16; ++qb)
+      for (int kb = 0; kb < KB; ++kb) rescale_running<NK, KB>(quad_max(amax[kb]), kb, E[kb], dk);
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dsf[qb][kb][r] = Tr::from_f32(s[qb][kb][r] * f);
+    for (int kb = 0; kb < KB; ++kb) {
+      const float f = sizeof(T) == 2 ? scale_of(E[kb]) : 1.0f;
+      const f32x2 fv = {f, f};
+#pragma unroll
+      for (int qb = 0; qb < KT / 16; ++qb) {
+        const f32x2 a = s[qb][kb].xy * fv, b = s[qb][kb].zw * fv;
+        dsf[qb][kb][0] = Tr::from_f32(a.x);
+        dsf[qb][kb][1] = Tr::from_f32(a.y);
+        dsf[qb][kb][2] = Tr::from_f32(b.x);
+        dsf[qb][kb][3] = Tr::from_f32(b.y);
+      }
     }
     tileT_times_frags<T, NK, KT / 16, KB>(buf + kDt, pf, lane, dv);  // dV^T += dO^T P
     tileT_times_frags<T, NK, KT / 16, KB>(buf + kQt, dsf, lane, dk);  // dK^T += Q^T dS
