@@ -18,8 +18,6 @@
 // layout: no LDS round trip between chained MFMAs.  Tensors stay in the projection layout [B][N][H][D].
 // Workgroup ids run head-fastest so that, with 8 heads and round-robin XCD dispatch, the workgroups that sweep one
 // head's K/V share an XCD L2.   MFMA-bound for N >= 1024 (4 N^2 D flops per head forward), latency-bound below.
-#include <stdlib.h>
-
 #include "attn_common.h"
 
 using namespace ga;
@@ -416,14 +414,11 @@ __device__ __forceinline__ float scale_of(int E) { return __uint_as_float((unsig
 constexpr float kLazy = 8.0f;  // forward: the running maximum is only raised when a score tops it by > 2^kLazy
 
 // =================================================================================================== forward
-// SPLIT = 2: the workgroup has two 4-wave halves that sweep the even / the odd key tiles of the same 64 x QB queries
-// through their own LDS buffers and merge (m, l, O) at the end.  At batch 1-2 the 64x64 layer only has 2048 query
-// waves (2 per SIMD); the split doubles the waves in flight so that one wave's softmax VALU work overlaps another's
-// MFMAs and LDS reads.
-template <typename T, int NK, int QB, int NBUF, int KT, int SPLIT>
-__device__ __forceinline__ void self_attn_fwd_body(const T* __restrict__ Q, const T* __restrict__ K,
-                                                   const T* __restrict__ V, T* __restrict__ O, float* __restrict__ LSE,
-                                                   int H, int N, int D, int nqt, int ldq, float scale) {
+template <typename T, int NK, int QB, int NBUF, int KT>
+__global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                                 const T* __restrict__ V, T* __restrict__ O,
+                                                                 float* __restrict__ LSE, int H, int N, int D, int nqt,
+                                                                 int ldq, float scale) {
   using Tr = Traits<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // one buffer = [K row-major | V column image]; buffers are addressed as base + cur * kBuf so that the compiler
@@ -431,11 +426,10 @@ __device__ __forceinline__ void self_attn_fwd_body(const T* __restrict__ Q, cons
   constexpr int kOne = row_img<T, NK, KT>() + col_img<T, NK, KT>();
   constexpr int kBuf = NBUF == 2 ? kOne : 0;
   constexpr int kVoff = row_img<T, NK, KT>();
-  const int half = SPLIT == 2 ? (int)(threadIdx.x >> 8) : 0;
-  T* const lds = reinterpret_cast<T*>(smem) + half * (NBUF * kOne);
+  T* const lds = reinterpret_cast<T*>(smem);
 
   const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
-  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, c = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq;     // row stride of Q / K / V (H*D, or 3*H*D when they are slices of a fused QKV)
   const size_t rso = (size_t)H * D;  // row stride of O
   const T* Qb = Q + (size_t)b * N * rs + (size_t)head * D;
@@ -448,16 +442,13 @@ __device__ __forceinline__ void self_attn_fwd_body(const T* __restrict__ Q, cons
   load_col_frags<T, NK, QB>(Qb, rs, q0, N, D, c, g, qf);
 
   const int ntiles = (N + KT - 1) / KT;
-  const int nit = (ntiles + SPLIT - 1) / SPLIT;  // both halves run the same number of barriers
   Stage<T, NK, KT, true> sk, sv;
   sk.init(Kb, D, rs);
   sv.init(Vb, D, rs);
-  if (half < ntiles) {
-    sk.load(half * KT, N, rs);
-    sv.load(half * KT, N, rs);
-    sk.store(lds, nullptr);
-    store_tile<T, NK, KT, true>(sv, nullptr, lds + kVoff);
-  }
+  sk.load(0, N, rs);
+  sv.load(0, N, rs);
+  sk.store(lds, nullptr);
+  store_tile<T, NK, KT, true>(sv, nullptr, lds + kVoff);
   __syncthreads();
 
   f32x4 o[NK][QB];
@@ -473,14 +464,14 @@ __device__ __forceinline__ void self_attn_fwd_body(const T* __restrict__ Q, cons
   // on every path into the loop and parks an s_waitcnt vmcnt(0) in front of the tile's first MFMA — which in steady
   // state waits for the NEXT tile's prefetch, issued a few instructions earlier.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
-  for (int it = 0; it < nit; ++it) {
-    const int kt = it * SPLIT + half, cur = it & 1;
-    const bool more = kt + SPLIT < ntiles;
-    if (more) {  // prefetch this half's next tile into registers; it lands in LDS after this tile's math
-      sk.load((kt + SPLIT) * KT, N, rs);
-      sv.load((kt + SPLIT) * KT, N, rs);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < ntiles;
+    if (more) {  // prefetch the next tile into registers; it lands in LDS after this tile's math
+      sk.load((kt + 1) * KT, N, rs);
+      sv.load((kt + 1) * KT, N, rs);
     }
-    if (kt < ntiles) {  // wave-uniform: only the odd half can run out one tile early
+    {  // the tile's scores and probabilities live in registers inside this scope only
       f32x4 s[KT / 16][QB];
 #pragma unroll
       for (int kb = 0; kb < KT / 16; ++kb)
@@ -565,37 +556,6 @@ __device__ __forceinline__ void self_attn_fwd_body(const T* __restrict__ Q, cons
     }
     __syncthreads();
   }
-  if constexpr (SPLIT == 2) {
-    // merge the odd half's (m, l, O) into the even half's; the tile buffers are free after the loop's last barrier
-    float* xch = reinterpret_cast<float*>(smem);  // [NK*QB*4 + 2*QB][256]
-    const int t = threadIdx.x & (kThreads - 1);
-    if (half == 1) {
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        xch[(2 * qb) * kThreads + t] = m[qb];
-        xch[(2 * qb + 1) * kThreads + t] = l[qb];
-#pragma unroll
-        for (int dt = 0; dt < NK; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) xch[(2 * QB + (qb * NK + dt) * 4 + r) * kThreads + t] = o[dt][qb][r];
-      }
-    }
-    __syncthreads();
-    if (half == 1) return;
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      const float m1 = xch[(2 * qb) * kThreads + t], l1 = xch[(2 * qb + 1) * kThreads + t];
-      const float mn = fmaxf(m[qb], m1);  // the even half always has a tile, so mn is finite
-      const float a0 = fast_exp2(m[qb] - mn), a1 = fast_exp2(m1 - mn);
-      l[qb] = l[qb] * a0 + l1 * a1;
-      m[qb] = mn;
-#pragma unroll
-      for (int dt = 0; dt < NK; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          o[dt][qb][r] = o[dt][qb][r] * a0 + xch[(2 * QB + (qb * NK + dt) * 4 + r) * kThreads + t] * a1;
-    }
-  }
   float inv[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
@@ -605,24 +565,6 @@ __device__ __forceinline__ void self_attn_fwd_body(const T* __restrict__ Q, cons
     if (LSE != nullptr && g == 0 && q < N) LSE[((size_t)b * H + head) * N + q] = m[qb] + log2f(lsum);
   }
   store_colsT<T, NK, QB>(O + ((size_t)b * N * H + head) * D, rso, q0, N, D, c, g, o, inv);
-}
-
-template <typename T, int NK, int QB, int NBUF, int KT>
-__global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
-                                                                 const T* __restrict__ V, T* __restrict__ O,
-                                                                 float* __restrict__ LSE, int H, int N, int D, int nqt,
-                                                                 int ldq, float scale) {
-  self_attn_fwd_body<T, NK, QB, NBUF, KT, 1>(Q, K, V, O, LSE, H, N, D, nqt, ldq, scale);
-}
-
-// 8 waves, at most 128 VGPRs each, so that two workgroups (16 waves) fit a CU
-template <typename T, int NK, int QB, int NBUF, int KT>
-__global__ __launch_bounds__(2 * kThreads, 4) void self_attn_fwd_split_kernel(const T* __restrict__ Q,
-                                                                              const T* __restrict__ K,
-                                                                              const T* __restrict__ V, T* __restrict__ O,
-                                                                              float* __restrict__ LSE, int H, int N,
-                                                                              int D, int nqt, int ldq, float scale) {
-  self_attn_fwd_body<T, NK, QB, NBUF, KT, 2>(Q, K, V, O, LSE, H, N, D, nqt, ldq, scale);
 }
 
 // =================================================================================================== backward prep
@@ -707,8 +649,13 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) s[kb][qb] = dp[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const T* buf = lds + cur * kBuf;
-    rows_times_cols<T, NK, KT / 16, QB>(buf, qf, c, g, s);
-    rows_times_cols<T, NK, KT / 16, QB>(buf + kVoff, dof, c, g, dp);
+    // 16 columns per wave leave registers for whole-tile read-ahead (see the forward)
+    constexpr bool kAhead = kTrRead<T> && QB == 1 && NK <= 5;
+    constexpr int kA = kAhead ? KT / 16 : 1;
+    rows_times_cols<T, NK, KT / 16, QB, kA>(buf, qf, c, g, s);
+    rows_times_cols<T, NK, KT / 16, QB, kA>(buf + kVoff, dof, c, g, dp);
+    ColFrags<T, NK, kAhead ? KT / 16 : 2> kcol;
+    if constexpr (kAhead) kcol.load(buf + kToff, lane);
     const int key0 = kt * KT;
     if (key0 + KT > N) {  // partial last tile: masked keys get p = exp2(-inf) = 0
 #pragma unroll
@@ -759,7 +706,8 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
         dsf[kb][qb][3] = Tr::from_f32(b.y);
       }
     }
-    tileT_times_frags<T, NK, KT / 16, QB>(buf + kToff, dsf, lane, acc);
+    if constexpr (kAhead) kcol.template apply<QB>(dsf, acc);
+    else tileT_times_frags<T, NK, KT / 16, QB>(buf + kToff, dsf, lane, acc);
     if (NBUF == 1) __syncthreads();
     if (kt + 1 < ntiles) {
       T* nxt = lds + (cur ^ 1) * kBuf;
@@ -853,8 +801,15 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
     const T* buf = lds + cur * kBuf;
     const float* Lq = stats + cur * kSbuf;
     const float* Dq = Lq + KT;
-    rows_times_cols<T, NK, KT / 16, KB>(buf, kf, c, g, s);
-    rows_times_cols<T, NK, KT / 16, KB>(buf + kDr, vf, c, g, dp);
+    constexpr bool kAhead = kTrRead<T> && KB == 1 && NK <= 5;
+    constexpr int kA = kAhead ? KT / 16 : 1;
+    rows_times_cols<T, NK, KT / 16, KB, kA>(buf, kf, c, g, s);
+    rows_times_cols<T, NK, KT / 16, KB, kA>(buf + kDr, vf, c, g, dp);
+    ColFrags<T, NK, kAhead ? KT / 16 : 2> docol, qcol;
+    if constexpr (kAhead) {
+      docol.load(buf + kDt, lane);
+      qcol.load(buf + kQt, lane);
+    }
     const int q0t = qt * KT;
     typename Tr::frag pf[KT / 16][KB], dsf[KT / 16][KB];
     const bool edge = q0t + KT > N;  // wave-uniform: only the last query tile has dead rows
@@ -907,8 +862,13 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
         dsf[qb][kb][3] = Tr::from_f32(b.y);
       }
     }
-    tileT_times_frags<T, NK, KT / 16, KB>(buf + kDt, pf, lane, dv);  // dV^T += dO^T P
-    tileT_times_frags<T, NK, KT / 16, KB>(buf + kQt, dsf, lane, dk);  // dK^T += Q^T dS
+    if constexpr (kAhead) {
+      docol.template apply<KB>(pf, dv);   // dV^T += dO^T P
+      qcol.template apply<KB>(dsf, dk);   // dK^T += Q^T dS
+    } else {
+      tileT_times_frags<T, NK, KT / 16, KB>(buf + kDt, pf, lane, dv);
+      tileT_times_frags<T, NK, KT / 16, KB>(buf + kQt, dsf, lane, dk);
+    }
     if (NBUF == 1) __syncthreads();
     if (qt + 1 < ntiles) {
       T* nxt = lds + (cur ^ 1) * kBuf;
@@ -959,32 +919,6 @@ bool wide_columns(int B, int H, int N) {
   return NK <= 5 && (long long)B * H * ((N + 127) / 128) >= 512;
 }
 
-// split-key forward (8 waves): 64-key tiles, double-buffered per half
-template <typename T, int NK, int QB>
-int launch_fwd_split(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D,
-                     int ldq, float scale, hipStream_t s) {
-  constexpr int KT = 64, NBUF = 2;
-  const size_t tiles = sizeof(T) * 2 * NBUF * (row_img<T, NK, KT>() + col_img<T, NK, KT>());
-  const size_t xch = sizeof(float) * kThreads * (NK * QB * 4 + 2 * QB);
-  const size_t lds = tiles > xch ? tiles : xch;
-  if (lds > kLdsLimit) return GA_ERR_SHAPE;
-  const int nqt = (N + 64 * QB - 1) / (64 * QB);
-  auto k = self_attn_fwd_split_kernel<T, NK, QB, NBUF, KT>;
-  int rc = set_dyn_lds(k, lds);
-  if (rc != GA_OK) return rc;
-  hipLaunchKernelGGL(k, dim3((unsigned)(B * H * nqt)), dim3(2 * kThreads), lds, s, (const T*)Q, (const T*)K,
-                     (const T*)V, (T*)O, LSE, H, N, D, nqt, ldq, scale);
-  return check_launch();
-}
-
-inline int fwd_variant() {  // experiment switch: GA_SA_FWD = 0 default heuristics, 1 split QB=1, 2 split QB=2
-  static const int v = [] {
-    const char* e = getenv("GA_SA_FWD");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-
 template <typename T, int NK, int QB>
 int launch_fwd_cb(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D,
                   int ldq, float scale, hipStream_t s) {
@@ -1004,10 +938,6 @@ int launch_fwd_cb(const void* Q, const void* K, const void* V, void* O, float* L
 template <typename T, int NK>
 int launch_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D, int ldq,
                float scale, hipStream_t s) {
-  if constexpr (NK <= 5 && sizeof(T) == 2) {
-    if (fwd_variant() == 1) return launch_fwd_split<T, NK, 1>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
-    if (fwd_variant() == 2) return launch_fwd_split<T, NK, 2>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
-  }
   if constexpr (NK <= 5) {
     if (wide_columns<NK>(B, H, N)) return launch_fwd_cb<T, NK, 2>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
   }
