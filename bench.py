@@ -228,6 +228,12 @@ def main():
     args = parse()
     from guided_attention_amd import ops, parallel
     rank, world, local = parallel.init_distributed()
+    if world > 1:
+        # one MIOpen user database / kernel cache per rank: N processes benchmarking the same conv shapes at the same
+        # time otherwise queue on the file locks of one shared database
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", f"/tmp/ga_miopen_{os.getuid()}_{local}")
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/ga_miopen_{os.getuid()}_{local}/cache")
+        os.makedirs(os.environ["MIOPEN_CUSTOM_CACHE_DIR"], exist_ok=True)
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
