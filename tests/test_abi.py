@@ -66,6 +66,21 @@ def test_argument_validation_needs_no_gpu(lib):
     # every entry point validates before touching the device: errors come back as codes
     assert lib.ga_attn_capture_fwd(None, None, None, None, None, 1, 8, 256, 77, 160, 0.1, 0, None) == -1
     assert lib.ga_latent_axpy(None, None, 1.0, None, None, 16, 0, None) == -1
+    assert lib.ga_geglu_fwd(None, None, 4, 16, 0, None) == -1
+    assert lib.ga_geglu_bwd(None, None, None, 4, 16, 0, None) == -1
+    assert lib.ga_bias_residual_add(None, None, None, None, 4, 16, 0, None) == -1
+    assert lib.ga_add_layer_norm_fwd(None, None, None, None, None, None, None, 4, 16, 1e-5, 0, None) == -1
+    assert lib.ga_add_layer_norm_bwd(None, None, None, None, None, None, 4, 16, 0, None) == -1
+    assert lib.ga_self_attn_fwd(None, None, None, None, None, 1, 8, 64, 40, 0, 0.1, 0, None) == -1
+    assert lib.ga_group_norm_fwd(None, None, None, None, None, None, None, 1, 64, 320, 32, 1e-5, 1, 0, None) == -1
+    # shape / dtype / alignment errors are told apart (host-side checks on fake, never dereferenced pointers)
+    p = ctypes.c_void_p(4096)
+    assert lib.ga_geglu_fwd(p, p, 4, 12, 0, None) == -2          # F = 12 fp16 is not a whole 16-byte vector
+    assert lib.ga_geglu_fwd(p, p, 4, 16, 7, None) == -3          # unknown dtype
+    assert lib.ga_geglu_fwd(ctypes.c_void_p(4100), p, 4, 16, 0, None) == -4
+    assert lib.ga_add_layer_norm_fwd(None, p, p, p, None, p, None, 4, 8192, 1e-5, 0, None) == -2   # C > 4096
+    assert lib.ga_self_attn_fwd(p, p, p, p, None, 1, 8, 64, 200, 0, 0.1, 0, None) == -2           # D > 160
+    assert lib.ga_self_attn_fwd(p, p, p, p, None, 1, 8, 64, 44, 0, 0.1, 0, None) == -4            # D % 8 != 0
 
 
 def test_product_refuses_cpu_tensors():
