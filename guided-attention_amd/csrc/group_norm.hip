@@ -104,37 +104,30 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict_
   fold_to_groups<NPT>(s0, s1, CP, cpg, G, lds, partial + ((size_t)b * gridDim.x + nb) * G * 2);
 }
 
-// One workgroup per image folds the NB per-block partials of every group in a fixed order (4 slices x 64 groups,
-// loads unrolled 8-deep) and turns them into what the apply kernels need:
+// One wave per (image, group) folds that group's NB per-block partials in a fixed order (lane = partial index mod 64,
+// then the butterfly) and turns them into what the apply kernels need — a single round of loads per lane:
 //   FWD : out[b][g] = (mean, rstd)            BWD : out[b][g] = (mean of dyhat, mean of dyhat*yhat)
+// grid (B, ceil(G / 4)), 4 waves = 4 groups per workgroup.
 template <bool FWD>
 __global__ __launch_bounds__(kThreads) void gn_finalize_kernel(const float* __restrict__ partial, int NB, int G,
                                                                float inv_n, float eps, float* __restrict__ out) {
-  // 256 lanes = 4 slices x 64 groups; a lane's <= 64 partials are fetched as float2 in two batches of 32 loads
-  __shared__ float slice[2][4][64];
-  const int b = blockIdx.x, g = threadIdx.x % 64, sl = threadIdx.x / 64;
-  float sa = 0.f, sc = 0.f;
+  const int b = blockIdx.x, g = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= G) return;
   const float2* pp = reinterpret_cast<const float2*>(partial) + (size_t)b * NB * G + g;
-  for (int nb0 = sl; nb0 < NB; nb0 += 128) {
-    float2 v[32];
+  float2 v[kMaxNB / 64];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int nb = nb0 + 4 * i;
-      v[i] = float2{0.f, 0.f};
-      if (g < G && nb < NB) v[i] = pp[(size_t)nb * G];
-    }
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      sa += v[i].x;
-      sc += v[i].y;
-    }
+  for (int i = 0; i < kMaxNB / 64; ++i) {
+    const int nb = lane + 64 * i;
+    v[i] = nb < NB ? pp[(size_t)nb * G] : float2{0.f, 0.f};
   }
-  slice[0][sl][g] = sa;
-  slice[1][sl][g] = sc;
-  __syncthreads();
-  if (threadIdx.x < G) {
-    const float v0 = (slice[0][0][g] + slice[0][1][g]) + (slice[0][2][g] + slice[0][3][g]);
-    const float v1 = (slice[1][0][g] + slice[1][1][g]) + (slice[1][2][g] + slice[1][3][g]);
+  float sa = 0.f, sc = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxNB / 64; ++i) {
+    sa += v[i].x;
+    sc += v[i].y;
+  }
+  const float v0 = wave_reduce_sum(sa), v1 = wave_reduce_sum(sc);
+  if (lane == 0) {
     float o0, o1;
     if (FWD) {
       const double mean = (double)v0 * inv_n;
@@ -559,7 +552,7 @@ int launch_fwd_t(const void* x, const void* cbias, const void* gamma, const void
   const float inv_n = 1.0f / ((float)HW * (float)(C / G));
   hipLaunchKernelGGL((gn_stats_kernel<T, NPT, W>), dim3(g.NB, B), dim3(kThreads), g.lds, s, (const T*)x,
                      (const T*)cbias, ws, HW, C, G, g.PBs);
-  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(B), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, eps, stats);
+  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(B, (G + 3) / 4), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, eps, stats);
   hipLaunchKernelGGL((gn_apply_kernel<T, ACT, NPT, W>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
                      (const T*)cbias, (const T*)gamma, (const T*)beta, (T*)y, stats, HW, C, G, g.PBa);
   return check_launch();
@@ -572,7 +565,7 @@ int launch_bwd_t(const void* x, const void* cbias, const void* dy, const void* g
   float* fin = ws + (size_t)B * kMaxNB * G * 2;  // [B][G][2] behind the partials
   hipLaunchKernelGGL((gn_bwd_stats_kernel<T, ACT, NPT, W>), dim3(g.NB, B), dim3(kThreads), g.lds, s, (const T*)x,
                      (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, HW, C, G, g.PBs);
-  hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(B), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, 0.0f, fin);
+  hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(B, (G + 3) / 4), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, 0.0f, fin);
   hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT, NPT, W>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
                      (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, fin, (T*)dx, HW, C, G, g.PBa);
   return check_launch();
