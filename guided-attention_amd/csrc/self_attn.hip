@@ -464,10 +464,28 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
   // on every path into the loop and parks an s_waitcnt vmcnt(0) in front of the tile's first MFMA — which in steady
   // state waits for the NEXT tile's prefetch, issued a few instructions earlier.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+  // Staging order with two LDS buffers: the registers always hold tile kt + 1 (loaded during tile kt - 1's math); at
+  // the top of iteration kt they go to the other buffer — free since the barrier that ended iteration kt - 1 — and
+  // the loads of tile kt + 2 are issued at once.  The LDS writes then overlap the tile's math instead of sitting
+  // between the math and the barrier, where every wave waits for the slowest writer.
+  if (NBUF == 2 && ntiles > 1) {
+    sk.load(KT, N, rs);
+    sv.load(KT, N, rs);
+  }
   for (int kt = 0; kt < ntiles; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < ntiles;
-    if (more) {  // prefetch the next tile into registers; it lands in LDS after this tile's math
+    if (NBUF == 2) {
+      if (more) {
+        T* nxt = lds + (cur ^ 1) * kBuf;
+        sk.store(nxt, nullptr);
+        store_tile<T, NK, KT, true>(sv, nullptr, nxt + kVoff);
+        if (kt + 2 < ntiles) {
+          sk.load((kt + 2) * KT, N, rs);
+          sv.load((kt + 2) * KT, N, rs);
+        }
+      }
+    } else if (more) {  // single buffer: prefetch to registers now, write after this tile's math and a barrier
       sk.load((kt + 1) * KT, N, rs);
       sv.load((kt + 1) * KT, N, rs);
     }
@@ -548,11 +566,12 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
       if constexpr (kAhead) vfr.template apply<QB>(pf, o);
       else tileT_times_frags<T, NK, KT / 16, QB>(vimg, pf, lane, o);
     }
-    if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before it is overwritten
-    if (more) {
-      T* nxt = lds + (cur ^ 1) * kBuf;
-      sk.store(nxt, nullptr);
-      store_tile<T, NK, KT, true>(sv, nullptr, nxt + kVoff);
+    if (NBUF == 1) {
+      __syncthreads();  // single buffer: everyone is done reading before it is overwritten
+      if (more) {
+        sk.store(lds, nullptr);
+        store_tile<T, NK, KT, true>(sv, nullptr, lds + kVoff);
+      }
     }
     __syncthreads();
   }
