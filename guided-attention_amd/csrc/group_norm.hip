@@ -329,6 +329,257 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
   }
 }
 
+// ---- wide path for the large levels (16-bit types, C % 8 == 0, 8 <= C/G, C <= 2048): 16-byte vectors that may
+// straddle a group boundary, and ALL 256 threads busy — thread t owns vector t % (C/8) of the pixels
+// p0 + t / (C/8), + RP, ... (C = 320: 40 vectors x 6 pixel rows; the 4/8-byte path above leaves 176 of 256 lanes
+// idle there).  A vector's 8 channels lie in at most two groups: gA (the first `split` channels) and gA + 1.
+struct WideMap {
+  int VP, RP, vec, pr, gA, split;
+  bool active;
+  __device__ __forceinline__ WideMap(int C, int G) {
+    const int cg = C / G;
+    VP = C >> 3;
+    RP = kThreads / VP;
+    vec = threadIdx.x % VP;
+    pr = threadIdx.x / VP;
+    active = pr < RP;
+    gA = (vec * 8) / cg;
+    split = min(8, (gA + 1) * cg - vec * 8);
+  }
+};
+
+template <typename T>
+struct alignas(16) Vec8 {
+  T v[8];
+};
+
+// per-thread (sumA0, sumA1, sumB0, sumB1) -> per-group partial sums of this pixel block, fixed order
+__device__ __forceinline__ void wide_fold(const WideMap& m, const float (&c0)[8], const float (&c1)[8], int C, int G,
+                                          float4* lds4, float* out) {
+  float4 r = {0.f, 0.f, 0.f, 0.f};
+  if (m.active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < m.split) {
+        r.x += c0[j];
+        r.y += c1[j];
+      } else {
+        r.z += c0[j];
+        r.w += c1[j];
+      }
+    }
+  }
+  lds4[threadIdx.x] = r;
+  __syncthreads();
+  const int cg = C / G;
+  for (int g = threadIdx.x; g < G; g += kThreads) {
+    const int vlo = (g * cg) >> 3, vhi = ((g + 1) * cg - 1) >> 3;
+    float a = 0.f, b = 0.f;
+    for (int v = vlo; v <= vhi; ++v) {
+      const bool first = (v * 8) / cg == g;  // g is this vector's gA, otherwise its gA + 1
+      for (int pr = 0; pr < m.RP; ++pr) {
+        const float4 e = lds4[pr * m.VP + v];
+        a += first ? e.x : e.z;
+        b += first ? e.y : e.w;
+      }
+    }
+    out[2 * g] = a;
+    out[2 * g + 1] = b;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gn_wide_stats_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+                                                                 float* __restrict__ partial, int HW, int C, int G,
+                                                                 int PB) {
+  __shared__ float4 lds4[kThreads];
+  const WideMap m(C, G);
+  const int b = blockIdx.y, nb = blockIdx.x, p0 = nb * PB, p1 = min(HW, p0 + PB);
+  float c0[8], c1[8], cb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c0[j] = c1[j] = cb[j] = 0.f;
+  if (m.active) {
+    if (cbias != nullptr) {
+      const Vec8<T> bv = reinterpret_cast<const Vec8<T>*>(cbias + (size_t)b * C)[m.vec];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cb[j] = Traits<T>::to_f32(bv.v[j]);
+    }
+    const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
+    for (int p = p0 + m.pr; p < p1; p += kU * m.RP) {
+      Vec8<T> v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (p + u * m.RP < p1) v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (p + u * m.RP < p1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float a = Traits<T>::to_f32(v[u].v[j]) + cb[j];
+            c0[j] += a;
+            c1[j] += a * a;
+          }
+        }
+    }
+  }
+  wide_fold(m, c0, c1, C, G, lds4, partial + ((size_t)b * gridDim.x + nb) * G * 2);
+}
+
+template <typename T, bool ACT>
+__global__ __launch_bounds__(kThreads) void gn_wide_apply_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+                                                                 const T* __restrict__ gamma,
+                                                                 const T* __restrict__ beta, T* __restrict__ y,
+                                                                 const float* __restrict__ stats, int HW, int C, int G,
+                                                                 int PB) {
+  const WideMap m(C, G);
+  if (!m.active) return;
+  const int b = blockIdx.y, p0 = blockIdx.x * PB, p1 = min(HW, p0 + PB);
+  const float* mr = stats + (size_t)b * G * 2;
+  float sc[8], sh[8];
+  {
+    const Vec8<T> gm = reinterpret_cast<const Vec8<T>*>(gamma)[m.vec], bt = reinterpret_cast<const Vec8<T>*>(beta)[m.vec];
+    Vec8<T> bv;
+    if (cbias != nullptr) bv = reinterpret_cast<const Vec8<T>*>(cbias + (size_t)b * C)[m.vec];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = j < m.split ? m.gA : m.gA + 1;
+      const float cbj = cbias != nullptr ? Traits<T>::to_f32(bv.v[j]) : 0.f;
+      sc[j] = Traits<T>::to_f32(gm.v[j]) * mr[2 * g + 1];
+      sh[j] = Traits<T>::to_f32(bt.v[j]) - (mr[2 * g] - cbj) * sc[j];  // (x + cb - mean) * scale + beta
+    }
+  }
+  const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
+  Vec8<T>* yb = reinterpret_cast<Vec8<T>*>(y + (size_t)b * HW * C) + m.vec;
+  for (int p = p0 + m.pr; p < p1; p += kU * m.RP) {
+    Vec8<T> v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (p + u * m.RP < p1) v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (p + u * m.RP < p1) {
+        Vec8<T> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float z = Traits<T>::to_f32(v[u].v[j]) * sc[j] + sh[j];
+          if (ACT) z *= sigmoidf_(z);
+          o.v[j] = Traits<T>::from_f32(z);
+        }
+        yb[(size_t)(p + u * m.RP) * m.VP] = o;
+      }
+  }
+}
+
+// the per-channel constants the backward kernels share
+template <typename T>
+struct WideBwdConst {
+  float mu[8], rs[8], gm[8], bt[8], cb[8];
+  __device__ __forceinline__ void load(const WideMap& m, const T* cbias, const T* gamma, const T* beta,
+                                       const float* stats, int b, int C, int G) {
+    const Vec8<T> g8 = reinterpret_cast<const Vec8<T>*>(gamma)[m.vec], b8 = reinterpret_cast<const Vec8<T>*>(beta)[m.vec];
+    Vec8<T> c8;
+    if (cbias != nullptr) c8 = reinterpret_cast<const Vec8<T>*>(cbias + (size_t)b * C)[m.vec];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = j < m.split ? m.gA : m.gA + 1;
+      mu[j] = stats[((size_t)b * G + g) * 2];
+      rs[j] = stats[((size_t)b * G + g) * 2 + 1];
+      gm[j] = Traits<T>::to_f32(g8.v[j]);
+      bt[j] = Traits<T>::to_f32(b8.v[j]);
+      cb[j] = cbias != nullptr ? Traits<T>::to_f32(c8.v[j]) : 0.f;
+    }
+  }
+};
+
+template <typename T, bool ACT>
+__global__ __launch_bounds__(kThreads) void gn_wide_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+                                                                     const T* __restrict__ dy,
+                                                                     const T* __restrict__ gamma,
+                                                                     const T* __restrict__ beta,
+                                                                     const float* __restrict__ stats,
+                                                                     float* __restrict__ partial, int HW, int C, int G,
+                                                                     int PB) {
+  __shared__ float4 lds4[kThreads];
+  const WideMap m(C, G);
+  const int b = blockIdx.y, nb = blockIdx.x, p0 = nb * PB, p1 = min(HW, p0 + PB);
+  float c0[8], c1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c0[j] = c1[j] = 0.f;
+  if (m.active) {
+    WideBwdConst<T> k;
+    k.load(m, cbias, gamma, beta, stats, b, C, G);
+    const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
+    const Vec8<T>* db = reinterpret_cast<const Vec8<T>*>(dy + (size_t)b * HW * C) + m.vec;
+    for (int p = p0 + m.pr; p < p1; p += kU * m.RP) {
+      Vec8<T> v[kU], d[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (p + u * m.RP < p1) {
+          v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
+          d[u] = db[(size_t)(p + u * m.RP) * m.VP];
+        }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (p + u * m.RP < p1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float yh = (Traits<T>::to_f32(v[u].v[j]) + k.cb[j] - k.mu[j]) * k.rs[j];
+            const float dh = dyhat_of<ACT>(yh, Traits<T>::to_f32(d[u].v[j]), k.gm[j], k.bt[j]);
+            c0[j] += dh;
+            c1[j] += dh * yh;
+          }
+        }
+    }
+  }
+  wide_fold(m, c0, c1, C, G, lds4, partial + ((size_t)b * gridDim.x + nb) * G * 2);
+}
+
+template <typename T, bool ACT>
+__global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+                                                                     const T* __restrict__ dy,
+                                                                     const T* __restrict__ gamma,
+                                                                     const T* __restrict__ beta,
+                                                                     const float* __restrict__ stats,
+                                                                     const float* __restrict__ fin, T* __restrict__ dx,
+                                                                     int HW, int C, int G, int PB) {
+  const WideMap m(C, G);
+  if (!m.active) return;
+  const int b = blockIdx.y, p0 = blockIdx.x * PB, p1 = min(HW, p0 + PB);
+  WideBwdConst<T> k;
+  k.load(m, cbias, gamma, beta, stats, b, C, G);
+  float a1[8], a2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int g = j < m.split ? m.gA : m.gA + 1;
+    a1[j] = fin[((size_t)b * G + g) * 2];
+    a2[j] = fin[((size_t)b * G + g) * 2 + 1];
+  }
+  const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
+  const Vec8<T>* db = reinterpret_cast<const Vec8<T>*>(dy + (size_t)b * HW * C) + m.vec;
+  Vec8<T>* ob = reinterpret_cast<Vec8<T>*>(dx + (size_t)b * HW * C) + m.vec;
+  for (int p = p0 + m.pr; p < p1; p += kU * m.RP) {
+    Vec8<T> v[kU], d[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (p + u * m.RP < p1) {
+        v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
+        d[u] = db[(size_t)(p + u * m.RP) * m.VP];
+      }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (p + u * m.RP < p1) {
+        Vec8<T> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float yh = (Traits<T>::to_f32(v[u].v[j]) + k.cb[j] - k.mu[j]) * k.rs[j];
+          const float dh = dyhat_of<ACT>(yh, Traits<T>::to_f32(d[u].v[j]), k.gm[j], k.bt[j]);
+          o.v[j] = Traits<T>::from_f32(k.rs[j] * (dh - a1[j] - yh * a2[j]));
+        }
+        ob[(size_t)(p + u * m.RP) * m.VP] = o;
+      }
+  }
+}
+
 // ---- small tensors (<= 256 pixels: the 16x16 and 8x8 levels): one launch, one workgroup per (image, group).
 // The group's slab (HW pixels x C/G channels, <= 20 480 elements) is read once into LDS while the sums are taken,
 // reduced in-block, then normalised from LDS: a single ~4 us latency chain instead of three launches.
@@ -594,9 +845,66 @@ int launch_bwd_t(const void* x, const void* cbias, const void* dy, const void* g
     default: return FN<T, ACT, 5, 2>(__VA_ARGS__);                   \
   }
 
+// wide path: geometry and launches
+inline bool wide_ok(int C, int G, size_t elem) { return elem == 2 && C % 8 == 0 && C / G >= 8 && C <= 8 * kThreads; }
+
+struct WideGeom {
+  int PBs, NB, PBa, NBa;
+  WideGeom(int HW, int C) {
+    const int RP = kThreads / (C / 8);
+    const int fill = (HW + kMaxNB - 1) / kMaxNB;     // stats: at most kMaxNB partial blocks
+    PBs = fill > 4 * RP ? fill : 4 * RP;             // >= 4 pixels per thread
+    NB = (HW + PBs - 1) / PBs;
+    PBa = 4 * RP;                                    // apply: one 4-deep batch of loads per thread
+    NBa = (HW + PBa - 1) / PBa;
+  }
+};
+
+template <typename T>
+int wide_fwd(const void* x, const void* cbias, const void* gamma, const void* beta, void* y, float* stats, float* ws,
+             int B, int HW, int C, int G, float eps, int act, hipStream_t s) {
+  const WideGeom g(HW, C);
+  const float inv_n = 1.0f / ((float)HW * (float)(C / G));
+  hipLaunchKernelGGL(gn_wide_stats_kernel<T>, dim3(g.NB, B), dim3(kThreads), 0, s, (const T*)x, (const T*)cbias, ws, HW,
+                     C, G, g.PBs);
+  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(B, (G + 3) / 4), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, eps, stats);
+  if (act)
+    hipLaunchKernelGGL((gn_wide_apply_kernel<T, true>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
+                       (const T*)cbias, (const T*)gamma, (const T*)beta, (T*)y, stats, HW, C, G, g.PBa);
+  else
+    hipLaunchKernelGGL((gn_wide_apply_kernel<T, false>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
+                       (const T*)cbias, (const T*)gamma, (const T*)beta, (T*)y, stats, HW, C, G, g.PBa);
+  return check_launch();
+}
+
+template <typename T>
+int wide_bwd(const void* x, const void* cbias, const void* dy, const void* gamma, const void* beta, const float* stats,
+             void* dx, float* ws, int B, int HW, int C, int G, int act, hipStream_t s) {
+  const WideGeom g(HW, C);
+  const float inv_n = 1.0f / ((float)HW * (float)(C / G));
+  float* fin = ws + (size_t)B * kMaxNB * G * 2;  // [B][G][2] behind the partials
+  if (act)
+    hipLaunchKernelGGL((gn_wide_bwd_stats_kernel<T, true>), dim3(g.NB, B), dim3(kThreads), 0, s, (const T*)x,
+                       (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, HW, C, G, g.PBs);
+  else
+    hipLaunchKernelGGL((gn_wide_bwd_stats_kernel<T, false>), dim3(g.NB, B), dim3(kThreads), 0, s, (const T*)x,
+                       (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, HW, C, G, g.PBs);
+  hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(B, (G + 3) / 4), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, 0.0f, fin);
+  if (act)
+    hipLaunchKernelGGL((gn_wide_bwd_apply_kernel<T, true>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
+                       (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, fin, (T*)dx, HW, C, G, g.PBa);
+  else
+    hipLaunchKernelGGL((gn_wide_bwd_apply_kernel<T, false>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
+                       (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, fin, (T*)dx, HW, C, G, g.PBa);
+  return check_launch();
+}
+
 template <typename T>
 int fwd_dtype(const void* x, const void* cbias, const void* gamma, const void* beta, void* y, float* stats, float* ws, int B,
               int HW, int C, int G, float eps, int act, const Geom& g, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    if (wide_ok(C, G, sizeof(T))) return wide_fwd<T>(x, cbias, gamma, beta, y, stats, ws, B, HW, C, G, eps, act, s);
+  }
   if (act) {
     GA_GN_NPT(launch_fwd_t, T, true, x, cbias, gamma, beta, y, stats, ws, B, HW, C, G, eps, g, s)
   }
@@ -606,6 +914,9 @@ int fwd_dtype(const void* x, const void* cbias, const void* gamma, const void* b
 template <typename T>
 int bwd_dtype(const void* x, const void* cbias, const void* dy, const void* gamma, const void* beta, const float* stats,
               void* dx, float* ws, int B, int HW, int C, int G, int act, const Geom& g, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    if (wide_ok(C, G, sizeof(T))) return wide_bwd<T>(x, cbias, dy, gamma, beta, stats, dx, ws, B, HW, C, G, act, s);
+  }
   if (act) {
     GA_GN_NPT(launch_bwd_t, T, true, x, cbias, dy, gamma, beta, stats, dx, ws, B, HW, C, G, g, s)
   }

@@ -350,7 +350,7 @@ def test_latent_ops(ops, dt, n):
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("act", [True, False])
 @pytest.mark.parametrize("shape", [(1, 320, 64, 64), (2, 320, 64, 64), (1, 640, 32, 32), (1, 960, 64, 64),
-                                   (1, 1920, 32, 32), (2, 2560, 16, 16), (1, 1920, 16, 16), (2, 1280, 16, 16), (1, 1280, 8, 8), (1, 64, 4, 4), (1, 32, 4, 4), (2, 96, 3, 5)])
+                                   (1, 1920, 32, 32), (1, 256, 20, 20), (2, 512, 17, 19), (2, 2560, 16, 16), (1, 1920, 16, 16), (2, 1280, 16, 16), (1, 1280, 8, 8), (1, 64, 4, 4), (1, 32, 4, 4), (2, 96, 3, 5)])
 def test_group_norm_act(ops, shape, act, dt):
     """Fused channels-last GroupNorm(+SiLU) forward/backward vs PyTorch's own ops in fp64 on the CPU."""
     B, C, H, W = shape
