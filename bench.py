@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--guidance-forward", default="full", choices=["full", "truncated"])
     ap.add_argument("--skip-unused-guidance", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying hipGraphs")
+    ap.add_argument("--no-joint-pass", action="store_true",
+                    help="run the loss-only guidance forward and the CFG pair as two passes (B=1, B=2) instead of one B=3 pass")
     return ap.parse_args()
 
 
@@ -63,6 +65,7 @@ def build_pipeline(args, device, rank, world):
     pipe.guidance_forward = args.guidance_forward
     pipe.skip_unused_guidance = args.skip_unused_guidance
     pipe.use_graphs = not args.eager
+    pipe.batch_loss_only_guidance = not args.no_joint_pass
     return pipe, cfg, {"messages": n_msgs, "seconds": bcast_s}
 
 
@@ -283,6 +286,9 @@ def main():
                                    f"meta_prompt '{META_PROMPT}', guidance 7.5, thresholds {rc.thresholds}, 1 seed per step",
                        "parallelism": f"seed-parallel x{world}", "guidance_forward": args.guidance_forward,
                        "skip_unused_guidance": args.skip_unused_guidance, "model": args.model,
+                       "loss_only_steps": ("two passes (B=1 guidance, B=2 CFG)" if args.no_joint_pass or args.eager else
+                                           "guidance forward + CFG pair of a step without latent update batched as one "
+                                           "B=3 pass (every evaluation performed)"),
                        "launch": "eager" if args.eager else "hipGraph replay of the UNet passes (captured in warm-up)",
                        "weights": "seeded random init (no checkpoint offline)"},
             "unet_calls_per_image": calls, "finite": ok,

@@ -6,6 +6,9 @@ HIP graphs and replayed:
     g_eval : latents -> UNet forward with the capture kernels -> aggregate -> smoothed box loss   (autograd on)
     g_grad : autograd backward of that loss to the latents (replays against g_eval's saved activations)
     g_cfg  : the no-grad CFG forward on [latents, latents]
+    g_joint: steps on which no latent update can follow the guidance evaluation (its loss is only logged): the
+             guidance forward (cond) and the CFG pair (uncond, cond) are three independent UNet evaluations of the
+             SAME latents — one no-grad batch-3 pass, sample 0's maps feeding aggregate + loss
 Host control flow (thresholds, refinement, recurse) stays in Python between replays; scalars that change
 per step (timestep) live in static device tensors, per-step kernel scalars (step size, alphas) stay in
 the eager one-launch kernels around the graphs.  The kernels inside the graphs are exactly the eager
@@ -23,7 +26,7 @@ class GraphRunner:
         plan = pipe._loss_plan(smooth, sigma, ksize)
         key = (tuple(latents.shape), latents.dtype, tuple(prompt_embeds.shape), pipe._plan_key, attention_res,
                pipe.guidance_forward, normalize_eot, str(pipe.prompt) if normalize_eot else None,
-               getattr(store, "capture", None))
+               getattr(store, "capture", None), bool(getattr(pipe, "batch_loss_only_guidance", False)))
         runner = pipe._graph_cache.get(key)
         if runner is None:
             pipe._graph_cache.clear()  # one live configuration: the pools hold every activation of both passes
@@ -31,6 +34,7 @@ class GraphRunner:
             pipe._graph_cache[key] = runner
         if not torch.equal(runner.embeds, prompt_embeds):
             runner.embeds.copy_(prompt_embeds)
+            runner._fill_embeds3()
             refresh_context_projections(pipe.unet)  # the captured graphs read the cached text K/V tensors
         return runner
 
@@ -41,9 +45,20 @@ class GraphRunner:
         self.embeds = prompt_embeds.detach().clone()
         self.lat_g = torch.zeros_like(latents).requires_grad_(True)
         self.lat2 = torch.zeros((2,) + tuple(latents.shape[1:]), dtype=latents.dtype, device=dev)
+        self.joint = bool(getattr(pipe, "batch_loss_only_guidance", False)) and prompt_embeds.shape[0] == 2
+        if self.joint:
+            self.lat3 = torch.zeros((3,) + tuple(latents.shape[1:]), dtype=latents.dtype, device=dev)
+            self.embeds3 = torch.empty((3,) + tuple(prompt_embeds.shape[1:]), dtype=prompt_embeds.dtype, device=dev)
+            self._fill_embeds3()
         self.loss_args = (smooth, sigma, ksize, normalize_eot)
         self.res = attention_res
         self._capture(store)
+
+    def _fill_embeds3(self):
+        if self.joint:  # [guidance: cond | CFG: uncond, cond]
+            self.embeds3[0].copy_(self.embeds[1])
+            self.embeds3[1].copy_(self.embeds[0])
+            self.embeds3[2].copy_(self.embeds[1])
 
     # -- bodies (run eagerly for warm-up, then once more under capture)
     def _eval_body(self, store):
@@ -63,6 +78,17 @@ class GraphRunner:
             out = self.pipe.unet(self.lat2, self.t_dev, encoder_hidden_states=self.embeds).sample
         return out, store.attention_store
 
+    def _joint_body(self, store):
+        pipe = self.pipe
+        with torch.no_grad():
+            out = pipe.unet(self.lat3, self.t_dev, encoder_hidden_states=self.embeds3).sample
+            # the guidance evaluation is sample 0: keep its head-maps only (the reference's guidance forward has batch 1)
+            snap = {k: [p[: p.shape[0] // 3] for p in v] for k, v in store.attention_store.items()}
+            store.attention_store = snap
+            A = aggregate_attention(store, self.res, ("up", "down", "mid"), True, 0)
+            parts = pipe._loss_device(A, *self.loss_args)
+        return out, parts, snap
+
     def _capture(self, store):
         calls = dict(self.pipe.unet_calls)
         self.t_dev.fill_(981)
@@ -74,6 +100,8 @@ class GraphRunner:
                 parts, _ = self._eval_body(store)
                 self._grad_body(parts[1])
                 self._cfg_body(store)
+                if self.joint:
+                    self._joint_body(store)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g_eval = torch.cuda.CUDAGraph()
@@ -87,6 +115,11 @@ class GraphRunner:
         with ops.census_scope() as c_cfg, torch.cuda.graph(self.g_cfg, pool=self.g_eval.pool()):
             self.noise, self.store_cfg = self._cfg_body(store)
         self.launches = {"eval": c_eval.launches, "grad": c_grad.launches, "cfg": c_cfg.launches}
+        if self.joint:
+            self.g_joint = torch.cuda.CUDAGraph()
+            with ops.census_scope() as c_joint, torch.cuda.graph(self.g_joint, pool=self.g_eval.pool()):
+                self.noise3, self.parts_joint, self.store_joint = self._joint_body(store)
+            self.launches["joint"] = c_joint.launches
         torch.cuda.synchronize()
         self.pipe.unet_calls.update(calls)  # capture / warm-up passes are not image work
 
@@ -118,3 +151,13 @@ class GraphRunner:
         ops.add_census(self.launches["cfg"])
         self._publish(store, self.store_cfg)
         return self.noise
+
+    def joint_forward(self, latents, t, store):
+        """-> (loss parts of the guidance evaluation, CFG noise prediction (2, ...)) from one batch-3 replay."""
+        self.t_dev.fill_(int(t))
+        for j in range(3):
+            self.lat3[j].copy_(latents[0])
+        self.g_joint.replay()
+        ops.add_census(self.launches["joint"])
+        self._publish(store, self.store_joint)
+        return self.parts_joint, self.noise3[1:3]

@@ -57,9 +57,13 @@ class GuidedAttention:
         # True: the two UNet passes are captured once into hipGraphs (guidance forward + loss, its backward, the CFG
         # forward) and replayed — same kernels, no per-launch host work.  False: eager launches.
         self.use_graphs = False
+        # With hipGraphs: on steps where no latent update can follow the guidance evaluation (its loss is only
+        # logged), run the guidance forward (cond) and the CFG pair (uncond, cond) — three independent evaluations of
+        # the same latents — as ONE batch-3 pass.  Nothing is skipped; False runs them as two passes (B=1, B=2).
+        self.batch_loss_only_guidance = True
         self._runner = None
         self._graph_cache = {}
-        self.unet_calls = {"fwd_b1_grad": 0, "bwd": 0, "fwd_b2": 0, "loss_evals": 0}
+        self.unet_calls = {"fwd_b1_grad": 0, "bwd": 0, "fwd_b2": 0, "loss_evals": 0, "joint_b3": 0}
         self._plan_key = None
         self._plan = None
 
@@ -465,7 +469,7 @@ class GuidedAttention:
         renoise_noise = list(renoise_noise) if renoise_noise is not None else None
         if hasattr(attention_store, "attention_res"):
             attention_store.attention_res = attention_res
-        self.unet_calls = {"fwd_b1_grad": 0, "bwd": 0, "fwd_b2": 0, "loss_evals": 0}
+        self.unet_calls = {"fwd_b1_grad": 0, "bwd": 0, "fwd_b2": 0, "loss_evals": 0, "joint_b3": 0}
         self._attention_store = attention_store
         self._deferred_log = []
         self._truncate_at = self._truncation_point(attention_res, height, width)
@@ -482,6 +486,7 @@ class GuidedAttention:
             a_t, a_prev = self.scheduler.alphas_for(t_int)
             for recurse_step in range(recurse_steps):
                 did_we_update = False
+                noise_joint = None
                 state.cur_time_step_iter = i
                 helpers.log(f"iteration {i}", self.verbose)
                 may_update = (not state.config.only_update_on_threshold_steps and i < max_iter_to_alter) or \
@@ -491,6 +496,16 @@ class GuidedAttention:
                     # with no consumer; kept only for call-count fidelity unless skip_unused_guidance is set
                     if not self.skip_unused_guidance:
                         self._guidance_forward(latents, t_int, cond)
+                elif (self._runner is not None and self._runner.joint and not may_update and not run_standard_sd
+                      and not self.skip_unused_guidance):
+                    # The guidance evaluation of this step cannot change the latents (no threshold, no per-step
+                    # update): its forward and the CFG pair see the SAME latents and run as one batch-3 pass.  Every
+                    # evaluation of the reference is still performed; the loss is computed and logged as before.
+                    self.unet_calls["fwd_b1_grad"] += 1
+                    self.unet_calls["fwd_b2"] += 1
+                    self.unet_calls["joint_b3"] += 1  # of the two counters above, how many ran as one batch-3 pass
+                    parts, noise_joint = self._runner.joint_forward(latents, t_int, attention_store)
+                    self._compute_loss(losses_dict=self._loss_host(*parts))
                 elif not (self.skip_unused_guidance and (run_standard_sd or not may_update)):
                     with torch.enable_grad():
                         latents, max_attention_per_index = self._guidance_eval(
@@ -522,13 +537,16 @@ class GuidedAttention:
                                             f"{max_attention_per_index['_fused']['host_loss'].item():0.4f}", self.verbose)
                 latents = latents.detach()
                 # CFG pass with the (possibly updated) latents, no autograd
-                model_in = torch.cat([latents] * 2) if do_cfg else latents
-                model_in = self.scheduler.scale_model_input(model_in, t_int)
-                self.unet_calls["fwd_b2"] += 1
-                if self._runner is not None and do_cfg:
-                    noise_pred = self._runner.cfg_forward(latents, t_int, attention_store)
+                if noise_joint is not None:
+                    noise_pred = noise_joint
                 else:
-                    noise_pred = self.unet(model_in, t_int, encoder_hidden_states=prompt_embeds).sample
+                    model_in = torch.cat([latents] * 2) if do_cfg else latents
+                    model_in = self.scheduler.scale_model_input(model_in, t_int)
+                    self.unet_calls["fwd_b2"] += 1
+                    if self._runner is not None and do_cfg:
+                        noise_pred = self._runner.cfg_forward(latents, t_int, attention_store)
+                    else:
+                        noise_pred = self.unet(model_in, t_int, encoder_hidden_states=prompt_embeds).sample
                 if do_cfg:
                     eps_uncond, eps_text = noise_pred.chunk(2)
                     latents, _x0 = ops.cfg_ddim_step(eps_uncond, eps_text, guidance_scale, latents, a_t, a_prev)

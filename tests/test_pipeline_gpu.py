@@ -61,7 +61,11 @@ def test_fp32_pipeline_matches_reference_call(meta):
     assert err < 5e-3, err  # fp32 GPU vs fp32 CPU through up to 41 forward + 33 backward UNet passes
 
 
-@pytest.mark.parametrize("variant", ["rerun", "reference-capture", "truncated", "skip-unused", "graphs", "graphs-truncated"])
+MAIN_CALLS = ("fwd_b1_grad", "bwd", "fwd_b2", "loss_evals")
+
+
+@pytest.mark.parametrize("variant", ["rerun", "reference-capture", "truncated", "skip-unused", "graphs", "graphs-truncated",
+                                     "graphs-two-pass"])
 def test_variants_are_result_identical(variant):
     """capture='reference', the truncated guidance forward and the skipped log-only guidance passes must
     not change the latents.  Library conv/GEMM kernels may be chosen differently from call to call, so
@@ -84,16 +88,22 @@ def test_variants_are_result_identical(variant):
         out, _ = run_product(pipe, meta, embeds, lat0, noise, thr, guidance_forward="truncated")
     elif variant.startswith("graphs"):
         mode = "truncated" if variant.endswith("truncated") else "full"
-        out, ctrl = run_product(pipe, meta, embeds, lat0, noise, thr, use_graphs=True, guidance_forward=mode)
-        assert out.unet_calls == base.unet_calls
+        joint = not variant.endswith("two-pass")
+        out, ctrl = run_product(pipe, meta, embeds, lat0, noise, thr, use_graphs=True, guidance_forward=mode,
+                                batch_loss_only_guidance=joint)
+        # every evaluation of the eager run is performed; with `joint`, the loss-only guidance forward and the CFG
+        # pair of a step share one batch-3 pass
+        assert {k: out.unet_calls[k] for k in MAIN_CALLS} == {k: base.unet_calls[k] for k in MAIN_CALLS}
+        assert (out.unet_calls["joint_b3"] > 0) == joint and base.unet_calls["joint_b3"] == 0
         assert {k: len(v) for k, v in ctrl.attention_store.items() if v} == {"down_cross": 2, "up_cross": 3}
-        out2, _ = run_product(pipe, meta, embeds, lat0, noise, thr, use_graphs=True, guidance_forward=mode)  # cached graphs
+        out2, _ = run_product(pipe, meta, embeds, lat0, noise, thr, use_graphs=True, guidance_forward=mode,
+                              batch_loss_only_guidance=joint)  # cached graphs
         err2 = (out.latents - out2.latents).abs().max().item() / out.latents.abs().max().item()
         assert err2 < 2e-4, err2  # library backward kernels are not bit-reproducible run to run
     else:
         out, _ = run_product(pipe, meta, embeds, lat0, noise, thr, skip_unused_guidance=True)
         assert out.unet_calls["fwd_b1_grad"] < base.unet_calls["fwd_b1_grad"]
-    pipe.guidance_forward, pipe.skip_unused_guidance, pipe.use_graphs = "full", False, False
+    pipe.guidance_forward, pipe.skip_unused_guidance, pipe.use_graphs, pipe.batch_loss_only_guidance = "full", False, False, True
     assert out.unet_calls["bwd"] == base.unet_calls["bwd"] and out.unet_calls["fwd_b2"] == base.unet_calls["fwd_b2"]
     err = (out.latents - base.latents).abs().max().item() / base.latents.abs().max().item()
     assert err < 2e-4, err
