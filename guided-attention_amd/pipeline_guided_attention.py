@@ -472,6 +472,7 @@ class GuidedAttention:
         self.unet_calls = {"fwd_b1_grad": 0, "bwd": 0, "fwd_b2": 0, "loss_evals": 0, "joint_b3": 0}
         self._attention_store = attention_store
         self._deferred_log = []
+        self._deferred_losses = []
         self._truncate_at = self._truncation_point(attention_res, height, width)
         cond = prompt_embeds[1:2] if do_cfg else prompt_embeds[0:1]
         guided = bool(getattr(state.config, "token_dict", None)) or bool(getattr(state.config, "custom_loss", None))
@@ -505,7 +506,9 @@ class GuidedAttention:
                     self.unet_calls["fwd_b2"] += 1
                     self.unet_calls["joint_b3"] += 1  # of the two counters above, how many ran as one batch-3 pass
                     parts, noise_joint = self._runner.joint_forward(latents, t_int, attention_store)
-                    self._compute_loss(losses_dict=self._loss_host(*parts))
+                    # the loss of such a step is only logged: keep the device values and read them back after the
+                    # loop (no host sync here, the host runs ahead of the GPU); the log lines go to their place
+                    self._deferred_losses.append((len(helpers.lines), i, parts[:4] + (parts[4].clone(),)))
                 elif not (self.skip_unused_guidance and (run_standard_sd or not may_update)):
                     with torch.enable_grad():
                         latents, max_attention_per_index = self._guidance_eval(
@@ -570,6 +573,16 @@ class GuidedAttention:
         for text, dev_scalar in self._deferred_log:  # device scalars are read once, after the loop
             helpers.log(text + str(dev_scalar.item()))
         self._deferred_log = []
+        shift = 0
+        for pos, step, parts in self._deferred_losses:  # loss logs of the log-only steps, inserted where they belong
+            state.cur_time_step_iter, state.sub_iteration = step, 0
+            mark = len(helpers.lines)
+            self._compute_loss(losses_dict=self._loss_host(*parts))
+            fresh = helpers.lines[mark:]
+            del helpers.lines[mark:]
+            helpers.lines[pos + shift:pos + shift] = fresh
+            shift += len(fresh)
+        self._deferred_losses = []
         has_nsfw_concept = False
         if output_type == "latent":
             image = latents
