@@ -127,6 +127,14 @@ def kernel_work(key):
     GroupNorm    = read x + write y (fwd), read x, dy + write dx (bwd)."""
     kind, B, H, N, Kt, D, flag, dt = key
     esz = 4 if dt == "torch.float32" else 2
+    if kind in ("geglu_fwd", "geglu_bwd"):            # B = rows, D = F: x [rows][2F] in, y [rows][F] out (bwd: + dy, dx)
+        return "hbm", esz * B * D * (3 if kind == "geglu_fwd" else 5)
+    if kind == "bias_residual_add":                  # y + residual in, out
+        return "hbm", esz * B * D * 3
+    if kind == "add_layer_norm_fwd":                 # (a,) x in; (x_new,) y out
+        return "hbm", esz * B * D * (4 if flag else 2)
+    if kind == "add_layer_norm_bwd":                 # row, dy (, g_res) in; dx out
+        return "hbm", esz * B * D * (4 if flag else 3)
     if kind.startswith("group_norm"):
         elems = B * N * D  # here H = groups, N = pixels, D = channels
         return "hbm", esz * elems * (2 if kind == "group_norm_fwd" else 3)

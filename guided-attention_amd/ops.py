@@ -66,7 +66,43 @@ def replay_launch_us(key, iters=100):
     dtype = {"torch.float16": torch.float16, "torch.bfloat16": torch.bfloat16, "torch.float32": torch.float32}[dt]
     dev = torch.device("cuda", torch.cuda.current_device())
     lib = load()
-    if kind.startswith("group_norm"):
+    if kind in ("geglu_fwd", "geglu_bwd", "bias_residual_add", "add_layer_norm_fwd", "add_layer_norm_bwd"):
+        rows, C = B, D
+        code = dtype_code(torch.empty(0, dtype=dtype))
+        t = lambda *shape: torch.randn(*shape, device=dev, dtype=dtype)  # noqa: E731
+        if kind.startswith("geglu"):
+            x, y, dy, dx = t(rows, 2 * C), t(rows, C), t(rows, C), t(rows, 2 * C)
+            if kind == "geglu_fwd":
+                def fn():
+                    check(lib.ga_geglu_fwd(_ptr(x), _ptr(y), rows, C, code, stream_ptr()), "replay geglu fwd")
+            else:
+                def fn():
+                    check(lib.ga_geglu_bwd(_ptr(x), _ptr(dy), _ptr(dx), rows, C, code, stream_ptr()), "replay geglu bwd")
+        elif kind == "bias_residual_add":
+            y, r, o, bias = t(rows, C), t(rows, C), t(rows, C), (t(C) if flag else None)
+
+            def fn():
+                check(lib.ga_bias_residual_add(_ptr(y), _ptr(bias), _ptr(r), _ptr(o), rows, C, code, stream_ptr()),
+                      "replay bias residual")
+        else:
+            a, x, w, b_ = t(rows, C), t(rows, C), t(C), t(C)
+            xn, y, dy, dx = t(rows, C), t(rows, C), t(rows, C), t(rows, C)
+            stats = torch.empty(rows, 2, device=dev, dtype=torch.float32)
+            check(lib.ga_add_layer_norm_fwd(_ptr(a), _ptr(x), _ptr(w), _ptr(b_), _ptr(xn), _ptr(y), _ptr(stats), rows, C,
+                                            1e-5, code, stream_ptr()), "replay ln")
+            if kind == "add_layer_norm_fwd":
+                a_arg = a if flag else None
+
+                def fn():
+                    check(lib.ga_add_layer_norm_fwd(_ptr(a_arg), _ptr(x), _ptr(w), _ptr(b_), _ptr(xn), _ptr(y), _ptr(stats),
+                                                    rows, C, 1e-5, code, stream_ptr()), "replay ln fwd")
+            else:
+                g_arg = a if flag else None
+
+                def fn():
+                    check(lib.ga_add_layer_norm_bwd(_ptr(xn), _ptr(stats), _ptr(w), _ptr(dy), _ptr(g_arg), _ptr(dx), rows,
+                                                    C, code, stream_ptr()), "replay ln bwd")
+    elif kind.startswith("group_norm"):
         groups, HW, C = H, N, D
         side_len = int(round(HW ** 0.5))
         x = torch.randn(B, C, side_len, HW // side_len, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
@@ -429,6 +465,7 @@ class Geglu(torch.autograd.Function):
         F2 = x.shape[-1]
         rows = x.numel() // F2
         y = torch.empty(x.shape[:-1] + (F2 // 2,), dtype=x.dtype, device=x.device)
+        _count(("geglu_fwd", rows, 0, 0, 0, F2 // 2, False, str(x.dtype)))
         check(load().ga_geglu_fwd(_ptr(x), _ptr(y), rows, F2 // 2, dtype_code(x), stream_ptr()), "ga_geglu_fwd")
         if ctx.needs_input_grad[0]:
             ctx.save_for_backward(x)
@@ -440,6 +477,7 @@ class Geglu(torch.autograd.Function):
         dy = dy.contiguous()
         F2 = x.shape[-1]
         dx = torch.empty_like(x)
+        _count(("geglu_bwd", x.numel() // F2, 0, 0, 0, F2 // 2, False, str(x.dtype)))
         check(load().ga_geglu_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.numel() // F2, F2 // 2, dtype_code(x), stream_ptr()),
               "ga_geglu_bwd")
         return dx
@@ -461,6 +499,7 @@ class BiasResidualAdd(torch.autograd.Function):
         y, residual = _nhwc(y), _nhwc(residual)
         B, C, H, W = y.shape
         out = torch.empty_like(y, memory_format=torch.channels_last)
+        _count(("bias_residual_add", B * H * W, 0, 0, 0, C, bias is not None, str(y.dtype)))
         check(load().ga_bias_residual_add(_ptr(y), _ptr(bias), _ptr(residual), _ptr(out), B * H * W, C, dtype_code(y),
                                           stream_ptr()), "ga_bias_residual_add")
         return out
@@ -485,6 +524,7 @@ def _ln_fwd(a, x, weight, bias, eps, need_stats):
     if a is not None:
         a = a.contiguous()
         xnew = torch.empty_like(x)
+    _count(("add_layer_norm_fwd", rows, 0, 0, 0, C, a is not None, str(x.dtype)))
     check(load().ga_add_layer_norm_fwd(_ptr(a), _ptr(x), _ptr(weight), _ptr(bias), _ptr(xnew), _ptr(y), _ptr(stats), rows,
                                        C, float(eps), dtype_code(x), stream_ptr()), "ga_add_layer_norm_fwd")
     return (x if a is None else xnew), y, stats
@@ -495,6 +535,7 @@ def _ln_bwd(row, stats, weight, g_y, g_res):
     g_y = g_y.contiguous()
     g_res = g_res.contiguous() if g_res is not None else None
     d = torch.empty_like(row)
+    _count(("add_layer_norm_bwd", row.numel() // C, 0, 0, 0, C, g_res is not None, str(row.dtype)))
     check(load().ga_add_layer_norm_bwd(_ptr(row), _ptr(stats), _ptr(weight), _ptr(g_y), _ptr(g_res), _ptr(d),
                                        row.numel() // C, C, dtype_code(row), stream_ptr()), "ga_add_layer_norm_bwd")
     return d
