@@ -205,29 +205,36 @@ __device__ __forceinline__ void rows_times_cols(const T* img, const typename Tra
   RowFrags<T, NK> fr[NS];
 #pragma unroll
   for (int rb = 0; rb < AHEAD && rb < NRB; ++rb) fr[rb % NS].load(row0 + rb * 16 * KS);
-#pragma unroll
-  for (int rb = 0; rb < NRB; ++rb) {
-    if (rb + AHEAD < NRB) fr[(rb + AHEAD) % NS].load(row0 + (rb + AHEAD) * 16 * KS);
+  // one k-step of one row block; an odd last chunk of a 16-bit type is the same 16x16x32 with the column operand's
+  // upper half zero (loop-invariant registers) and, on the row side, the chunk-0 fragment once more as a finite
+  // filler — no zeroing moves in the loop.  Do NOT chain a legacy v_mfma_f32_16x16x16_f16 onto a 16x16x32's
+  // accumulator: hipcc (ROCm 7.2) emits the pair back-to-back without the wait states the differing pass counts
+  // need, and the second MFMA reads a stale SrcC (wrong results).
+  auto step = [&](int rb, int kc) {
     const RowFrags<T, NK>& f = fr[rb % NS];
 #pragma unroll
-    for (int kc = 0; kc + 1 < NK; kc += 2)
+    for (int cb = 0; cb < CB; ++cb) {
+      if (kc + 1 < NK) acc[rb][cb] = Traits<T>::mma16x2(f.a[kc], f.a[kc + 1], x[cb][kc], x[cb][kc + 1], acc[rb][cb]);
+      else if constexpr (sizeof(T) == 2) acc[rb][cb] = Traits<T>::mma16x2(f.a[NK - 1], f.a[NK], x[cb][NK - 1], z, acc[rb][cb]);
+      else acc[rb][cb] = Traits<T>::mma16(f.a[NK - 1], x[cb][NK - 1], acc[rb][cb]);
+    }
+  };
+  if constexpr (AHEAD >= NRB) {
+    // every fragment is already on its way: sweep the k-steps over batches of 4 row blocks, so that an MFMA never
+    // waits for the one issued just before it (the two k-steps of a row block are a dependent chain)
+    constexpr int GRP = NRB < 4 ? NRB : 4;
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-        acc[rb][cb] = Traits<T>::mma16x2(f.a[kc], f.a[kc + 1], x[cb][kc], x[cb][kc + 1], acc[rb][cb]);
-    if (NK & 1) {
-      if constexpr (sizeof(T) == 2) {
-        // odd chunk: the same 16x16x32 with the column operand's upper half zero (loop-invariant registers) and, on
-        // the row side, the chunk-0 fragment once more as a finite filler — no zeroing moves in the loop.  Do NOT
-        // chain a legacy v_mfma_f32_16x16x16_f16 onto a 16x16x32's accumulator: hipcc (ROCm 7.2) emits the pair
-        // back-to-back without the wait states the differing pass counts need, and the second MFMA reads a stale
-        // SrcC (wrong results).
+    for (int rb0 = 0; rb0 < NRB; rb0 += GRP)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-          acc[rb][cb] = Traits<T>::mma16x2(f.a[NK - 1], f.a[NK], x[cb][NK - 1], z, acc[rb][cb]);
-      } else {
+      for (int kc = 0; kc < NK; kc += 2)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = Traits<T>::mma16(f.a[NK - 1], x[cb][NK - 1], acc[rb][cb]);
-      }
+        for (int rb = rb0; rb < rb0 + GRP && rb < NRB; ++rb) step(rb, kc);
+  } else {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      if (rb + AHEAD < NRB) fr[(rb + AHEAD) % NS].load(row0 + (rb + AHEAD) * 16 * KS);
+#pragma unroll
+      for (int kc = 0; kc < NK; kc += 2) step(rb, kc);
     }
   }
 }
