@@ -25,6 +25,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 META_PROMPT = "a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55]"
+META_PROMPT_SD21 = "a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55] under a [moon:.35,.05,.35,.35]"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -34,7 +35,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=2, help="timed guided images per GPU")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="default", choices=["default", "every-step"])
-    ap.add_argument("--model", default=os.environ.get("GA_BENCH_MODEL", "sd15"), choices=["sd15", "tiny"])
+    ap.add_argument("--model", default=os.environ.get("GA_BENCH_MODEL", "sd15"), choices=["sd15", "sd21", "tiny"],
+                    help="sd21 = BASELINE config 4: SD-2.1 UNet shapes at 768^2 (latent 96^2, maps 24x24), 3 box tokens")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--guidance-forward", default="full", choices=["full", "truncated"])
@@ -50,7 +52,7 @@ def build_pipeline(args, device, rank, world):
     from guided_attention_amd.pipeline_guided_attention import GuidedAttention
     from guided_attention_amd.text import SyntheticTextEncoder, WordTokenizer
     from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig
-    cfg = UNetConfig.sd15() if args.model == "sd15" else UNetConfig.tiny(64, 768)
+    cfg = {"sd15": UNetConfig.sd15, "sd21": UNetConfig.sd21}.get(args.model, lambda: UNetConfig.tiny(64, 768))()
     with torch.device(device):
         unet = UNet2DConditionModel(cfg)
     unet = unet.half()
@@ -73,8 +75,10 @@ def make_run(args, pipe, cfg, device):
     from guided_attention_amd import run
     from guided_attention_amd.config import RunConfig
     from guided_attention_amd.utils import helpers, ptp_utils, shared_state as state
-    rc = RunConfig(meta_prompt=META_PROMPT, output_path="/tmp/ga_bench_out", half_precision=True,
-                   n_inference_steps=args.ddim_steps)
+    rc = RunConfig(meta_prompt=META_PROMPT_SD21 if args.model == "sd21" else META_PROMPT,
+                   output_path="/tmp/ga_bench_out", half_precision=True, n_inference_steps=args.ddim_steps)
+    if args.model == "sd21":
+        rc.attention_res = cfg.sample_size // 4   # the 24x24 maps of the 96^2 latent (synthetic embeddings: no EOT slice)
     if args.workload == "every-step":
         rc.only_update_on_threshold_steps = False
         rc.max_iter_to_alter = 25
@@ -285,13 +289,14 @@ def main():
     if rank == 0:
         n_images = args.steps * world
         roof = roofline_entry(census, ops)
-        flops_per_fwd = 0.803e12 if args.model == "sd15" else None
+        flops_per_fwd = {"sd15": 0.803e12, "sd21": 2.149e12}.get(args.model)
         line = {
-            "metric": "guided images/sec (50-step SD-1.5 512^2)", "value": n_images / elapsed, "unit": "images/s",
+            "metric": ("guided images/sec (50-step SD-2.1 768^2)" if args.model == "sd21" else
+                       "guided images/sec (50-step SD-1.5 512^2)"), "value": n_images / elapsed, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"W-{args.workload}: SD-1.x UNet 512^2 (latent 64^2), {args.ddim_steps} DDIM steps, "
-                                   f"meta_prompt '{META_PROMPT}', guidance 7.5, thresholds {rc.thresholds}, 1 seed per step",
+            "config": {"workload": f"W-{args.workload}: {'SD-2.1 UNet 768^2 (latent 96^2)' if args.model == 'sd21' else 'SD-1.x UNet 512^2 (latent 64^2)'}, {args.ddim_steps} DDIM steps, "
+                                   f"meta_prompt '{rc.meta_prompt}', guidance 7.5, thresholds {rc.thresholds}, 1 seed per step",
                        "parallelism": f"seed-parallel x{world}", "guidance_forward": args.guidance_forward,
                        "skip_unused_guidance": args.skip_unused_guidance, "model": args.model,
                        "loss_only_steps": ("two passes (B=1 guidance, B=2 CFG)" if args.no_joint_pass or args.eager else
