@@ -52,7 +52,15 @@ class GraphRunner:
             self._fill_embeds3()
         self.loss_args = (smooth, sigma, ksize, normalize_eot)
         self.res = attention_res
+        # static copies of unet.time_projection(t, batch): the graphs read these instead of recomputing the
+        # timestep-only part of the UNet in every pass; `_set_t` refreshes them before a replay
+        self.tp = {n: torch.empty_like(pipe.unet.time_projection(981, n)) for n in ((1, 2, 3) if self.joint else (1, 2))}
         self._capture(store)
+
+    def _set_t(self, t, *batches):
+        self.t_dev.fill_(int(t))
+        for n in batches:
+            self.tp[n].copy_(self.pipe.unet.time_projection(int(t), n))
 
     def _fill_embeds3(self):
         if self.joint:  # [guidance: cond | CFG: uncond, cond]
@@ -64,7 +72,7 @@ class GraphRunner:
     def _eval_body(self, store):
         pipe = self.pipe
         with torch.enable_grad():
-            pipe._guidance_forward(self.lat_g, self.t_dev, self.embeds[1:2])
+            pipe._guidance_forward(self.lat_g, self.t_dev, self.embeds[1:2], time_projection=self.tp[1])
             A = aggregate_attention(store, self.res, ("up", "down", "mid"), True, 0)
             parts = pipe._loss_device(A, *self.loss_args)
         return parts, store.attention_store
@@ -75,13 +83,14 @@ class GraphRunner:
 
     def _cfg_body(self, store):
         with torch.no_grad():
-            out = self.pipe.unet(self.lat2, self.t_dev, encoder_hidden_states=self.embeds).sample
+            out = self.pipe.unet(self.lat2, self.t_dev, encoder_hidden_states=self.embeds,
+                                 time_projection=self.tp[2]).sample
         return out, store.attention_store
 
     def _joint_body(self, store):
         pipe = self.pipe
         with torch.no_grad():
-            out = pipe.unet(self.lat3, self.t_dev, encoder_hidden_states=self.embeds3).sample
+            out = pipe.unet(self.lat3, self.t_dev, encoder_hidden_states=self.embeds3, time_projection=self.tp[3]).sample
             # the guidance evaluation is sample 0: keep its head-maps only (the reference's guidance forward has batch 1)
             snap = {k: [p[: p.shape[0] // 3] for p in v] for k, v in store.attention_store.items()}
             store.attention_store = snap
@@ -91,7 +100,7 @@ class GraphRunner:
 
     def _capture(self, store):
         calls = dict(self.pipe.unet_calls)
-        self.t_dev.fill_(981)
+        self._set_t(981, *self.tp)
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -130,7 +139,7 @@ class GraphRunner:
             store.cur_step += 1
 
     def evaluate(self, latents, t, store):
-        self.t_dev.fill_(int(t))
+        self._set_t(t, 1)
         with torch.no_grad():
             self.lat_g.copy_(latents)
         self.g_eval.replay()
@@ -144,7 +153,7 @@ class GraphRunner:
         return self.grad
 
     def cfg_forward(self, latents, t, store):
-        self.t_dev.fill_(int(t))
+        self._set_t(t, 2)
         self.lat2[0].copy_(latents[0])
         self.lat2[1].copy_(latents[0])
         self.g_cfg.replay()
@@ -154,7 +163,7 @@ class GraphRunner:
 
     def joint_forward(self, latents, t, store):
         """-> (loss parts of the guidance evaluation, CFG noise prediction (2, ...)) from one batch-3 replay."""
-        self.t_dev.fill_(int(t))
+        self._set_t(t, 3)
         for j in range(3):
             self.lat3[j].copy_(latents[0])
         self.g_joint.replay()

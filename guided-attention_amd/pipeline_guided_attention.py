@@ -350,14 +350,15 @@ class GuidedAttention:
         self._deferred_log.append(("gradient size average: ", absmean))
         return new_latents
 
-    def _guidance_forward(self, latents, t, cond):
+    def _guidance_forward(self, latents, t, cond, time_projection=None):
         self.unet_calls["fwd_b1_grad"] += 1
         if self.guidance_forward == "truncated" and self._truncate_at is not None:
-            out = self.unet(latents, t, encoder_hidden_states=cond, stop_after_up_block=self._truncate_at).sample
+            out = self.unet(latents, t, encoder_hidden_states=cond, stop_after_up_block=self._truncate_at,
+                            time_projection=time_projection).sample
             if hasattr(self._attention_store, "flush"):
                 self._attention_store.flush()
             return out
-        return self.unet(latents, t, encoder_hidden_states=cond).sample
+        return self.unet(latents, t, encoder_hidden_states=cond, time_projection=time_projection).sample
 
     def _guidance_eval(self, latents, t, cond, attention_store, attention_res, smooth_attentions, sigma, kernel_size,
                        normalize_eot):

@@ -422,6 +422,45 @@ class UNet2DConditionModel(nn.Module):
         parts = F.linear(temb_act, w, bias).split(sizes, dim=1)
         return {id(b): p for b, p in zip(blocks, parts)}
 
+    def time_projection(self, timestep, batch):
+        """Everything the UNet derives from the timestep alone — sinusoid, the 2-layer time MLP, SiLU and the 22
+        per-block projections (with conv1's bias) — as ONE flat buffer laid out block-major, [block][batch][C_block],
+        so that every ResnetBlock2D gets a contiguous (batch, C) view.  It depends on the timestep and on frozen
+        weights only, so it is computed once per (timestep, batch) and kept (the reference recomputes ~15 small
+        kernels per UNet call; with batch > 1 the per-block column slices of a row-major projection also cost one
+        copy each).  Inference-time only: the cache is bypassed while any time-embedding weight requires grad."""
+        blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        tw = [self.time_embedding.linear_1.weight, self.time_embedding.linear_1.bias, self.time_embedding.linear_2.weight,
+              self.time_embedding.linear_2.bias]
+        wkey = tuple((p.data_ptr(), p._version) for p in tw) + tuple(
+            (b.time_emb_proj.weight.data_ptr(), b.time_emb_proj.weight._version, b.time_emb_proj.bias._version,
+             b.conv1.bias._version) for b in blocks)
+        cache = self.__dict__.setdefault("_tp_cache", {"key": None, "items": {}})
+        if cache["key"] != wkey:
+            cache["key"], cache["items"] = wkey, {}
+        k = (float(timestep), int(batch), self.dtype)
+        flat = cache["items"].get(k)
+        if flat is None:
+            with torch.no_grad():
+                t = torch.tensor([timestep], dtype=torch.int64 if float(timestep).is_integer() else torch.float64,
+                                 device=self.device)
+                t_emb = timestep_embedding(t, self.config.block_out_channels[0]).to(self.dtype)
+                parts = self._time_projections(F.silu(self.time_embedding(t_emb)))
+                flat = torch.cat([parts[id(b)].expand(batch, -1).reshape(-1) for b in blocks])
+            cache["items"][k] = flat
+        return flat
+
+    def _split_time_projection(self, flat, batch):
+        blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        out, off = {}, 0
+        for b in blocks:
+            c = b.time_emb_proj.out_features
+            out[id(b)] = flat[off:off + batch * c].view(batch, c)
+            off += batch * c
+        if off != flat.numel():
+            raise ValueError(f"time projection buffer has {flat.numel()} elements, expected {off} for batch {batch}")
+        return out
+
     def set_norm_impl(self, impl):
         """Install (or with None remove) the GroupNorm(+SiLU) implementation of every norm layer."""
         for m in self.modules():
@@ -448,22 +487,30 @@ class UNet2DConditionModel(nn.Module):
         return self.conv_in.weight.device
 
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
-                cross_attention_kwargs=None, return_dict=True, stop_after_up_block=None):
+                cross_attention_kwargs=None, return_dict=True, stop_after_up_block=None, time_projection=None):
         """stop_after_up_block = (i, n): run up_blocks[:i] fully and only the first n layers of up_blocks[i],
-        then return sample=None — everything after the last attention map the loss consumes is skipped."""
+        then return sample=None — everything after the last attention map the loss consumes is skipped.
+        time_projection: the flat buffer of `time_projection(timestep, batch)` (then `timestep` is not read); a Python
+        number as `timestep` uses the cached buffer by itself when the time-embedding weights are frozen."""
         cfg = self.config
         up_factor = 2 ** self.num_upsamplers
         forward_upsample_size = any(s % up_factor != 0 for s in sample.shape[-2:])
         if cfg.center_input_sample:
             sample = 2 * sample - 1.0
-        if not torch.is_tensor(timestep):
-            timestep = torch.tensor([timestep], dtype=torch.int64 if isinstance(timestep, int) else torch.float64,
-                                    device=sample.device)
-        elif timestep.dim() == 0:
-            timestep = timestep[None].to(sample.device)
-        timestep = timestep.expand(sample.shape[0])
-        t_emb = timestep_embedding(timestep, cfg.block_out_channels[0]).to(self.dtype)
-        temb_act = self._time_projections(F.silu(self.time_embedding(t_emb)))
+        if time_projection is None and not torch.is_tensor(timestep) and sample.is_cuda and \
+                not self.time_embedding.linear_1.weight.requires_grad:
+            time_projection = self.time_projection(timestep, sample.shape[0])
+        if time_projection is not None:
+            temb_act = self._split_time_projection(time_projection, sample.shape[0])
+        else:
+            if not torch.is_tensor(timestep):
+                timestep = torch.tensor([timestep], dtype=torch.int64 if isinstance(timestep, int) else torch.float64,
+                                        device=sample.device)
+            elif timestep.dim() == 0:
+                timestep = timestep[None].to(sample.device)
+            timestep = timestep.expand(sample.shape[0])
+            t_emb = timestep_embedding(timestep, cfg.block_out_channels[0]).to(self.dtype)
+            temb_act = self._time_projections(F.silu(self.time_embedding(t_emb)))
 
         x = self.conv_in(sample)
         skips = [x]
