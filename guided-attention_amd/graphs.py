@@ -91,11 +91,14 @@ class GraphRunner:
         pipe = self.pipe
         with torch.no_grad():
             out = pipe.unet(self.lat3, self.t_dev, encoder_hidden_states=self.embeds3, time_projection=self.tp[3]).sample
-            # the guidance evaluation is sample 0: keep its head-maps only (the reference's guidance forward has batch 1)
-            snap = {k: [p[: p.shape[0] // 3] for p in v] for k, v in store.attention_store.items()}
-            store.attention_store = snap
+            # the guidance evaluation is sample 0: the loss reads its head-maps only (the reference's guidance forward
+            # has batch 1); what stays published afterwards is what the CFG pass would have left: samples 1 and 2
+            full = store.attention_store
+            store.attention_store = {k: [p[: p.shape[0] // 3] for p in v] for k, v in full.items()}
             A = aggregate_attention(store, self.res, ("up", "down", "mid"), True, 0)
             parts = pipe._loss_device(A, *self.loss_args)
+            snap = {k: [p[p.shape[0] // 3:] for p in v] for k, v in full.items()}
+            store.attention_store = snap
         return out, parts, snap
 
     def _capture(self, store):

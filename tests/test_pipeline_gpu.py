@@ -95,6 +95,8 @@ def test_variants_are_result_identical(variant):
         # pair of a step share one batch-3 pass
         assert {k: out.unet_calls[k] for k in MAIN_CALLS} == {k: base.unet_calls[k] for k in MAIN_CALLS}
         assert (out.unet_calls["joint_b3"] > 0) == joint and base.unet_calls["joint_b3"] == 0
+        # after the run the store holds the maps of the last CFG evaluation (uncond + cond), however it was batched
+        assert ctrl.attention_store["up_cross"][0].shape[0] == 2 * 2
         assert {k: len(v) for k, v in ctrl.attention_store.items() if v} == {"down_cross": 2, "up_cross": 3}
         out2, _ = run_product(pipe, meta, embeds, lat0, noise, thr, use_graphs=True, guidance_forward=mode,
                               batch_loss_only_guidance=joint)  # cached graphs
