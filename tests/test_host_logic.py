@@ -218,3 +218,35 @@ def test_pipeline_surface_and_loud_failures():
     state.curHyperParams = dict(state.hyperParameterOverrides)
     with pytest.raises(GaError):
         pipe.unet(torch.zeros(1, 4, 32, 32), 981, encoder_hidden_states=torch.zeros(1, 77, 48))
+
+
+def test_time_projection_buffer_equals_the_in_forward_computation():
+    """The cached timestep-only buffer (sinusoid -> time MLP -> SiLU -> per-block projections, block-major) must be
+    what the UNet computes inside its forward, for any batch, and must follow weight changes."""
+    import torch
+    from guided_attention_amd.unet import ResnetBlock2D, UNet2DConditionModel, UNetConfig
+    unet = UNet2DConditionModel(UNetConfig.tiny(16, 32)).init_weights_(seed=3).float()
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    from oracle.attention import OracleStore
+    from oracle.pipeline import install_processors
+    install_processors(unet, OracleStore())  # the product's attention refuses the CPU; the checker's processors run here
+    x = torch.from_numpy(np.random.default_rng(0).standard_normal((2, 4, 16, 16)).astype(np.float32))
+    ctx = torch.from_numpy(np.random.default_rng(1).standard_normal((2, 77, 32)).astype(np.float32))
+    ref = unet(x, 481, encoder_hidden_states=ctx).sample                       # CPU: computes the projection in place
+    flat = unet.time_projection(481, 2)
+    blocks = [m for m in unet.modules() if isinstance(m, ResnetBlock2D)]
+    assert flat.numel() == 2 * sum(b.time_emb_proj.out_features for b in blocks)
+    out = unet(x, torch.tensor(0), encoder_hidden_states=ctx, time_projection=flat).sample  # timestep is not read
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+    assert unet.time_projection(481, 2) is flat                                  # cached per (timestep, batch)
+    assert unet.time_projection(481, 1).numel() * 2 == flat.numel()
+    with pytest.raises(ValueError):
+        unet(x, 481, encoder_hidden_states=ctx, time_projection=unet.time_projection(481, 1))
+    with torch.no_grad():
+        blocks[0].time_emb_proj.weight.mul_(-1.5)                                # a weight changes -> new buffer
+    flat2 = unet.time_projection(481, 2)
+    assert flat2 is not flat and not torch.equal(flat2, flat)
+    ref2 = unet(x, 481, encoder_hidden_states=ctx).sample
+    out2 = unet(x, 481, encoder_hidden_states=ctx, time_projection=flat2).sample
+    assert torch.allclose(out2, ref2, rtol=1e-5, atol=1e-6) and not torch.allclose(ref2, ref)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU time of the three captured passes of the guided-attention loop for the SD-1.x UNet (hipGraph replay,
 so host launch cost is excluded): guidance forward + loss (B=1, autograd), its backward to the latents, and
-the CFG forward (B=2).  usage: unet_bench.py [truncated] [nhwc-off]"""
+the CFG forward (B=2), the batch-3 joint pass.  usage: unet_bench.py [truncated] [nhwc-off] [benchmark] [only=eval|grad|cfg|joint]"""
 import sys
 from pathlib import Path
 
@@ -51,9 +51,16 @@ def main():
     emb = torch.randn(2, 77, 768, device="cuda", dtype=torch.half)
     lat = torch.randn(1, 4, 64, 64, device="cuda", dtype=torch.half)
     r = GraphRunner(pipe, store, emb, lat, 16, True, 0.5, 3, False)
+    only = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("only=")), None)
+    if only:  # for rocprofv3: one pass replayed 60 times dominates the kernel statistics
+        g = {"eval": r.g_eval, "grad": r.g_grad, "cfg": r.g_cfg, "joint": getattr(r, "g_joint", None)}[only]
+        print(f"{only}: {replay_ms(g, 60):7.3f} ms")
+        return
     print(f"guidance forward + loss (B=1): {replay_ms(r.g_eval):7.3f} ms")
     print(f"backward to the latents      : {replay_ms(r.g_grad):7.3f} ms")
     print(f"CFG forward (B=2)            : {replay_ms(r.g_cfg):7.3f} ms")
+    if getattr(r, "g_joint", None) is not None:
+        print(f"joint pass (B=3) + loss      : {replay_ms(r.g_joint):7.3f} ms")
 
 
 if __name__ == "__main__":
