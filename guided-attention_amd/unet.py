@@ -452,13 +452,14 @@ class UNet2DConditionModel(nn.Module):
 
     def _split_time_projection(self, flat, batch):
         blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        want = batch * sum(b.time_emb_proj.out_features for b in blocks)
+        if flat.numel() != want:
+            raise ValueError(f"time projection buffer has {flat.numel()} elements, expected {want} for batch {batch}")
         out, off = {}, 0
         for b in blocks:
             c = b.time_emb_proj.out_features
             out[id(b)] = flat[off:off + batch * c].view(batch, c)
             off += batch * c
-        if off != flat.numel():
-            raise ValueError(f"time projection buffer has {flat.numel()} elements, expected {off} for batch {batch}")
         return out
 
     def set_norm_impl(self, impl):
