@@ -28,15 +28,24 @@ using Lds = TileLds<T, NT * 16>;
 // Stage one (batch, head) slice [key][D] of a [B][Kt][H][D] projection into LDS as a row-major image and/or a
 // transposed image; padding keys / columns are zero-filled.  All global loads of a pass are issued before the
 // first LDS store (one L2 round trip per pass instead of one per vector); up to two sources share a pass.
-template <typename T, int NT, int NTHREADS>
+// The "column image" (tr*) is the one whose ROWS are the contraction index of the second product (V in P.V, K in
+// dS.K): a transposed [d][key] image for f32, a row-major image with row stride trs<NK>() read through
+// ds_read_b64_tr_b16 for the 16-bit types (attn_common.h) — no 2-byte scatter stores.
+template <typename T, int NT, int NK>
+__host__ __device__ constexpr int col_image_elems() {
+  return kTrRead<T> ? NT * 16 * trs<NK>() : Lds<T, NT>::tr_size(NK * 16);
+}
+
+template <typename T, int NT, int NK, int NTHREADS>
 __device__ __forceinline__ void stage_kv2(const T* __restrict__ srcA, T* rowA, T* trA, const T* __restrict__ srcB,
-                                          T* rowB, T* trB, int H, int Kt, int D, int DP) {
+                                          T* rowB, T* trB, int H, int Kt, int D) {
   constexpr int VEC = Lds<T, NT>::VEC;
   constexpr int KP = Lds<T, NT>::KP;
   constexpr int UNROLL = 4;
-  const int KS = Lds<T, NT>::ks(DP);
-  const int vpr = DP / VEC;  // vectors per row
-  const int total = KP * vpr;
+  constexpr int DP = NK * 16;
+  constexpr int KS = DP + VEC;
+  constexpr int vpr = DP / VEC;  // vectors per row
+  constexpr int total = KP * vpr;
   for (int base = 0; base < total; base += NTHREADS * UNROLL) {
     uint4 a[UNROLL], b[UNROLL];
 #pragma unroll
@@ -61,33 +70,71 @@ __device__ __forceinline__ void stage_kv2(const T* __restrict__ srcA, T* rowA, T
       const int d = (idx - key * vpr) * VEC;
       if (rowA) *reinterpret_cast<uint4*>(rowA + key * KS + d) = a[u];
       if (rowB) *reinterpret_cast<uint4*>(rowB + key * KS + d) = b[u];
-      const T* ea = reinterpret_cast<const T*>(&a[u]);
-      const T* eb = reinterpret_cast<const T*>(&b[u]);
-      if (trA) {
+      if constexpr (kTrRead<T>) {
+        if (trA) *reinterpret_cast<uint4*>(trA + key * trs<NK>() + d) = a[u];
+        if (trB) *reinterpret_cast<uint4*>(trB + key * trs<NK>() + d) = b[u];
+      } else {
+        const T* ea = reinterpret_cast<const T*>(&a[u]);
+        const T* eb = reinterpret_cast<const T*>(&b[u]);
+        if (trA) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) trA[Lds<T, NT>::tr(d + i) + key] = ea[i];
-      }
-      if (trB) {
+          for (int i = 0; i < VEC; ++i) trA[Lds<T, NT>::tr(d + i) + key] = ea[i];
+        }
+        if (trB) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) trB[Lds<T, NT>::tr(d + i) + key] = eb[i];
+          for (int i = 0; i < VEC; ++i) trB[Lds<T, NT>::tr(d + i) + key] = eb[i];
+        }
       }
     }
   }
 }
 
 // S^T tiles: acc[t][r] = sum_d Kimg[16t + 4g + r][d] * X[q][d]   (X = Q or dO row of this lane's query)
+// k-chunks go through the MFMA in pairs (one 16x16x32 does the work of two 16x16x16 in the same cycles on gfx950);
+// an odd last chunk of a 16-bit type is the same instruction with the column operand's upper half zero and the
+// chunk-0 fragment as a finite filler on the row side (never a legacy 16x16x16 chained onto a 16x16x32: self_attn.hip).
 template <typename T, int NT, int NK>
 __device__ __forceinline__ void qk_tiles(const typename Traits<T>::frag (&x)[NK], const T* kimg, int KS, int c, int g,
                                          f32x4 (&acc)[NT]) {
   using Tr = Traits<T>;
+  const typename Tr::frag z = zero_frag<T>();
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kc = 0; kc < NK; ++kc) {
-    const int d = (kc << 4) + (g << 2);
+  for (int kc = 0; kc < NK; kc += 2) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = Tr::mma16(load_frag<T>(kimg + (t * 16 + c) * KS + d), x[kc], acc[t]);
+    for (int t = 0; t < NT; ++t) {
+      const T* row = kimg + (t * 16 + c) * KS + 4 * g;
+      if (kc + 1 < NK) acc[t] = Tr::mma16x2(lds_frag<T>(row + kc * 16), lds_frag<T>(row + kc * 16 + 16), x[kc], x[kc + 1], acc[t]);
+      else if constexpr (sizeof(T) == 2) acc[t] = Tr::mma16x2(lds_frag<T>(row + kc * 16), lds_frag<T>(row), x[kc], z, acc[t]);
+      else acc[t] = Tr::mma16(load_frag<T>(row + kc * 16), x[kc], acc[t]);
+    }
   }
+}
+
+// out^T[d block dt][this lane's query] = sum over the NT key blocks of ColImg^T . F   (O^T = V^T P^T, dQ^T = K^T dS^T)
+template <typename T, int NT, int NK>
+__device__ __forceinline__ f32x4 keys_times_frags(const T* colimg, const typename Traits<T>::frag (&f)[NT], int dt,
+                                                  int lane) {
+  using Tr = Traits<T>;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (kTrRead<T>) {
+    constexpr int S = trs<NK>();
+    const int i = lane & 15;
+    const T* base = colimg + (4 * (lane >> 4) + (i >> 2)) * S + 4 * (i & 3) + dt * 16;
+    const typename Tr::frag z = zero_frag<T>();
+#pragma unroll
+    for (int t = 0; t < NT; t += 2) {
+      const typename Tr::frag a0 = tr_read<T>(base + t * 16 * S);
+      if (t + 1 < NT) o = Tr::mma16x2(a0, tr_read<T>(base + (t + 1) * 16 * S), f[t], f[t + 1], o);
+      else o = Tr::mma16x2(a0, a0, f[t], z, o);  // odd block count: finite filler x zero
+    }
+  } else {
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) o = Tr::mma16(load_frag<T>(colimg + Lds<T, NT>::tr(dt * 16 + c) + t * 16 + 4 * g), f[t], o);
+  }
+  return o;
 }
 
 // in place: acc (raw q.k) -> normalised probabilities (f32); keys >= Kt get 0
@@ -107,7 +154,7 @@ __device__ __forceinline__ void softmax_keys(f32x4 (&acc)[NT], int Kt, int g, fl
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float p = (t * 16 + 4 * g + r < Kt) ? exp2f((acc[t][r] - m) * c1) : 0.f;
+      const float p = (t * 16 + 4 * g + r < Kt) ? __builtin_amdgcn_exp2f((acc[t][r] - m) * c1) : 0.f;  // arg <= 0
       acc[t][r] = p;
       sum += p;
     }
@@ -131,8 +178,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_fwd_kernel(const T* _
   const int KS = Lds<T, NT>::ks(DP);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Ks = reinterpret_cast<T*>(smem);  // [KP][KS]
-  T* Vt = Ks + KP * KS;                // [DP][VS]
-  T* Pst = Vt + Lds<T, NT>::tr_size(DP);  // [ROWS][Kt] (only when P != nullptr)
+  T* Vt = Ks + KP * KS;                // V column image
+  T* Pst = Vt + col_image_elems<T, NT, NK>();  // [ROWS][Kt] (only when P != nullptr)
 
   const int b = blockIdx.z, head = blockIdx.y, q_wg = blockIdx.x * ROWS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
@@ -142,7 +189,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_fwd_kernel(const T* _
   const size_t row_off = (((size_t)b * N + (ok ? q : 0)) * H + head) * D;
   typename Tr::frag xq[NK];
   load_row_frags<T, NK>(Q + row_off, ok, D, g, xq);  // in flight while K/V are staged
-  stage_kv2<T, NT, WAVES * 64>(K + kv_off, Ks, nullptr, V + kv_off, nullptr, Vt, H, Kt, D, DP);
+  stage_kv2<T, NT, NK, WAVES * 64>(K + kv_off, Ks, nullptr, V + kv_off, nullptr, Vt, H, Kt, D);
   __syncthreads();
 
   f32x4 acc[NT];
@@ -167,10 +214,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_fwd_kernel(const T* _
   }
 
   T* orow = O + row_off;
-  for (int dt = 0; dt < NK; ++dt) {
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NT; ++t) o = Tr::mma16(load_frag<T>(Vt + Lds<T, NT>::tr(dt * 16 + c) + t * 16 + 4 * g), pf[t], o);
+  for (int dt = 0; dt < NK; ++dt) {
+    const f32x4 o = keys_times_frags<T, NT, NK>(Vt, pf, dt, lane);
     const int d = (dt << 4) + (g << 2);  // o[r] = O[q][d + r]
     if (ok && d < D) {
       typename Tr::frag of;
@@ -210,7 +256,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Ks = reinterpret_cast<T*>(smem);  // [KP][KS]   K row-major  (scores)
   T* Vs = Ks + KP * KS;                // [KP][KS]   V row-major  (dP = dO V^T)
-  T* Ktr = Vs + KP * KS;               // [DP][VS]   K transposed (dQ = dS K)
+  T* Ktr = Vs + KP * KS;               // K column image (dQ = dS K)
 
   const int b = blockIdx.z, head = blockIdx.y, q_wg = blockIdx.x * ROWS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
@@ -221,7 +267,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
   typename Tr::frag xq[NK], xdo[NK];
   load_row_frags<T, NK>(Q + row_off, ok, D, g, xq);
   load_row_frags<T, NK>(dO + row_off, ok, D, g, xdo);
-  stage_kv2<T, NT, WAVES * 64>(K + kv_off, Ks, Ktr, V + kv_off, Vs, nullptr, H, Kt, D, DP);
+  stage_kv2<T, NT, NK, WAVES * 64>(K + kv_off, Ks, Ktr, V + kv_off, Vs, nullptr, H, Kt, D);
   __syncthreads();
 
   f32x4 p[NT], dp[NT];
@@ -279,10 +325,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
     for (int r = 0; r < 4; ++r) dsf[t][r] = Tr::from_f32(p[t][r]);
 
   T* orow = dQ + row_off;
-  for (int dt = 0; dt < NK; ++dt) {
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NT; ++t) o = Tr::mma16(load_frag<T>(Ktr + Lds<T, NT>::tr(dt * 16 + c) + t * 16 + 4 * g), dsf[t], o);
+  for (int dt = 0; dt < NK; ++dt) {
+    const f32x4 o = keys_times_frags<T, NT, NK>(Ktr, dsf, dt, lane);
     const int d = (dt << 4) + (g << 2);
     if (ok && d < D) {
       typename Tr::frag of;
@@ -293,14 +338,14 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
   }
 }
 
-template <typename T, int NT>
-size_t fwd_lds_bytes(int DP, int Kt, int waves, bool withP) {
-  return sizeof(T) * ((size_t)Lds<T, NT>::KP * Lds<T, NT>::ks(DP) + (size_t)Lds<T, NT>::tr_size(DP) +
+template <typename T, int NT, int NK>
+size_t fwd_lds_bytes(int Kt, int waves, bool withP) {
+  return sizeof(T) * ((size_t)Lds<T, NT>::KP * Lds<T, NT>::ks(NK * 16) + (size_t)col_image_elems<T, NT, NK>() +
                       (withP ? (size_t)waves * 16 * Kt : 0));
 }
-template <typename T, int NT>
-size_t bwd_lds_bytes(int DP) {
-  return sizeof(T) * (2 * (size_t)Lds<T, NT>::KP * Lds<T, NT>::ks(DP) + (size_t)Lds<T, NT>::tr_size(DP));
+template <typename T, int NT, int NK>
+size_t bwd_lds_bytes() {
+  return sizeof(T) * (2 * (size_t)Lds<T, NT>::KP * Lds<T, NT>::ks(NK * 16) + (size_t)col_image_elems<T, NT, NK>());
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -311,7 +356,7 @@ template <typename T, int NT, int NK>
 int launch_fwd_nk(const void* Q, const void* K, const void* V, void* O, void* P, int B, int H, int N, int Kt, int D,
                   float scale, hipStream_t s) {
   const int DP = NK * 16;
-  const size_t lds = fwd_lds_bytes<T, NT>(DP, Kt, 4, P != nullptr);
+  const size_t lds = fwd_lds_bytes<T, NT, NK>(Kt, 4, P != nullptr);
   if (lds > kLdsLimit) return GA_ERR_SHAPE;
   dim3 grid((N + 63) / 64, H, B);
   auto k = attn_capture_fwd_kernel<T, NT, 4, NK>;
@@ -326,7 +371,7 @@ template <typename T, int NT, int NK>
 int launch_bwd_nk(const void* Q, const void* K, const void* V, const void* dO, const void* dP, int64_t sb, int64_t sn,
                   void* dQ, int B, int H, int N, int Kt, int D, float scale, hipStream_t s) {
   const int DP = NK * 16;
-  const size_t lds = bwd_lds_bytes<T, NT>(DP);
+  const size_t lds = bwd_lds_bytes<T, NT, NK>();
   if (lds > kLdsLimit) return GA_ERR_SHAPE;
   dim3 grid((N + 63) / 64, H, B);
   auto k = attn_capture_bwd_kernel<T, NT, 4, NK>;

@@ -144,40 +144,9 @@ __host__ __device__ constexpr int tr_img() {
   return NK * 16 * TL<T, KT>::VS + TL<T, KT>::ROT * (NK * 16 / TL<T, KT>::VEC);
 }
 
-// 16-bit tiles whose rows are the contraction index of a product (V in P.V, K in dS.K, Q / dO in the dK / dV sums)
-// stay ROW-major in LDS and are read with gfx950's transposing ds_read_b64_tr_b16: no second, transposed image, no
-// 2-byte scatter stores.  Row stride TRS = DP rounded up to an odd multiple of 16 elements (8 dwords): the 8 rows x
-// 8 dwords a 32-lane half touches per read then tile the 64 banks exactly.
-template <int NK>
-__host__ __device__ constexpr int trs() { return NK * 16 + ((NK & 1) ? 0 : 16); }
-template <typename T>
-constexpr bool kTrRead = sizeof(T) == 2;
-
-template <typename T>
-__device__ __forceinline__ typename Traits<T>::frag tr_read(const T* p) {
-  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
-  return __builtin_bit_cast(typename Traits<T>::frag, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p));
-}
-
 // acc[rb][cb] += Img[rb*16 + .][:] . X[cb][:]   (rows of the LDS image on accumulator rows, this lane's column
 // fragments X in registers);  NRB row blocks of 16, CB column blocks.  k-chunks go through the MFMA in pairs
 // (16x16x32: twice the work of a 16x16x16 in the same cycles).
-// 8-byte LDS fragment read the compiler may not fuse with its neighbours.  Left alone, hipcc pairs adjacent 8-byte
-// reads into ds_read2_b64 across UNRELATED fragments: half the LDS rate (128 B/clk, 32-bank rule -> the padded rows
-// conflict 2-way), an address add per row block (8-bit offsets) and two v_mov per MFMA to reassemble the operands —
-// a quarter of the forward loop's VALU instructions.  A volatile access is never merged; ds_read_b64 runs at
-// 256 B/clk, conflict-free on these images, with a 16-bit immediate offset, straight into the operand registers.
-template <typename T>
-__device__ __forceinline__ typename Traits<T>::frag lds_frag(const T* p) {
-  if constexpr (sizeof(T) == 2) {
-    typedef const volatile __attribute__((address_space(3))) unsigned long long* lds_ptr;  // keep it a ds_ access
-    const unsigned long long v = *(lds_ptr)p;
-    return __builtin_bit_cast(typename Traits<T>::frag, v);
-  } else {
-    return load_frag<T>(p);
-  }
-}
-
 // One row block's fragments: NK chunks, plus (16-bit types, odd NK) the chunk-0 fragment once more as the finite
 // filler that pairs with the odd chunk.
 template <typename T, int NK>
