@@ -475,7 +475,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
       const T* vimg = kimg + kVoff;
       // 16 queries per wave leave the registers for whole-tile read-ahead (K before the score MFMAs, V under the
       // softmax); the 32-query variant keeps the depth-2 pipelines
-      constexpr bool kAhead = kTrRead<T> && QB == 1 && NK <= 5;
+      constexpr bool kAhead = kTrRead<T> && ((QB == 1 && NK <= 5) || (QB == 2 && NK <= 3));
       rows_times_cols<T, NK, KT / 16, QB, kAhead ? KT / 16 : 1>(kimg, qf, c, g, s);
       ColFrags<T, NK, kAhead ? KT / 16 : 2> vfr;
       if constexpr (kAhead) vfr.load(vimg, lane);
@@ -905,13 +905,15 @@ size_t dkdv_lds() {
 constexpr size_t kLdsLimit = 160 * 1024;
 
 // Columns (queries, or keys in dk_dv) per wave = 16 * CB.  CB = 2 halves the LDS operand traffic per MFMA but needs
-// ~200 VGPRs and halves the number of workgroups; at batch 1-2 the layers only have 1024-2048 column blocks in all,
-// and a lone wave per SIMD cannot hide its own MFMA / LDS / exp latencies.  Measured on the 4096-token layer:
-// B = 1: CB = 1 116 us vs CB = 2 139 us; B = 2: CB = 2 170 us vs CB = 1 254 us.  Hence: CB = 2 only when it still
-// leaves >= 512 workgroups (2 per CU) and the head is small enough for the register budget.
+// more registers and halves the number of workgroups; at batch 1 the 64x64 layer only has 2048 column blocks in
+// all.  Measured (fp16, us, final round-1 kernels):
+//   forward   4096x40: B=1 CB=1 65.9 / CB=2 62.8;  B=2 CB=2 97 (CB=1 ~128);  1024x80: B=3 CB=1 28.6 / CB=2 23.6
+//             (384 workgroups of 86 KB LDS = two rounds of one per CU), B<=2 CB=1 better
+//   backward  4096x40: B=1 CB=1 236 / CB=2 245
+// Hence CB = 2 from 192 column-block pairs per launch in the forward, from 512 in the backward.
 template <int NK>
-bool wide_columns(int B, int H, int N) {
-  return NK <= 5 && (long long)B * H * ((N + 127) / 128) >= 512;
+bool wide_columns(int B, int H, int N, bool backward) {
+  return NK <= 5 && (long long)B * H * ((N + 127) / 128) >= (backward ? 512 : 192);
 }
 
 template <typename T, int NK, int QB>
@@ -934,7 +936,7 @@ template <typename T, int NK>
 int launch_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D, int ldq,
                float scale, hipStream_t s) {
   if constexpr (NK <= 5) {
-    if (wide_columns<NK>(B, H, N)) return launch_fwd_cb<T, NK, 2>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
+    if (wide_columns<NK>(B, H, N, false)) return launch_fwd_cb<T, NK, 2>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
   }
   return launch_fwd_cb<T, NK, 1>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
 }
@@ -969,7 +971,7 @@ int launch_bwd(const void* Q, const void* K, const void* V, const void* O, const
                float* delta, void* dQ, void* dK, void* dV, int B, int H, int N, int D, int ldq, float scale,
                hipStream_t s) {
   if constexpr (NK <= 5) {
-    if (wide_columns<NK>(B, H, N))
+    if (wide_columns<NK>(B, H, N, true))
       return launch_bwd_cb<T, NK, 2>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);
   }
   return launch_bwd_cb<T, NK, 1>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);

@@ -41,7 +41,7 @@ if __name__ == "__main__" and "--self-attn" not in sys.argv and "--group-norm" n
 def self_attn_bench():
     import torch
     print(f"\n{'self-attn':12s} {'B':>2s} {'N':>5s} {'D':>4s} {'fwd us':>8s} {'TF/s':>7s} {'bwd us':>8s} {'TF/s':>7s}   (SDPA fwd us, bwd us)")
-    for B, N, D in ((1, 4096, 40), (2, 4096, 40), (1, 1024, 80), (2, 1024, 80)) + (() if "--no160" in sys.argv else ((1, 256, 160), (1, 64, 160))):
+    for B, N, D in ((1, 4096, 40), (2, 4096, 40), (3, 4096, 40), (1, 1024, 80), (2, 1024, 80), (3, 1024, 80)) + (() if "--no160" in sys.argv else ((1, 256, 160), (1, 64, 160))):
         H = 8
         q, k, v, do = (torch.randn(B, N, H * D, device="cuda", dtype=torch.half) for _ in range(4))
         o, lse = ops.self_attn_fwd(q, k, v, H, D ** -0.5)
