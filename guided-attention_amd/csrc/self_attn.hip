@@ -4,10 +4,10 @@
 // fp16, x5 layers, kept alive by autograd); here P never leaves the registers.
 //
 //   forward  : O = softmax(scale Q K^T) V, plus LSE (per query, log2 domain) for the backward
-//   backward : recompute-based, two kernels without atomics (deterministic):
+//   backward : recompute-based, two kernels without atomics (deterministic; delta is taken in the first one):
 //                dq    : per query block, sweeps the key tiles:  dQ  = scale * sum_k dS K
 //                dk_dv : per key block, sweeps the query tiles:  dV = P^T dO,  dK = scale * dS^T Q
-//              with dS = P o (dO V^T - delta), delta = rowsum(dO o O) (prep kernel).
+//              with dS = P o (dO V^T - delta), delta = rowsum(dO o O) (taken by the dq kernel from its own fragments).
 //
 // gfx950 mapping (same transposed-score trick as attn_capture.hip): a wave owns QB x 16 queries (dq / forward) or
 // QB x 16 keys (dk_dv) ON ITS LANES; the swept tile (64 rows) sits in LDS as a bank-padded row-major image and/or a
@@ -183,9 +183,13 @@ __device__ __forceinline__ void rows_times_cols(const T* img, const typename Tra
     const RowFrags<T, NK>& f = fr[rb % NS];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
-      if (kc + 1 < NK) acc[rb][cb] = Traits<T>::mma16x2(f.a[kc], f.a[kc + 1], x[cb][kc], x[cb][kc + 1], acc[rb][cb]);
-      else if constexpr (sizeof(T) == 2) acc[rb][cb] = Traits<T>::mma16x2(f.a[NK - 1], f.a[NK], x[cb][NK - 1], z, acc[rb][cb]);
-      else acc[rb][cb] = Traits<T>::mma16(f.a[NK - 1], x[cb][NK - 1], acc[rb][cb]);
+      if (kc + 1 < NK) {
+        acc[rb][cb] = Traits<T>::mma16x2(f.a[kc], f.a[kc + 1], x[cb][kc], x[cb][kc + 1], acc[rb][cb]);
+      } else if constexpr ((NK & 1) != 0) {  // the odd last chunk
+        constexpr int L = RowFrags<T, NK>::NF - 1;  // index of the filler (16-bit types)
+        if constexpr (sizeof(T) == 2) acc[rb][cb] = Traits<T>::mma16x2(f.a[NK - 1], f.a[L], x[cb][NK - 1], z, acc[rb][cb]);
+        else acc[rb][cb] = Traits<T>::mma16(f.a[NK - 1], x[cb][NK - 1], acc[rb][cb]);
+      }
     }
   };
   if constexpr (AHEAD >= NRB) {
@@ -562,34 +566,14 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
   store_colsT<T, NK, QB>(O + ((size_t)b * N * H + head) * D, rso, q0, N, D, c, g, o, inv);
 }
 
-// =================================================================================================== backward prep
-// delta[bh][q] = sum_d dO[q][d] * O[q][d]
-template <typename T>
-__global__ __launch_bounds__(kThreads) void self_attn_delta_kernel(const T* __restrict__ O, const T* __restrict__ dO,
-                                                                   float* __restrict__ delta, int H, int N, int D,
-                                                                   long long rows) {
-  const long long row = (long long)blockIdx.x * kThreads + threadIdx.x;  // row = (b*N + q)*H + head
-  if (row >= rows) return;
-  const T* o = O + row * D;
-  const T* d = dO + row * D;
-  float acc = 0.f;
-  for (int i = 0; i < D; i += 4) {
-    const typename Traits<T>::frag a = load_frag<T>(o + i), e = load_frag<T>(d + i);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc += Traits<T>::to_f32(a[j]) * Traits<T>::to_f32(e[j]);
-  }
-  const long long head = row % H, bq = row / H, q = bq % N, b = bq / N;
-  delta[((size_t)b * H + head) * N + q] = acc;
-}
-
 // =================================================================================================== backward dQ
 template <typename T, int NK, int QB, int NBUF, int KT>
 __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __restrict__ Q, const T* __restrict__ K,
-                                                                    const T* __restrict__ V, const T* __restrict__ dO,
+                                                                    const T* __restrict__ V, const T* __restrict__ O,
+                                                                    const T* __restrict__ dO,
                                                                     const float* __restrict__ LSE,
-                                                                    const float* __restrict__ delta,
-                                                                    T* __restrict__ dQ, int H, int N, int D, int nqt,
-                                                                    int ldq, float scale) {
+                                                                    float* __restrict__ delta, T* __restrict__ dQ,
+                                                                    int H, int N, int D, int nqt, int ldq, float scale) {
   using Tr = Traits<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // one buffer = [K row-major | V row-major | K column image (transposed, or row-major for the transposing read)]
@@ -607,12 +591,25 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
   typename Tr::frag qf[QB][NK], dof[QB][NK];
   load_col_frags<T, NK, QB>(Q + off, rs, q0, N, D, c, g, qf);
   load_col_frags<T, NK, QB>(dO + offo, rso, q0, N, D, c, g, dof);
+  // delta[q] = sum_d dO[q][d] O[q][d]: this wave holds its queries' dO rows as fragments anyway; with the O rows
+  // beside them the row sum is 12 FMAs and the column's cross-lane step — no separate pass over O and dO.  The
+  // values also go to `delta` for the dK/dV kernel that follows on the stream.
   float lse[QB], dl[QB];
+  {
+    typename Tr::frag of[QB][NK];
+    load_col_frags<T, NK, QB>(O + offo, rso, q0, N, D, c, g, of);
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const int q = q0 + qb * 16 + c;
-    lse[qb] = q < N ? LSE[((size_t)b * H + head) * N + q] : 0.f;
-    dl[qb] = q < N ? delta[((size_t)b * H + head) * N + q] : 0.f;
+    for (int qb = 0; qb < QB; ++qb) {
+      float part = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += Tr::to_f32(dof[qb][kc][r]) * Tr::to_f32(of[qb][kc][r]);
+      dl[qb] = quad_sum(part);
+      const int q = q0 + qb * 16 + c;
+      lse[qb] = q < N ? LSE[((size_t)b * H + head) * N + q] : 0.f;
+      if (g == 0 && q < N) delta[((size_t)b * H + head) * N + q] = dl[qb];
+    }
   }
   Stage<T, NK, KT, false> sk, sv;
   sk.init(K + off, D, rs);
@@ -948,9 +945,6 @@ int launch_bwd_cb(const void* Q, const void* K, const void* V, const void* O, co
   constexpr int KT = 64;
   const size_t l1 = dq_lds<T, NK, KT>(), l2 = dkdv_lds<T, NK, KT>();
   if (l1 > kLdsLimit || l2 > kLdsLimit) return GA_ERR_SHAPE;
-  const long long rows = (long long)B * N * H;
-  hipLaunchKernelGGL(self_attn_delta_kernel<T>, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                     s, (const T*)O, (const T*)dO, delta, H, N, D, rows);
   const int nt = (N + 64 * CB - 1) / (64 * CB);
   auto kq = self_attn_bwd_dq_kernel<T, NK, CB, Bufs<T, NK>::value, KT>;
   auto kk = self_attn_bwd_dkdv_kernel<T, NK, 1, Bufs<T, NK>::value, KT>;  // dk_dv: 16 keys per wave (register budget)
@@ -959,7 +953,7 @@ int launch_bwd_cb(const void* Q, const void* K, const void* V, const void* O, co
   rc = set_dyn_lds(kk, l2);
   if (rc != GA_OK) return rc;
   hipLaunchKernelGGL(kq, dim3((unsigned)(B * H * nt)), dim3(kThreads), l1, s, (const T*)Q, (const T*)K, (const T*)V,
-                     (const T*)dO, LSE, (const float*)delta, (T*)dQ, H, N, D, nt, ldq, scale);
+                     (const T*)O, (const T*)dO, LSE, delta, (T*)dQ, H, N, D, nt, ldq, scale);
   const int nk = (N + 63) / 64;
   hipLaunchKernelGGL(kk, dim3((unsigned)(B * H * nk)), dim3(kThreads), l2, s, (const T*)Q, (const T*)K, (const T*)V,
                      (const T*)dO, LSE, (const float*)delta, (T*)dK, (T*)dV, H, N, D, nk, ldq, scale);

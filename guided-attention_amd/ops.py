@@ -61,7 +61,7 @@ def replay_launch_us(key, iters=100):
     """Average duration (us) of one launch of a recorded kernel shape, inputs resident in HBM: `iters` launches
     captured into one hipGraph (no host in the loop: a Python-driven loop is launch-bound at ~10 us per call and
     hides the kernel time), replayed between two HIP events on the launch stream.  For the self-attention and
-    GroupNorm backward the figure covers the launches of one backward call (3 resp. 2 kernels)."""
+    GroupNorm backward the figure covers the launches of one backward call (2 resp. up to 3 kernels)."""
     kind, B, H, N, Kt, D, flag, dt = key
     dtype = {"torch.float16": torch.float16, "torch.bfloat16": torch.bfloat16, "torch.float32": torch.float32}[dt]
     dev = torch.device("cuda", torch.cuda.current_device())

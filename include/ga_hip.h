@@ -157,7 +157,7 @@ int ga_cfg_ddim_step(const void* eps_uncond, const void* eps_text, float guidanc
  *   forward, in the log2 domain, and read by the backward; delta is scratch the backward fills).
  *   ld_qkv = row stride (elements) of Q, K, V and of dQ, dK, dV: 0 (= H*D) for separate projections, 3*H*D when
    they are the three column slices of one fused QKV projection (pass the slice base pointers); O / dO are dense.
-   D % 8 == 0, D <= 160 (f32: D <= 80).  Backward = 3 launches (delta, dQ, dK+dV), no atomics.
+   D % 8 == 0, D <= 160 (f32: D <= 80).  Backward = 2 launches (dQ, which also fills delta; then dK+dV), no atomics.
  */
 int ga_self_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE,
                      int B, int H, int N, int D, int ld_qkv, float scale, int dtype, ga_stream_t stream);
