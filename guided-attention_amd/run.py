@@ -30,7 +30,11 @@ def load_model(config: RunConfig, random_init=None):
         random_init = os.environ.get("GA_RANDOM_INIT", "0") == "1"
     revision = "fp16" if config.half_precision else None
     stable = GuidedAttention.from_pretrained(name, revision=revision, random_init=random_init)
-    return stable.to(device)
+    stable = stable.to(device)
+    # the UNet passes replay as hipGraphs (captured in the first image's warm-up); GA_EAGER=1 launches every kernel
+    # from the host instead (same kernels, same results, ~3x slower at batch 1)
+    stable.use_graphs = os.environ.get("GA_EAGER", "0") != "1"
+    return stable
 
 
 def run_on_prompt(prompt: List[str], model: GuidedAttention, controller: AttentionStore, seed: torch.Generator,
