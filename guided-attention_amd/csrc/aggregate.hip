@@ -25,7 +25,16 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a, int n_elem, f
   float acc = 0.f;
   for (int m = 0; m < a.n_maps; ++m) {
     const T* src = static_cast<const T*>(a.maps[m]) + e;
-    for (int h = 0; h < a.heads[m]; ++h) acc += Traits<T>::to_f32(src[(size_t)h * n_elem]);
+    const int nh = a.heads[m];
+    int h = 0;
+    for (; h + 8 <= nh; h += 8) {  // 8 loads in flight, then the adds in list order (same sum as the scalar loop)
+      T v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(h + j) * n_elem];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += Traits<T>::to_f32(v[j]);
+    }
+    for (; h < nh; ++h) acc += Traits<T>::to_f32(src[(size_t)h * n_elem]);
   }
   A[e] = acc / (float)a.total_heads;
 }
