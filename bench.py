@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — guided images/sec of the guided-attention hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment), or run directly — then this process touches no GPU and starts the N ranks
+itself as child processes (one per GPU, rendezvous on 127.0.0.1), relays rank 0's JSON line and exits with the worst
+return code.
 
 One "step" = one guided image: the full 50-step DDIM guided sampling of the SD-1.x UNet at 512^2
 (latent 64^2), prompt 'a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55]', guidance 7.5, the
@@ -15,6 +20,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -26,17 +33,19 @@ sys.path.insert(0, str(ROOT))
 
 META_PROMPT = "a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55]"
 META_PROMPT_SD21 = "a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55] under a [moon:.35,.05,.35,.35]"
+META_PROMPT_SDXL = "a [robot:.6,.3,.4,.55] and a blue [vase:.2,.3,.4,.55]"   # BASELINE config 5: 2 guided tokens
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2, help="timed guided images per GPU")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="default", choices=["default", "every-step"])
-    ap.add_argument("--model", default=os.environ.get("GA_BENCH_MODEL", "sd15"), choices=["sd15", "sd21", "tiny"],
-                    help="sd21 = BASELINE config 4: SD-2.1 UNet shapes at 768^2 (latent 96^2, maps 24x24), 3 box tokens")
+    ap.add_argument("--model", default=os.environ.get("GA_BENCH_MODEL", "sd15"), choices=["sd15", "sd21", "sdxl", "tiny"],
+                    help="sd21 = BASELINE config 4: SD-2.1 UNet shapes at 768^2 (latent 96^2, maps 24x24), 3 box tokens; "
+                         "sdxl = config 5: SDXL-base UNet shapes at 1024^2 (latent 128^2, maps 32x32), 2 tokens, bf16")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--guidance-forward", default="full", choices=["full", "truncated"])
@@ -44,7 +53,75 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying hipGraphs")
     ap.add_argument("--no-joint-pass", action="store_true",
                     help="run the loss-only guidance forward and the CFG pair as two passes (B=1, B=2) instead of one B=3 pass")
-    return ap.parse_args()
+    ap.add_argument("--two-pass-steps", type=int, default=1,
+                    help="after the timed region, also time this many images with the two-pass form of the loss-only "
+                         "steps and report it beside the headline (0 = skip)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only exercise the N-rank launch + rendezvous (gloo when no GPU is visible) and print one line")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ N-rank self-launch
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_envs(n, port, base=None):
+    """Environment of each of the n ranks of one node (what torch.distributed.run would set)."""
+    base = dict(os.environ if base is None else base)
+    envs = []
+    for r in range(n):
+        e = dict(base)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GA_BENCH_SELF_LAUNCHED="1")
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+        e.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+        envs.append(e)
+    return envs
+
+
+def launch_ranks(n, argv):
+    """Start n copies of this script, one per GPU.  The parent has made no GPU call and execs nothing: children are
+    ordinary subprocesses; rank 0 inherits stdout (its JSON line is THE line), the other ranks' stdout is dropped,
+    stderr is shared.  Returns the worst child return code; if one rank dies the others are terminated."""
+    port = free_port()
+    procs = []
+    for r, env in enumerate(rank_envs(n, port)):
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                for o in alive:          # a rank failed: the others would wait in a collective forever
+                    procs[o].terminate()
+        time.sleep(0.2)
+    return worst
+
+
+def launch_check():
+    """The launch path without the workload: rendezvous, one all-reduce, one line (CPU: gloo)."""
+    from guided_attention_amd import parallel
+    import torch.distributed as dist
+    rank, world, local = parallel.init_distributed()
+    dev = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+    x = torch.tensor([float(rank + 1)], device=dev)
+    if world > 1:
+        dist.all_reduce(x)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "backend": dist.get_backend() if world > 1 else None,
+                          "sum": float(x), "self_launched": os.environ.get("GA_BENCH_SELF_LAUNCHED") == "1"}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def build_pipeline(args, device, rank, world):
@@ -52,33 +129,44 @@ def build_pipeline(args, device, rank, world):
     from guided_attention_amd.pipeline_guided_attention import GuidedAttention
     from guided_attention_amd.text import SyntheticTextEncoder, WordTokenizer
     from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig
-    cfg = {"sd15": UNetConfig.sd15, "sd21": UNetConfig.sd21}.get(args.model, lambda: UNetConfig.tiny(64, 768))()
+    import torch.distributed as dist
+    cfg = {"sd15": UNetConfig.sd15, "sd21": UNetConfig.sd21, "sdxl": UNetConfig.sdxl}.get(
+        args.model, lambda: UNetConfig.tiny(64, 768))()
+    dtype = torch.bfloat16 if args.model == "sdxl" else torch.float16   # BASELINE config 5 is quoted in bf16
     with torch.device(device):
         unet = UNet2DConditionModel(cfg)
-    unet = unet.half()
+    unet = unet.to(dtype)
     if rank == 0:
-        unet.init_weights_(seed=0)       # seeded random weights of the SD-1.x architecture
+        unet.init_weights_(seed=0)       # seeded random weights of the architecture; the other ranks receive them
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     n_msgs = parallel.broadcast_module_(unet)  # RCCL over xGMI: the only start-up collective
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     bcast_s = time.perf_counter() - t0
+    nbytes = sum(p.numel() * p.element_size() for p in unet.parameters())
     pipe = GuidedAttention(unet, None, None, SyntheticTextEncoder(cfg.cross_attention_dim), WordTokenizer())
-    pipe.to(device, torch.float16)
+    pipe.to(device, dtype)
     pipe.guidance_forward = args.guidance_forward
     pipe.skip_unused_guidance = args.skip_unused_guidance
     pipe.use_graphs = not args.eager
     pipe.batch_loss_only_guidance = not args.no_joint_pass
-    return pipe, cfg, {"messages": n_msgs, "seconds": bcast_s}
+    return pipe, cfg, {"messages": n_msgs, "seconds": round(bcast_s, 4), "bytes": nbytes,
+                       "timed": "between two barriers" if world > 1 else "single rank: no collective"}
 
 
 def make_run(args, pipe, cfg, device):
     from guided_attention_amd import run
     from guided_attention_amd.config import RunConfig
     from guided_attention_amd.utils import helpers, ptp_utils, shared_state as state
-    rc = RunConfig(meta_prompt=META_PROMPT_SD21 if args.model == "sd21" else META_PROMPT,
+    rc = RunConfig(meta_prompt={"sd21": META_PROMPT_SD21, "sdxl": META_PROMPT_SDXL}.get(args.model, META_PROMPT),
                    output_path="/tmp/ga_bench_out", half_precision=True, n_inference_steps=args.ddim_steps)
-    if args.model == "sd21":
-        rc.attention_res = cfg.sample_size // 4   # the 24x24 maps of the 96^2 latent (synthetic embeddings: no EOT slice)
+    if args.model in ("sd21", "sdxl"):
+        # the (latent/4)^2 maps: 24x24 of the 96^2 latent, 32x32 of the 128^2 latent (synthetic embeddings: no EOT slice)
+        rc.attention_res = cfg.sample_size // 4
     if args.workload == "every-step":
         rc.only_update_on_threshold_steps = False
         rc.max_iter_to_alter = 25
@@ -87,7 +175,7 @@ def make_run(args, pipe, cfg, device):
     run.overrideConfig(rc)        # thresholds := {0: 1.0}, as the reference does at run time
     run.parseMetaPrompt(rc)
     g = torch.Generator("cpu").manual_seed(1234)
-    embeds = torch.randn(2, 77, cfg.cross_attention_dim, generator=g).to(device, torch.float16)
+    embeds = torch.randn(2, 77, cfg.cross_attention_dim, generator=g).to(device, pipe.unet.dtype)
     lat_side = cfg.sample_size
 
     def one_image(seed):
@@ -151,20 +239,23 @@ def kernel_work(key):
     return "mfma", flops * (1.0 if kind == "self_attn_fwd" else 2.5)
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel's largest shape from the committed PMC run (FETCH_SIZE and
-    WRITE_SIZE collected in separate rocprofv3 --pmc passes, gfx950 correction applied: profiles/r1_pmc_self_attn.json);
-    None when no PMC profile of that kernel is committed."""
+def pmc_traffic(kernel, model, shape):
+    """HBM bytes per launch of the dominant kernel from the committed PMC run of THIS model's dominant shape
+    (profiles/r2_pmc_traffic_<model>.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes with
+    the gfx950 corrections of MI355X_MICROARCH.md applied by tools/pmc_summary.py).  None when no PMC profile of that
+    kernel AND shape is committed — the field is never filled from another model's or another shape's run."""
     try:
-        doc = json.loads((ROOT / "profiles" / "r1_pmc_self_attn.json").read_text())
-        k = doc["kernels"][kernel]
-        return {"hbm_bytes": k["hbm_bytes_corrected"], "algorithmic_bytes": k["algorithmic_bytes"], "shape": doc["shape"],
-                "source": "profiles/r1_pmc_self_attn.json"}
+        doc = json.loads((ROOT / "profiles" / f"r2_pmc_traffic_{model}.json").read_text())
+        for k in doc["kernels"]:
+            if k["kernel"] == kernel and all(k["shape"].get(x) == shape.get(x) for x in ("B", "H", "N", "D")):
+                return {"hbm_bytes": k["hbm_bytes_corrected"], "algorithmic_bytes": k["algorithmic_bytes"],
+                        "shape": k["shape"], "source": f"profiles/r2_pmc_traffic_{model}.json"}
     except (OSError, KeyError, ValueError):
-        return None
+        pass
+    return None
 
 
-def roofline_entry(census, ops):
+def roofline_entry(census, ops, model="sd15"):
     """Dominant hand-written kernel = the ga_* entry point with the largest total time over the timed region.
     achieved = sum of algorithmic work over its calls / sum of their durations; each shape's duration is measured by a
     back-to-back hipGraph replay between two HIP events on the launch stream (the weighted mean equals what
@@ -194,17 +285,39 @@ def roofline_entry(census, ops):
 
     kind, d = max(per_kind.items(), key=lambda kv: kv[1]["time_us"])
     out = summary(kind, d)
-    out["traffic"] = pmc_traffic("ga_" + kind)
     out["shapes"] = sorted(d["shapes"], key=lambda x: -x["calls"] * x["call_us"])[:6]
+    out["traffic"] = pmc_traffic("ga_" + kind, model, out["shapes"][0])
     out["other_kernels"] = [summary(k, v) for k, v in sorted(per_kind.items(), key=lambda kv: -kv[1]["time_us"]) if k != kind]
     return out
 
 
-def cpu_baseline(args, cfg, calls, rc):
-    """The oracle (CPU fp32 restatement, oracle/pipeline.py) on the host cores: one guidance evaluation
-    (forward with autograd + loss), one backward to the latents and one CFG forward of the SAME UNet
-    shape, extrapolated with the GPU run's per-image call counts."""
-    import copy
+def cpu_model_name():
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _timed(fn, reps):
+    """One untimed warm-up call, then `reps` timed calls -> (median seconds, [seconds])."""
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2], ts
+
+
+def cpu_baseline(args, cfg, calls, rc, reps=3):
+    """The oracle (CPU fp32 restatement, oracle/pipeline.py) on the host cores: per pass kind one warm-up and `reps`
+    timed repetitions of a guidance evaluation (forward with autograd + loss), a backward to the latents and a CFG
+    forward of the SAME UNet shape (medians), extrapolated with the GPU run's per-image call counts; the
+    reference-style Python-pixel-loop loss (oracle.loss.loss_reference_loops) is timed as its own field, because the
+    vectorised oracle loss is far faster than what the reference executes."""
     from oracle import loss as oloss
     from oracle.pipeline import GuidedSampler
     from guided_attention_amd.unet import UNet2DConditionModel
@@ -213,34 +326,76 @@ def cpu_baseline(args, cfg, calls, rc):
     unet = UNet2DConditionModel(cfg).init_weights_(seed=0).float()
     for p in unet.parameters():
         p.requires_grad_(False)
-    entries = [{"index": 2, "kind": "BOX", "geom": (.6, .3, .4, .55), "subprompt": "robot"},
-               {"index": 5, "kind": "BOX", "geom": (.2, .3, .4, .55), "subprompt": "blue vase"},
-               {"index": 6, "kind": "BOX", "geom": (.2, .3, .4, .55), "subprompt": "blue vase"}]
-    s = GuidedSampler(unet, oloss.TokenPlan(entries), thresholds={0: 1.0}, steps=args.ddim_steps)
+    from guided_attention_amd.utils import helpers
+    entries = []      # the guided tokens of the GPU run's own meta-prompt (rc.token_dict), as plain data
+    for idx, info in rc.token_dict.items():
+        box = info["loss_type"] == helpers.AnnotationType.BOX
+        entries.append({"index": idx, "kind": "BOX" if box else "COOR",
+                        "geom": info["loss"].as_tuple() if box else tuple(info["loss"]), "subprompt": info["subprompt"]})
+    plan = oloss.TokenPlan(entries)
+    s = GuidedSampler(unet, plan, thresholds={0: 1.0}, steps=args.ddim_steps, attention_res=rc.attention_res)
     g = torch.Generator("cpu").manual_seed(1234)
     embeds = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
     lat = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator("cpu").manual_seed(0))
-    t0 = time.perf_counter()
-    with torch.enable_grad():
-        lat_g, r, _ = s._evaluate(lat, 981, embeds[1:2])
-    t1 = time.perf_counter()
-    with torch.enable_grad():
-        s._update(lat_g, r["loss"], 20.0)
-    t2 = time.perf_counter()
-    with torch.no_grad():
-        unet(torch.cat([lat] * 2), 981, encoder_hidden_states=embeds)
-    t3 = time.perf_counter()
-    per = {"fwd_b1_grad": t1 - t0, "bwd": t2 - t1, "fwd_b2": t3 - t2}
+    box = {}
+
+    def fwd():
+        with torch.enable_grad():
+            box["lat"], box["r"], _ = s._evaluate(lat, 981, embeds[1:2])
+
+    def bwd():
+        with torch.enable_grad():
+            s._update(box["lat"], box["r"]["loss"], 20.0)
+
+    def cfg_fwd():
+        with torch.no_grad():
+            unet(torch.cat([lat] * 2), 981, encoder_hidden_states=embeds)
+
+    per, raw = {}, {}
+    per["fwd_b1_grad"], raw["fwd_b1_grad"] = _timed(fwd, reps)
+    per["bwd"], raw["bwd"] = _timed(bwd, reps)
+    per["fwd_b2"], raw["fwd_b2"] = _timed(cfg_fwd, reps)
     sec_per_image = sum(per[k] * calls[k] for k in per)
-    return {"value": 1.0 / sec_per_image, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "1x guidance forward+loss (autograd), 1x backward to latents, 1x CFG forward (B=2) of the same "
-                      f"{args.model} UNet in fp32 on the host, extrapolated with the GPU run's per-image call counts "
-                      f"{ {k: calls[k] for k in per} }",
-            "seconds_per_kind": {k: round(v, 3) for k, v in per.items()}, "seconds_per_image": round(sec_per_image, 1)}
+    # the loss the way the reference evaluates it (Python loops over the res x res pixels, scalar tensor ops)
+    A = torch.softmax(torch.randn(rc.attention_res, rc.attention_res, 77, generator=g), -1)
+
+    def loop_loss():
+        a = A.clone().requires_grad_(True)
+        r = oloss.loss_reference_loops(a * 1.0, plan)
+        box["loop_r"], box["loop_a"] = r, a
+
+    def loop_loss_bwd():
+        torch.autograd.grad(box["loop_r"]["loss"], [box["loop_a"]], retain_graph=True)
+
+    def vec_loss():
+        oloss.loss_torch(A, plan)
+
+    loop_s, _ = _timed(loop_loss, reps)
+    loop_bwd_s, _ = _timed(loop_loss_bwd, reps)
+    vec_s, _ = _timed(vec_loss, reps)
+    evals = calls.get("loss_evals", calls["fwd_b1_grad"])
+    with_loops = sec_per_image + evals * (loop_s - vec_s) + calls["bwd"] * loop_bwd_s
+    return {"value": 1.0 / sec_per_image, "unit": "images/s", "cores": cores, "cpu_model": cpu_model_name(),
+            "threads": torch.get_num_threads(), "kind": "port",
+            "sample": f"per pass kind 1 warm-up + {reps} timed repetitions (median) of: guidance forward+loss (autograd), "
+                      f"backward to latents, CFG forward (B=2) of the same {args.model} UNet in fp32 on the host, "
+                      f"extrapolated with the GPU run's per-image call counts { {k: calls[k] for k in per} }",
+            "seconds_per_kind": {k: round(v, 3) for k, v in per.items()},
+            "seconds_per_kind_all": {k: [round(x, 3) for x in v] for k, v in raw.items()},
+            "seconds_per_image": round(sec_per_image, 1),
+            "reference_style_loop_loss": {"fwd_ms": round(loop_s * 1e3, 2), "bwd_ms": round(loop_bwd_s * 1e3, 2),
+                                          "vectorised_oracle_fwd_ms": round(vec_s * 1e3, 2),
+                                          "images_per_s_with_loop_loss": 1.0 / with_loops}}
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # run directly with --gpus N: start the N ranks ourselves.  Nothing above touched the GPU.
+        raise SystemExit(launch_ranks(args.gpus, argv))
+    if args.launch_check:
+        return launch_check()
     from guided_attention_amd import ops, parallel
     rank, world, local = parallel.init_distributed()
     if world > 1:
@@ -250,8 +405,7 @@ def main():
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/ga_miopen_{os.getuid()}_{local}/cache")
         os.makedirs(os.environ["MIOPEN_CUSTOM_CACHE_DIR"], exist_ok=True)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the guided-attention path has no CPU fallback")
     device = torch.device("cuda", local)
@@ -276,26 +430,53 @@ def main():
         finals.append(out.latents)
         calls = out.unet_calls
     torch.cuda.synchronize()
+    t_mine = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     census = ops.stop_census()
+    per_rank = [args.steps / t_mine]
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
+        mine = torch.tensor([args.steps / t_mine], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(x) for x in allr]
     gathered = parallel.gather_tensors(finals)  # the end-of-run gather of the final latents (32 KB each)
     ok = all(torch.isfinite(f).all().item() for f in finals)
+    if world > 1:
+        okt = torch.tensor([1.0 if ok else 0.0], device=device)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item() > 0)
+    two_pass = None
+    if world == 1 and args.two_pass_steps > 0 and pipe.batch_loss_only_guidance and pipe.use_graphs:
+        # the strict two-pass form of the loss-only steps (B=1 guidance forward, then the B=2 CFG pass), quoted
+        # beside the headline; outside the timed region (its graphs are captured in an untimed image first)
+        pipe.batch_loss_only_guidance = False
+        one_image(2000)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for j in range(args.two_pass_steps):
+            one_image(3000 + j)
+        torch.cuda.synchronize()
+        two_pass = args.two_pass_steps / (time.perf_counter() - t1)
+        pipe.batch_loss_only_guidance = True
     if rank == 0:
         n_images = args.steps * world
-        roof = roofline_entry(census, ops)
+        roof = roofline_entry(census, ops, args.model)
         flops_per_fwd = {"sd15": 0.803e12, "sd21": 2.149e12}.get(args.model)
+        names = {"sd21": ("guided images/sec (50-step SD-2.1 768^2)", "SD-2.1 UNet 768^2 (latent 96^2)"),
+                 "sdxl": ("guided images/sec (50-step SDXL-base 1024^2)", "SDXL-base UNet 1024^2 (latent 128^2)"),
+                 "tiny": ("guided images/sec (50-step reduced-width UNet 512^2)", "1/10-width SD-1.x UNet 512^2")}
+        metric, shape = names.get(args.model, ("guided images/sec (50-step SD-1.5 512^2)", "SD-1.x UNet 512^2 (latent 64^2)"))
+        dt_name = {torch.float16: "f16", torch.bfloat16: "bf16"}[pipe.unet.dtype]
         line = {
-            "metric": ("guided images/sec (50-step SD-2.1 768^2)" if args.model == "sd21" else
-                       "guided images/sec (50-step SD-1.5 512^2)"), "value": n_images / elapsed, "unit": "images/s",
+            "metric": metric, "value": n_images / elapsed, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"W-{args.workload}: {'SD-2.1 UNet 768^2 (latent 96^2)' if args.model == 'sd21' else 'SD-1.x UNet 512^2 (latent 64^2)'}, {args.ddim_steps} DDIM steps, "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt_name, "data": "synthetic",
+            "config": {"workload": f"W-{args.workload}: {shape}, {args.ddim_steps} DDIM steps, "
                                    f"meta_prompt '{rc.meta_prompt}', guidance 7.5, thresholds {rc.thresholds}, 1 seed per step",
                        "parallelism": f"seed-parallel x{world}", "guidance_forward": args.guidance_forward,
                        "skip_unused_guidance": args.skip_unused_guidance, "model": args.model,
@@ -303,10 +484,17 @@ def main():
                                            "guidance forward + CFG pair of a step without latent update batched as one "
                                            "B=3 pass (every evaluation performed)"),
                        "launch": "eager" if args.eager else "hipGraph replay of the UNet passes (captured in warm-up)",
-                       "weights": "seeded random init (no checkpoint offline)"},
+                       "weights": "seeded random init (no checkpoint offline)",
+                       "side_effects": "PNG / log dumps of the reference (diagnostics) are off and outside the timed region"},
             "unet_calls_per_image": calls, "finite": ok,
             "weight_broadcast": bcast,
+            "distributed": {"backend": dist.get_backend() if world > 1 else None, "world_size": world,
+                            "self_launched": os.environ.get("GA_BENCH_SELF_LAUNCHED") == "1",
+                            "images_per_s_per_rank": [round(x, 4) for x in per_rank],
+                            "gathered_latents": sum(len(x) for x in gathered) if gathered else 0},
         }
+        if two_pass is not None:
+            line["two_pass_images_per_s"] = round(two_pass, 4)
         if flops_per_fwd:
             tf = flops_per_fwd * (calls["fwd_b1_grad"] + 2 * calls["fwd_b2"] + calls["bwd"]) / 1e12
             line["end_to_end"] = {"tflop_per_image": round(tf, 1),
@@ -316,10 +504,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, cfg, calls, rc)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("non-finite latents: the printed line is not a valid measurement")
 
 
 if __name__ == "__main__":

@@ -17,18 +17,22 @@ ones (same C-ABI calls on the capture stream).
 import torch
 
 from . import ops
-from .utils.ptp_utils import aggregate_attention, refresh_context_projections
+from .utils.ptp_utils import aggregate_attention, pin_context_projections, refresh_context_projections
 
 
 class GraphRunner:
     @classmethod
     def for_run(cls, pipe, store, prompt_embeds, latents, attention_res, smooth, sigma, ksize, normalize_eot):
+        from .utils import shared_state as state
         plan = pipe._loss_plan(smooth, sigma, ksize)
-        key = (tuple(latents.shape), latents.dtype, tuple(prompt_embeds.shape), pipe._plan_key, attention_res,
+        custom = getattr(state.config, "custom_loss", None) or {}
+        key = (tuple((name, id(fn), str(args)) for name, (fn, args) in sorted(custom.items())), tuple(latents.shape), latents.dtype, tuple(prompt_embeds.shape), pipe._plan_key, attention_res,
                pipe.guidance_forward, normalize_eot, str(pipe.prompt) if normalize_eot else None,
                getattr(store, "capture", None), bool(getattr(pipe, "batch_loss_only_guidance", False)))
         runner = pipe._graph_cache.get(key)
         if runner is None:
+            for old in pipe._graph_cache.values():
+                old.release()
             pipe._graph_cache.clear()  # one live configuration: the pools hold every activation of both passes
             runner = cls(pipe, store, prompt_embeds, latents, attention_res, smooth, sigma, ksize, normalize_eot)
             pipe._graph_cache[key] = runner
@@ -134,6 +138,20 @@ class GraphRunner:
             self.launches["joint"] = c_joint.launches
         torch.cuda.synchronize()
         self.pipe.unet_calls.update(calls)  # capture / warm-up passes are not image work
+        # The captured kernels read the cached text K/V projections of the static prompt buffers by raw pointer:
+        # pin those cache entries so that eager passes with other contexts can never evict (= free) them.
+        self._storages = {b.untyped_storage().data_ptr() for b in (self.embeds, getattr(self, "embeds3", None))
+                          if b is not None}
+        self.pinned = pin_context_projections(self.pipe.unet, self._storages, +1)
+        GraphRunner.captures += 1
+
+    captures = 0  # how many runners were ever captured (tests assert graph reuse across seeds)
+
+    def release(self):
+        """Unpin the text K/V entries (the runner is being dropped; its graphs must not be replayed afterwards)."""
+        if self._storages:
+            pin_context_projections(self.pipe.unet, self._storages, -1)
+            self._storages = set()
 
     # -- replays
     def _publish(self, store, snapshot):

@@ -280,6 +280,9 @@ class LossPlan:
     """Host-side descriptor of the guided tokens and hyper-parameters (what config.token_dict and
     shared_state.curHyperParams hold in the reference), marshalled once into the C structs."""
 
+    # the hyper-parameters a plan reads (what its cache key must cover)
+    HYPER_KEYS = ("strict", "inside_loss_scale", "outside_loss_scale", "bb_center_weight", "shrink_factor")
+
     def __init__(self, entries, hyper, smooth=True, sigma=0.5, kernel_size=3, sub_prompt_avg_within=False):
         """entries: list of dict(index, kind 'BOX'|'COOR', geom, subprompt)."""
         self.entries = list(entries)

@@ -43,7 +43,9 @@ def broadcast_module_(module, src=0, bucket_bytes=512 << 20):
     up to `bucket_bytes` (few, large messages: xGMI is point-to-point, ~153 GB/s per link)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    # the parameters themselves (not `.data`): `copy_` below then bumps their version counters, which is what the
+    # weight-derived caches (fused QKV, cached text K/V, batched time projections) are keyed on
+    tensors = list(module.parameters()) + list(module.buffers())
     by_dtype = {}
     for t in tensors:
         by_dtype.setdefault((t.dtype, t.device), []).append(t)
@@ -107,11 +109,16 @@ def unstripe(per_rank):
     return [per_rank[i % world][i // world] for i in range(total)]
 
 
+def rank_world():
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def execute_seeds(generate, seeds, module=None):
     """Run `generate(seed) -> tensor` for this rank's share of `seeds`; weights of `module` are first
     broadcast from rank 0; returns on rank 0 the results in seed order (None on other ranks)."""
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank, world = rank_world()
     if module is not None:
         broadcast_module_(module)
     mine = [generate(s) for s in shard_seeds(seeds, rank, world)]

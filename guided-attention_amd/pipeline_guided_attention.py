@@ -70,10 +70,11 @@ class GuidedAttention:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_pretrained(cls, name_or_path, revision=None, torch_dtype=None, random_init=False, unet_config=None,
-                        seed=0, **kwargs):
+                        seed=0, weights=True, **kwargs):
         """Local diffusers-layout folder -> weights loaded by name.  There is no network here: an id that is
         not a local folder raises unless random_init=True, which builds seeded random weights of the named
-        architecture (SD-1.x for anything but '*2-1*')."""
+        architecture (SD-1.x for anything but '*2-1*').  weights=False builds the architecture only (no file read,
+        no random draw): what the ranks other than 0 do before the weight broadcast (run.load_model)."""
         from pathlib import Path
         from .text import SyntheticTextEncoder, WordTokenizer, load_clip
         from .unet import UNet2DConditionModel, UNetConfig
@@ -83,20 +84,24 @@ class GuidedAttention:
         folder = Path(str(name_or_path))
         if folder.is_dir() and (folder / "unet").is_dir():
             from safetensors.torch import load_file
-            unet = UNet2DConditionModel(cfg).load_diffusers_state(
-                load_file(str(folder / "unet" / "diffusion_pytorch_model.safetensors")))
+            unet = UNet2DConditionModel(cfg)
+            if weights:
+                unet.load_diffusers_state(load_file(str(folder / "unet" / "diffusion_pytorch_model.safetensors")))
             vae = AutoencoderKLDecoder()
             vae_file = folder / "vae" / "diffusion_pytorch_model.safetensors"
-            if vae_file.exists():
+            if vae_file.exists() and weights:
                 sd = {k: v for k, v in load_file(str(vae_file)).items()
                       if k.startswith(("decoder.", "post_quant_conv."))}
                 vae.load_state_dict(sd, strict=False)
             clip = load_clip(folder)
             tok, enc = clip if clip else (WordTokenizer(), SyntheticTextEncoder(cfg.cross_attention_dim))
         elif random_init:
-            unet = UNet2DConditionModel(cfg).init_weights_(seed)
+            unet = UNet2DConditionModel(cfg)
             small = cfg.block_out_channels[0] < 128
-            vae = (AutoencoderKLDecoder.tiny() if small else AutoencoderKLDecoder()).init_weights_(seed + 1)
+            vae = AutoencoderKLDecoder.tiny() if small else AutoencoderKLDecoder()
+            if weights:
+                unet.init_weights_(seed)
+                vae.init_weights_(seed + 1)
             tok, enc = WordTokenizer(pad_token_id=0 if sd21 else 49407), SyntheticTextEncoder(cfg.cross_attention_dim)
         else:
             raise FileNotFoundError(f"{name_or_path!r} is not a local checkpoint folder and there is no network; "
@@ -207,19 +212,24 @@ class GuidedAttention:
     def _loss_plan(self, smooth, sigma, kernel_size):
         td = state.config.token_dict
         hp = state.curHyperParams
-        key = (id(td), tuple(td.keys()), smooth, sigma, kernel_size, state.config.sub_prompt_avg_within,
-               tuple(sorted((k, str(v)) for k, v in hp.items())))
+        entries = []
+        for idx, info in td.items():
+            if info["loss_type"] == helpers.AnnotationType.BOX:
+                entries.append({"index": idx, "kind": "BOX", "geom": tuple(float(v) for v in info["loss"].as_tuple()),
+                                "subprompt": info["subprompt"]})
+            elif info["loss_type"] == helpers.AnnotationType.COOR:
+                entries.append({"index": idx, "kind": "COOR", "geom": tuple(float(v) for v in info["loss"]),
+                                "subprompt": info["subprompt"]})
+            else:  # KEYWORD tokens only mark sub-prompts for custom losses: no built-in term
+                continue
+        # keyed on CONTENT (token positions, kinds, geometry, sub-prompts, the hyper-parameters the plan reads): an
+        # in-place edit of a Rect invalidates the plan (the captured hipGraphs bake the geometry in by value), and a
+        # fresh but equal token_dict — run.execute builds one per (seed, hyper-parameter state) — reuses plan and graphs
+        key = (tuple((e["index"], e["kind"], e["geom"], e["subprompt"]) for e in entries),
+               tuple((idx, info["loss_type"].name) for idx, info in td.items()),
+               smooth, sigma, kernel_size, state.config.sub_prompt_avg_within,
+               tuple(sorted((k, str(v)) for k, v in hp.items() if k in ops.LossPlan.HYPER_KEYS)))
         if key != self._plan_key:
-            entries = []
-            for idx, info in td.items():
-                if info["loss_type"] == helpers.AnnotationType.BOX:
-                    entries.append({"index": idx, "kind": "BOX", "geom": info["loss"].as_tuple(),
-                                    "subprompt": info["subprompt"]})
-                elif info["loss_type"] == helpers.AnnotationType.COOR:
-                    entries.append({"index": idx, "kind": "COOR", "geom": tuple(info["loss"]),
-                                    "subprompt": info["subprompt"]})
-                else:  # KEYWORD tokens only mark sub-prompts for custom losses: no built-in term
-                    continue
             self._plan = ops.LossPlan(entries, hp, smooth, sigma, kernel_size, state.config.sub_prompt_avg_within)
             self._plan_key = key
         return self._plan
@@ -243,7 +253,9 @@ class GuidedAttention:
             for _name, (fn, args) in state.config.custom_loss.items():
                 v = fn.calc_loss(text_maps, args)
                 custom = v if custom is None else custom + v
-        packed = torch.cat([terms.detach().reshape(-1), loss.detach()])
+        # everything the host tests in ONE device->host copy: the term table, the fused loss and the custom-loss value
+        cval = custom.detach().float().reshape(-1)[:1] if custom is not None else loss.new_zeros(1)
+        packed = torch.cat([terms.detach().reshape(-1), loss.detach(), cval])
         return terms, loss, custom, plan, packed
 
     def _loss_host(self, terms, loss, custom, plan, packed):
@@ -251,9 +263,11 @@ class GuidedAttention:
         `losses_dict` keys (one entry per guided token) plus the fused results."""
         self.unet_calls["loss_evals"] += 1
         host = packed.cpu()
-        host_terms = host[:-1].view(plan.T, 8)
+        host_terms = host[:-2].view(plan.T, 8)
         losses_dict = {k: [terms[t, c] for t in range(plan.T)] for k, c in TERM.items() if c < 5}
-        losses_dict["_fused"] = {"loss": loss, "host_terms": host_terms, "host_loss": host[-1:], "plan": plan}
+        # host_total = the value the reference tests with `loss != 0` (:551, :1002): box terms plus custom loss
+        losses_dict["_fused"] = {"loss": loss, "host_terms": host_terms, "host_loss": host[-2:-1], "plan": plan,
+                                 "host_custom": host[-1:], "host_total": host[-2:-1] + host[-1:]}
         if custom is not None:
             losses_dict["custom_loss"] = custom
         for t, e in enumerate(plan.entries):
@@ -321,8 +335,8 @@ class GuidedAttention:
         loss = fused["loss"]
         if "custom_loss" in losses_dict:
             custom = losses_dict["custom_loss"]
-            losses.append((None, custom.detach().float().cpu()))
-            unscaled.append((None, custom.detach().float().cpu()))
+            losses.append((None, fused["host_custom"]))
+            unscaled.append((None, fused["host_custom"]))
             loss = loss + custom.to(loss.dtype).reshape(1)
         return loss, losses, unscaled
 
@@ -397,7 +411,7 @@ class GuidedAttention:
                 latents, t, text_embeddings[1].unsqueeze(0), attention_store, attention_res, smooth_attentions, sigma,
                 kernel_size, normalize_eot)
             loss, losses, unscaled_losses = self._compute_loss(losses_dict, return_losses=True)
-            if losses_dict["_fused"]["host_loss"].item() != 0 or "custom_loss" in losses_dict:
+            if losses_dict["_fused"]["host_total"].item() != 0:  # reference :551 `elif loss != 0`
                 latents = self._update_latent(latents, loss, step_size)
             if iteration >= max_refinement_steps:
                 helpers.log(f"\t Exceeded max number of iterations ({max_refinement_steps})! ", self.verbose)
@@ -406,7 +420,7 @@ class GuidedAttention:
             latents, t, text_embeddings[1].unsqueeze(0), attention_store, attention_res, smooth_attentions, sigma,
             kernel_size, normalize_eot)
         loss, losses, unscaled_losses = self._compute_loss(max_attention_per_index, return_losses=True)
-        helpers.log(f"\t Finished with loss of: {max_attention_per_index['_fused']['host_loss'].item()} "
+        helpers.log(f"\t Finished with loss of: {max_attention_per_index['_fused']['host_total'].item()} "
                     f"iter: {iteration}", self.verbose)
         state.sub_iteration = 0
         return loss, latents, max_attention_per_index
@@ -533,12 +547,11 @@ class GuidedAttention:
                                     did_we_update = True
                                     loss, losses, unscaled_losses = self._compute_loss(
                                         losses_dict=max_attention_per_index)
-                                    if max_attention_per_index["_fused"]["host_loss"].item() != 0 or \
-                                            "custom_loss" in max_attention_per_index:
+                                    if max_attention_per_index["_fused"]["host_total"].item() != 0:  # :1002
                                         latents = self._update_latent(latents=latents, loss=loss,
                                                                       step_size=scale_factor * np.sqrt(scale_range[i]))
                                 helpers.log(f"Iteration {i} | Loss: "
-                                            f"{max_attention_per_index['_fused']['host_loss'].item():0.4f}", self.verbose)
+                                            f"{max_attention_per_index['_fused']['host_total'].item():0.4f}", self.verbose)
                 latents = latents.detach()
                 # CFG pass with the (possibly updated) latents, no autograd
                 if noise_joint is not None:

@@ -19,18 +19,26 @@ from .utils.ptp_utils import AttentionStore
 
 def load_model(config: RunConfig, random_init=None):
     """reference run.py:18-29.  Model ids resolve to local folders only (no network); set
-    GA_RANDOM_INIT=1 or pass random_init=True to build seeded random weights of the architecture."""
+    GA_RANDOM_INIT=1 or pass random_init=True to build seeded random weights of the architecture.
+    Under torch.distributed.run (WORLD_SIZE > 1) every rank builds the architecture on its own GPU, only rank 0
+    reads / initialises the weights, and ONE bucketed RCCL broadcast over xGMI hands them to the other ranks."""
     import os
+    from . import parallel
     if not torch.cuda.is_available():
         raise RuntimeError("no GPU visible: the guided-attention path runs on HIP kernels only")
-    device = torch.device("cuda:0") if "LOCAL_RANK" not in os.environ else torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+    rank, world, local = parallel.init_distributed()
+    device = torch.device("cuda", local if "LOCAL_RANK" in os.environ else 0)
     name = "stabilityai/stable-diffusion-2-1-base" if config.sd_2_1 else "CompVis/stable-diffusion-v1-4"
     name = os.environ.get("GA_MODEL_DIR", name)
     if random_init is None:
         random_init = os.environ.get("GA_RANDOM_INIT", "0") == "1"
     revision = "fp16" if config.half_precision else None
-    stable = GuidedAttention.from_pretrained(name, revision=revision, random_init=random_init)
+    stable = GuidedAttention.from_pretrained(name, revision=revision, random_init=random_init, weights=(rank == 0))
     stable = stable.to(device)
+    if world > 1:
+        for module in (stable.unet, stable.vae, stable.text_encoder):
+            if isinstance(module, torch.nn.Module):
+                parallel.broadcast_module_(module)
     # the UNet passes replay as hipGraphs (captured in the first image's warm-up); GA_EAGER=1 launches every kernel
     # from the host instead (same kernels, same results, ~3x slower at batch 1)
     stable.use_graphs = os.environ.get("GA_EAGER", "0") != "1"
@@ -81,34 +89,65 @@ def parseMetaPrompt(config):
 
 
 def execute(config, save=True):
-    """One image per (seed, hyper-parameter state), serially on this process's GPU (reference run.py:93-135).
-    Seed-parallel execution over several GPUs lives in guided_attention_amd.parallel."""
-    images, image_path = [], None
-    for seed in config.seeds:
-        for hp in shared_state.get_hyperparam_states():
-            shared_state.curHyperParams = hp
-            overrideConfig(config)
-            parseMetaPrompt(config)
-            helpers.log_clear()
-            shared_state.cur_seed = seed
-            print(f"Seed: {seed}")
-            g = torch.Generator(config.stable.device).manual_seed(seed)
-            controller = AttentionStore()
-            image = run_on_prompt(prompt=config.prompt, model=config.stable, controller=controller, seed=g, config=config)
-            images.append(image)
-            if save:
-                out_dir = config.output_path / helpers.get_inner_folder_name()
-                out_dir.mkdir(exist_ok=True, parents=True)
-                name = helpers.dictToString(shared_state.curHyperParams)
-                image_path = out_dir / f"{seed}{name}.png"
-                try:
-                    image.save(image_path)
-                except OSError:
-                    print("bad path. this is often due to exceeding max path length.")
-                    name = ""
-                    image_path = out_dir / f"{seed}.png"
-                    image.save(image_path)
-                helpers.log_save(out_dir / f"{seed}{name}.txt")
+    """One image per (seed, hyper-parameter state) (reference run.py:93-135).  The reference runs them serially on one
+    device; images of different (seed, state) are independent, so under torch.distributed.run the job list is striped
+    over the ranks (job j on rank j % world, one process per GPU, no per-step exchange) and rank 0 gathers the final
+    latents and images back into job order.  Single process: exactly the reference's serial loop.
+    Returns the path of the last job's image (as the reference does); on rank 0 `shared_state.last_results` holds
+    {"latents": [...], "images": [...]} in job order (None on the other ranks)."""
+    from . import parallel
+    from .utils import vis_utils
+    rank, world = parallel.rank_world()
+    jobs = [(seed, hp) for seed in config.seeds for hp in shared_state.get_hyperparam_states()]
+    images, latents, image_path, paths = [], [], None, {}
+    for j, (seed, hp) in enumerate(jobs):
+        shared_state.curHyperParams = hp
+        overrideConfig(config)
+        parseMetaPrompt(config)
+        out_dir = config.output_path / helpers.get_inner_folder_name()
+        name = helpers.dictToString(shared_state.curHyperParams)
+        paths[j] = out_dir / f"{seed}{name}.png"
+        if j % world != rank:
+            continue
+        helpers.log_clear()
+        shared_state.cur_seed = seed
+        print(f"Seed: {seed}")
+        g = torch.Generator(config.stable.device).manual_seed(seed)
+        controller = AttentionStore()
+        out = run_on_prompt(prompt=config.prompt, model=config.stable, controller=controller, seed=g, config=config,
+                            output_type="pil")
+        image = out.images[0]
+        images.append(image)
+        latents.append(out.latents.detach())
+        if save:
+            out_dir.mkdir(exist_ok=True, parents=True)
+            helpers.annotate_image(image)
+            try:
+                image.save(paths[j])
+            except OSError:
+                print("bad path. this is often due to exceeding max path length.")
+                name = ""
+                paths[j] = out_dir / f"{seed}.png"
+                image.save(paths[j])
+            helpers.log_save(out_dir / f"{seed}{name}.txt")
+            helpers.save_latent_stats(out_dir / f"{seed}{name}figure.png")
+    if jobs:
+        image_path = paths[len(jobs) - 1]
+    if world > 1:
+        import numpy as np
+        from PIL import Image
+        dev = config.stable.device
+        pix = [torch.from_numpy(np.asarray(im.convert("RGB")).copy()).to(dev) for im in images]
+        g_lat, g_pix = parallel.gather_tensors(latents), parallel.gather_tensors(pix)
+        if rank == 0:
+            latents = parallel.unstripe(g_lat)
+            images = [Image.fromarray(t.cpu().numpy()) for t in parallel.unstripe(g_pix)]
+    shared_state.last_results = {"latents": latents, "images": images} if rank == 0 else None
+    if rank == 0 and save and images:
+        joined = vis_utils.get_image_grid(images)  # a grid of the results across all seeds (reference :131-134)
+        if not config.interactive:
+            helpers.annotate_image(joined)
+        joined.save(config.output_path / f"{helpers.get_meta_prompt_clean()}.png")
     return image_path
 
 

@@ -184,3 +184,76 @@ def log_save(filename):
     with open(filename, "w") as fp:
         fp.writelines(lines)
     log_clear()
+
+
+# ---- image annotation / latent statistics (reference helpers.py:129-152, 309-349): side effects of run.execute,
+# off by default (config.annotate, config.diagnostic_level) and never inside the timed sampling loop
+colors = ["#0000a0", "#a00000", "#00a000", "#ecf024", "#8d24f0"]
+
+
+def get_color(i):
+    return colors[i]
+
+
+def _font(size=20):
+    from PIL import ImageFont
+    try:
+        return ImageFont.truetype("arial.ttf", size, encoding="unic")   # what the reference asks for
+    except OSError:
+        try:
+            return ImageFont.truetype("DejaVuSans.ttf", size)
+        except OSError:
+            return ImageFont.load_default()
+
+
+def annotate_image(image):
+    """Draw the boxes / target crosses of the meta-prompt on a PIL image when config.annotate is set (reference
+    :129-152; it hard-codes 512 px and a 16-cell grid — generalised to the image's own size)."""
+    if not (state.config.annotate and not state.config.interactive):
+        return
+    from PIL import ImageDraw
+    draw = ImageDraw.Draw(image)
+    font = _font()
+    w, h = image.size
+    for i, (word, kind, geom) in enumerate(state.config.meta_info):
+        color = get_color(i % len(colors))
+        if kind == AnnotationType.COOR:
+            x, y, length = geom[0] * w, geom[1] * h, 15
+            draw.line([(x - length, y), (x + length, y)], fill=color)
+            draw.line([(x, y - length), (x, y + length)], fill=color)
+            draw.text((x, y), word, fill=color, font=font)
+        elif kind == AnnotationType.BOX:
+            draw.rectangle([(geom.x * w, geom.y * h), (geom.right() * w, geom.bottom() * h)], fill=None, width=2,
+                           outline=color)
+            draw.text((w * geom.x, h * geom.y), word, fill=color, font=font)
+
+
+means, stds, percentile99 = {}, {}, {}
+
+
+def log_latent_stats(latent, per_channel=False):
+    """mean / std of |x| / 99th percentile of |x| of the latents, appended per call (reference :313-333).  Forces a
+    device->host copy: the pipeline only calls it when config.diagnostic_level > 0."""
+    import numpy
+    keys = [f"ch{i}" for i in range(latent.shape[1])] if per_channel else ["all"]
+    for n, key in enumerate(keys):
+        x = (latent[0, n] if per_channel else latent).float()
+        percentile99.setdefault(key, []).append(float(numpy.quantile(x.abs().cpu().numpy(), .99)))
+        stds.setdefault(key, []).append(x.abs().std().item())
+        means.setdefault(key, []).append(x.mean().item())
+
+
+def save_latent_stats(filename):
+    """Plot the collected latent statistics (reference :335-349); only when config.diagnostic_level > 0."""
+    global means, stds, percentile99
+    if state.config.diagnostic_level > 0 and percentile99:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        for key in percentile99:
+            plt.plot(means[key], label=f"{key} mean")
+            plt.plot(percentile99[key], label=f"{key} 99")
+        plt.legend(loc="best")
+        plt.savefig(filename)
+        plt.clf()
+    means, stds, percentile99 = {}, {}, {}

@@ -73,11 +73,31 @@ def cached_context_projections(attn, context):
     hit = cache.get(k)
     if hit is None:
         with torch.no_grad():
-            hit = (context, attn.to_k(context), attn.to_v(context))
-        if len(cache) >= 4:
-            cache.pop(next(iter(cache)))
+            hit = [context, attn.to_k(context), attn.to_v(context), 0]   # [ctx, K, V, pin count]
+        unpinned = [key for key, e in cache.items() if e[3] == 0]
+        while len(unpinned) >= KV_CACHE_ENTRIES:   # FIFO over the entries no captured hipGraph reads
+            cache.pop(unpinned.pop(0))
         cache[k] = hit
     return hit[1], hit[2]
+
+
+KV_CACHE_ENTRIES = 4
+
+
+def pin_context_projections(unet, storages, delta):
+    """Pin (+1) / unpin (-1) every cached (K, V) pair whose context lives in one of `storages` (data pointers of
+    untyped storages).  Captured hipGraphs read these K/V tensors by raw pointer: a pinned entry is never evicted,
+    so the memory stays alive and `refresh_context_projections` keeps it current.  -> number of entries touched."""
+    n = 0
+    for mod in unet.modules():
+        cache = mod.__dict__.get("_kv_cache")
+        if not cache:
+            continue
+        for e in cache.values():
+            if e[0].untyped_storage().data_ptr() in storages:
+                e[3] = max(0, e[3] + delta)
+                n += 1
+    return n
 
 
 def fused_qkv_projection(attn, hidden_states):
@@ -102,10 +122,10 @@ def refresh_context_projections(unet):
             continue
         fresh = {}
         with torch.no_grad():
-            for ctx, k, v in cache.values():
+            for ctx, k, v, pins in cache.values():
                 k.copy_(mod.to_k(ctx))
                 v.copy_(mod.to_v(ctx))
-                fresh[_kv_key(mod, ctx)] = (ctx, k, v)
+                fresh[_kv_key(mod, ctx)] = [ctx, k, v, pins]
         cache.clear()
         cache.update(fresh)
 

@@ -156,6 +156,105 @@ def loss_torch(A, plan, smooth=True, sigma=0.5, kernel_size=3, normalize_eot=Fal
     return out
 
 
+def strict_weights(rect, res, shrink):
+    """helpers.py:216-246: the per-pixel weight table of calculate_bounding_box_losses, normalised separately over the
+    inside and the outside pixels.  Inside: np.interp of the normalised distance from the box centre over
+    xp [0, .333, .666, 1], fp [3, 2.5, 1, .2]; outside: 1.  Geometry in float64, table and sums in fp32 (the
+    reference writes into a `tr.ones(16,16)` fp32 tensor and accumulates the sums in pixel order)."""
+    x, y, w, h = scaled_rect(rect, res)
+    mask = inside_mask(rect, res, shrink)
+    cx, cy = x + w / 2.0, y + h / 2.0
+    W = np.ones((res, res), np.float32)
+    for ii in range(res):
+        for jj in range(res):
+            if mask[ii, jj]:
+                d = math.sqrt(math.pow(2 * (cx - (jj + .5)) / w, 2) + math.pow(2 * (cy - (ii + .5)) / h, 2)) / math.sqrt(2)
+                W[ii, jj] = np.float32(np.interp(d, [0, .333, .666, 1.0], [3, 2.5, 1, .2]))
+    s_in = np.float32(0)
+    s_out = np.float32(0)
+    for ii in range(res):
+        for jj in range(res):
+            if mask[ii, jj]:
+                s_in = np.float32(s_in + W[ii, jj])
+            else:
+                s_out = np.float32(s_out + W[ii, jj])
+    Wn = np.where(mask, W / (s_in if s_in != 0 else np.float32(1)), W / (s_out if s_out != 0 else np.float32(1)))
+    return Wn.astype(np.float32), mask, int(mask.sum())
+
+
+def loss_reference_loops(A, plan, smooth=True, sigma=0.5, kernel_size=3, normalize_eot=False, n_prompt_tokens=None):
+    """The loss evaluated the way the reference executes it: Python double loops over the res x res pixels doing
+    scalar fp32 tensor operations, each an autograd node (pipeline:248-281, helpers.py:215-277), including the
+    `strict` branch (helpers.py:250-264).  Slow on purpose — it is the timing leg "reference-style loop loss" of
+    bench.py's cpu_baseline and the second, independent form the strict mode is checked with.
+    A: (res, res, ntok) fp32 NON-LEAF tensor (the reference scales a view of it in place)."""
+    res, ntok = A.shape[0], A.shape[-1]
+    first, last = text_slice(ntok, normalize_eot, n_prompt_tokens)
+    hp = plan.hyper
+    text = A[:, :, first:last]
+    text = text * 100
+    S = torch.nn.functional.softmax(text, dim=-1)
+    G = torch.from_numpy(gaussian_weights(kernel_size, sigma))
+    pad = kernel_size // 2
+    cw = hp.get("bb_center_weight", .05)
+    out = {"max": [], "col": [], "row": [], "inside": [], "outside": [], "token_loss": [], "unscaled": []}
+    total = None
+    for e, w_tok in zip(plan.entries, plan.token_weights()):
+        image = S[:, :, e["index"] - 1]
+        if smooth:
+            inp = torch.nn.functional.pad(image[None, None], (pad, pad, pad, pad), mode="reflect")
+            image = torch.nn.functional.conv2d(inp, G[None, None])[0, 0]
+        out["max"].append(image.max())
+        Pn = image / image.sum()
+        col = torch.zeros(1)
+        row = torch.zeros(1)
+        for ii in range(res):
+            for jj in range(res):
+                col = col + (jj + .5) * Pn[ii][jj]
+                row = row + (ii + .5) * Pn[ii][jj]
+        if e["kind"] == "BOX":
+            Wn, mask, n_in = strict_weights(e["geom"], res, hp["shrink_factor"])
+            at_most = 1.0 / n_in           # ZeroDivisionError when no pixel centre is inside, as in the reference
+            zero = torch.zeros(1)
+            if hp.get("strict", False):
+                inside = torch.zeros(1)
+                outside = torch.zeros(1)
+                for ii in range(res):
+                    for jj in range(res):
+                        if mask[ii, jj]:
+                            inside = inside + float(Wn[ii, jj]) * (2. * max(zero, at_most - Pn[ii, jj]))
+                        else:
+                            outside = outside + float(Wn[ii, jj]) * max(zero, Pn[ii, jj] - zero)
+            else:
+                s_in = torch.zeros(1)
+                s_out = torch.zeros(1)
+                for ii in range(res):
+                    for jj in range(res):
+                        if mask[ii, jj]:
+                            s_in = s_in + Pn[ii, jj]
+                        else:
+                            s_out = s_out + Pn[ii, jj]
+                inside, outside = 1. - s_in, s_out
+            center = rect_center(e["geom"])
+        else:
+            inside = outside = torch.zeros(1)
+            center = e["geom"]
+        centering = (col - center[0] * res).abs() / (res - 1.) + 4. * (row - center[1] * res).abs() / (res - 1.)
+        if e["kind"] == "BOX":
+            unscaled = inside + outside
+            item = hp["inside_loss_scale"] * inside + hp["outside_loss_scale"] * outside * 3
+            if cw > 0:
+                item = item + cw * centering
+        else:
+            item = unscaled = centering
+        for k, v in (("col", col), ("row", row), ("inside", inside), ("outside", outside), ("token_loss", item),
+                     ("unscaled", unscaled)):
+            out[k].append(v)
+        total = w_tok * item if total is None else total + w_tok * item
+    out["loss"] = total if total is not None else torch.zeros(1)
+    return out
+
+
 def subprompt_sums(plan, values):
     """pipeline:359-387 for a list of per-token values (e.g. the unscaled losses)."""
     sums = OrderedDict()

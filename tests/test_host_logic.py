@@ -251,3 +251,56 @@ def test_time_projection_buffer_equals_the_in_forward_computation():
     ref2 = unet(x, 481, encoder_hidden_states=ctx).sample
     out2 = unet(x, 481, encoder_hidden_states=ctx, time_projection=flat2).sample
     assert (out2 - ref2).abs().max() < 1e-4 * ref2.abs().max() and (ref2 - ref).abs().max() > 1e-3 * ref.abs().max()
+
+
+# ---- loss-plan cache key: content, not identity (round-1 advisor finding)
+def _plan_pipe(meta_prompt="a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55]"):
+    pipe = GuidedAttention(UNet2DConditionModel(UNetConfig.tiny(32, 48)), None, None, None, WordTokenizer())
+    cfg = RunConfig(meta_prompt=meta_prompt, output_path="/tmp/ga_test_out")
+    cfg.stable = pipe
+    state.curHyperParams = dict(state.hyperParameterOverrides)
+    run.parseMetaPrompt(cfg)
+    return pipe, cfg
+
+
+def test_loss_plan_is_keyed_on_content_not_identity():
+    pipe, cfg = _plan_pipe()
+    p1 = pipe._loss_plan(True, 0.5, 3)
+    run.parseMetaPrompt(cfg)                     # run.execute builds a FRESH but equal token_dict per (seed, state)
+    assert pipe._loss_plan(True, 0.5, 3) is p1   # -> same plan, hence the same hipGraphs
+    state.curHyperParams["recurse_steps"] = 1    # a hyper-parameter the plan does not read
+    assert pipe._loss_plan(True, 0.5, 3) is p1
+    cfg.token_dict[2]["loss"].x = 0.1            # in-place edit of a Rect: the plan bakes the geometry in by value
+    p2 = pipe._loss_plan(True, 0.5, 3)
+    assert p2 is not p1 and p2.tokens[0].geom[0] == 0.1
+    state.curHyperParams["shrink_factor"] = 0.0  # a hyper-parameter the plan reads
+    p3 = pipe._loss_plan(True, 0.5, 3)
+    assert p3 is not p2 and p3.params.shrink == 0.0
+    assert pipe._loss_plan(False, 0.5, 3) is not p3
+
+
+# ---- text K/V cache: entries a captured hipGraph reads are pinned against eviction
+def test_kv_cache_pins_survive_eviction():
+    attn = torch.nn.Module()
+    attn.to_k, attn.to_v = torch.nn.Linear(6, 4, bias=False), torch.nn.Linear(6, 4, bias=False)
+    unet = torch.nn.Module()
+    unet.a = attn
+    static = torch.randn(2, 5, 6)                        # the runner's static prompt buffer
+    k0, v0 = ptp_utils.cached_context_projections(attn, static)
+    k1, _ = ptp_utils.cached_context_projections(attn, static[1:2])
+    assert ptp_utils.pin_context_projections(unet, {static.untyped_storage().data_ptr()}, +1) == 2
+    others = [torch.randn(1, 5, 6) for _ in range(3 * ptp_utils.KV_CACHE_ENTRIES)]
+    for ctx in others:                                   # eager images with other prompts
+        ptp_utils.cached_context_projections(attn, ctx)
+    cache = attn.__dict__["_kv_cache"]
+    assert len(cache) == 2 + ptp_utils.KV_CACHE_ENTRIES  # the pinned pair + a bounded FIFO of the rest
+    k0b, v0b = ptp_utils.cached_context_projections(attn, static)
+    assert k0b is k0 and v0b is v0                       # same tensors: the pointers the graph captured stay valid
+    with torch.no_grad():
+        static.copy_(torch.randn(2, 5, 6))               # new prompt written into the static buffer
+    ptp_utils.refresh_context_projections(unet)
+    assert torch.allclose(k0, attn.to_k(static)) and torch.allclose(k1, attn.to_k(static[1:2]))  # refreshed in place
+    ptp_utils.pin_context_projections(unet, {static.untyped_storage().data_ptr()}, -1)
+    for ctx in others:
+        ptp_utils.cached_context_projections(attn, ctx + 1)
+    assert len(attn.__dict__["_kv_cache"]) == ptp_utils.KV_CACHE_ENTRIES
