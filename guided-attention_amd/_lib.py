@@ -31,7 +31,7 @@ class ga_token_t(ctypes.Structure):
 class ga_loss_params_t(ctypes.Structure):
     _fields_ = [("inside_scale", ctypes.c_float), ("outside_scale", ctypes.c_float), ("center_weight", ctypes.c_float),
                 ("sigma", ctypes.c_float), ("shrink", ctypes.c_double), ("ksize", ctypes.c_int32),
-                ("smooth", ctypes.c_int32)]
+                ("smooth", ctypes.c_int32), ("strict", ctypes.c_int32), ("_pad", ctypes.c_int32)]
 
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64

@@ -12,6 +12,9 @@
 //       col = sum (j+.5) Pn, row = sum (i+.5) Pn, inside = 1 - sum_in Pn, outside = sum_out Pn
 //       item = w_in*inside + 3*w_out*outside + w_c*(|col - res*cx| + 4|row - res*cy|)/(res-1)
 //   loss = sum_k weight_k * item_k
+// strict mode (curHyperParams["strict"], helpers.py:216-264): a per-pixel weight table W (inside: np.interp of the
+// normalised distance from the box centre, outside: 1; normalised separately over the inside and the outside pixels)
+// and hinge terms  inside = sum_in W * 2*max(0, 1/n_in - Pn),  outside = sum_out W * max(0, Pn).
 // The reference hard-codes res = 16 ("16", "15."); res and res-1 are used here (identical at 16).
 #include "ga_common.h"
 
@@ -26,7 +29,7 @@ constexpr int kThreads = 256;
 struct LossArgs {
   const float* A;
   int res, Kt, first, last, T;
-  int ksize, smooth;
+  int ksize, smooth, strict;
   float w_in, w_out3, w_c;
   double shrink;
   ga_token_t tok[kMaxTok];
@@ -87,13 +90,74 @@ __device__ __forceinline__ void pixel_softmax_stats(const LossArgs& a, float* mx
 }
 
 struct TokenStats {
-  float s, mxv, col, row, in, out;
+  float s, mxv, col, row, in, out, at_most;
 };
+
+// helpers.py:159-162 get_corresponding_weight = np.interp(x, [0, .333, .666, 1], [3, 2.5, 1, .2]) in float64
+__device__ __forceinline__ double interp_weight(double x) {
+  const double xp[4] = {0.0, .333, .666, 1.0}, fp[4] = {3.0, 2.5, 1.0, .2};
+  if (x <= xp[0]) return fp[0];
+  if (x >= xp[3]) return fp[3];
+  int j = 0;
+  while (j < 2 && x >= xp[j + 1]) ++j;
+  const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+  return slope * (x - xp[j]) + fp[j];
+}
+
+// helpers.py:216-246: the strict-mode weight table of one BOX token into W[npix] (LDS), normalised separately over
+// the inside and the outside pixels; the two sums run in pixel order in fp32 like the reference's (one thread: 256 to
+// 4096 adds, strict mode is off by default).  Returns 1/n_inside rounded to fp32 (`at_most`, helpers.py:249).
+__device__ __forceinline__ float strict_weights(const LossArgs& a, const ga_token_t& tk, float* W, float* scratch) {
+  const int res = a.res, npix = res * res;
+  const double ratio = (double)res;
+  const double x = __dmul_rn(tk.geom[0], ratio), y = __dmul_rn(tk.geom[1], ratio);
+  const double w = __dmul_rn(tk.geom[2], ratio), h = __dmul_rn(tk.geom[3], ratio);
+  const double ccx = __dadd_rn(x, w / 2.0), ccy = __dadd_rn(y, h / 2.0);  // Rect.center() of the scaled rect
+  for (int p = threadIdx.x; p < npix; p += kThreads) {
+    const int i = p / res, j = p - i * res;
+    float wv = 1.0f;  // outside: get_corresponding_weight_distance_from == 1
+    if (inside_box(tk, res, a.shrink, i, j)) {
+      const double dx = __ddiv_rn(__dmul_rn(2.0, __dsub_rn(ccx, (double)j + 0.5)), w);
+      const double dy = __ddiv_rn(__dmul_rn(2.0, __dsub_rn(ccy, (double)i + 0.5)), h);
+      const double d = __ddiv_rn(__dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy))), __dsqrt_rn(2.0));
+      wv = (float)interp_weight(d);
+    }
+    W[p] = wv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s_in = 0.f, s_out = 0.f;
+    int n_in = 0;
+    for (int p = 0; p < npix; ++p) {
+      const int i = p / res, j = p - i * res;
+      if (inside_box(tk, res, a.shrink, i, j)) {
+        s_in += W[p];
+        ++n_in;
+      } else {
+        s_out += W[p];
+      }
+    }
+    scratch[0] = s_in;
+    scratch[1] = s_out;
+    scratch[2] = (float)(1.0 / (double)n_in);
+  }
+  __syncthreads();
+  const float s_in = scratch[0], s_out = scratch[1], at_most = scratch[2];
+  for (int p = threadIdx.x; p < npix; p += kThreads) {
+    const int i = p / res, j = p - i * res;
+    W[p] = W[p] / (inside_box(tk, res, a.shrink, i, j) ? s_in : s_out);
+  }
+  __syncthreads();
+  return at_most;
+}
 
 // Forward of one token into LDS: M (raw map), Pn (smoothed, normalised).  Returns the reductions.
 __device__ __forceinline__ TokenStats token_forward(const LossArgs& a, const ga_token_t& tk, const float* mx,
-                                                    const float* sm, float* M, float* Pn, float* scratch) {
+                                                    const float* sm, float* M, float* Pn, float* W, float* scratch) {
   const int res = a.res, npix = res * res;
+  const bool strict = a.strict && tk.kind == GA_TOK_BOX;
+  float at_most = 0.f;
+  if (strict) at_most = strict_weights(a, tk, W, scratch);
   const int colA = a.first + tk.token - 1;  // pipeline:228 "index - 1" into the [first:last) slice
   for (int p = threadIdx.x; p < npix; p += kThreads) M[p] = expf(a.A[(size_t)p * a.Kt + colA] * 100.0f - mx[p]) / sm[p];
   __syncthreads();
@@ -128,10 +192,17 @@ __device__ __forceinline__ TokenStats token_forward(const LossArgs& a, const ga_
     v4[0] += ((float)j + 0.5f) * pn;
     v4[1] += ((float)i + 0.5f) * pn;
     if (tk.kind == GA_TOK_BOX) {
-      if (inside_box(tk, res, a.shrink, i, j))
+      const bool in = inside_box(tk, res, a.shrink, i, j);
+      if (strict) {  // helpers.py:250-264
+        if (in)
+          v4[2] += W[p] * (2.0f * fmaxf(0.f, at_most - pn));
+        else
+          v4[3] += W[p] * fmaxf(0.f, pn);
+      } else if (in) {
         v4[2] += pn;
-      else
+      } else {
         v4[3] += pn;
+      }
     }
   }
   block_sum<4>(v4, scratch);
@@ -139,6 +210,7 @@ __device__ __forceinline__ TokenStats token_forward(const LossArgs& a, const ga_
   st.row = v4[1];
   st.in = v4[2];
   st.out = v4[3];
+  st.at_most = at_most;
   return st;
 }
 
@@ -153,8 +225,8 @@ __device__ __forceinline__ TokenLoss token_loss(const LossArgs& a, const ga_toke
   if (tk.kind == GA_TOK_BOX) {  // helpers.py:26-27 Rect.center in float64, then used against fp32 tensors
     cx = (float)(tk.geom[0] + tk.geom[2] / 2.0);
     cy = (float)(tk.geom[1] + tk.geom[3] / 2.0);
-    r.inside = 1.0f - st.in;   // helpers.py:275
-    r.outside = st.out;        // helpers.py:276
+    r.inside = a.strict ? st.in : 1.0f - st.in;  // helpers.py:261 (strict) / :275
+    r.outside = st.out;                          // helpers.py:263 (strict) / :276
     r.w_in = a.w_in;
     r.w_out3 = a.w_out3;
     r.w_c = a.w_c > 0.f ? a.w_c : 0.f;
@@ -186,12 +258,13 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_fwd_kernel(LossArgs a, f
   float* M = sm + npix;
   float* Pn = M + npix;
   float* scratch = Pn + npix;  // 16 floats
+  float* W = scratch + 16;     // [npix], strict mode only
   pixel_softmax_stats(a, mx, sm);
   __syncthreads();
   float total = 0.f;
   for (int t = 0; t < a.T; ++t) {
     const ga_token_t& tk = a.tok[t];
-    const TokenStats st = token_forward(a, tk, mx, sm, M, Pn, scratch);
+    const TokenStats st = token_forward(a, tk, mx, sm, M, Pn, W, scratch);
     const TokenLoss tl = token_loss(a, tk, st);
     total += tk.weight * tl.item;
     if (threadIdx.x == 0) {
@@ -225,6 +298,7 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
   float* scratch = dot + npix;  // 16 floats
   int* colmap = reinterpret_cast<int*>(scratch + 16);  // [Kt]: guided-token slot of column c, or -1
   float* dS = reinterpret_cast<float*>(colmap + ((a.Kt + 3) & ~3));  // [T][npix]
+  float* W = dS + (size_t)a.T * npix;                                // [npix], strict mode only
 
   pixel_softmax_stats(a, mx, sm);
   for (int c = threadIdx.x; c < a.Kt; c += kThreads) colmap[c] = -1;
@@ -233,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
   const float rm1 = (float)res - 1.0f;
   for (int t = 0; t < a.T; ++t) {
     const ga_token_t& tk = a.tok[t];
-    const TokenStats st = token_forward(a, tk, mx, sm, M, Pn, scratch);
+    const TokenStats st = token_forward(a, tk, mx, sm, M, Pn, W, scratch);
     const TokenLoss tl = token_loss(a, tk, st);
     if (threadIdx.x == 0) colmap[a.first + tk.token - 1] = t;
     const float sgc = tl.dc > 0.f ? 1.f : (tl.dc < 0.f ? -1.f : 0.f);
@@ -242,7 +316,13 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
     for (int p = threadIdx.x; p < npix; p += kThreads) {
       const int i = p / res, j = p - i * res;
       float g = tl.w_c * (sgc / rm1 * ((float)j + 0.5f) + 4.0f * sgr / rm1 * ((float)i + 0.5f));
-      if (tk.kind == GA_TOK_BOX) g += inside_box(tk, res, a.shrink, i, j) ? -tl.w_in : tl.w_out3;
+      if (tk.kind == GA_TOK_BOX) {
+        const bool in = inside_box(tk, res, a.shrink, i, j);
+        if (a.strict)  // hinge terms: the gradient passes only where the hinge is open (Python max(min_loss, v): v > 0)
+          g += in ? (st.at_most - Pn[p] > 0.f ? -2.0f * tl.w_in * W[p] : 0.f) : (Pn[p] > 0.f ? tl.w_out3 * W[p] : 0.f);
+        else
+          g += in ? -tl.w_in : tl.w_out3;
+      }
       G[p] = g;
       gd[0] += g * Pn[p];
     }
@@ -296,9 +376,9 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
   }
 }
 
-size_t fwd_lds(int npix) { return sizeof(float) * (4 * (size_t)npix + 16); }
-size_t bwd_lds(int npix, int Kt, int T) {
-  return sizeof(float) * (6 * (size_t)npix + 16 + ((Kt + 3) & ~3) + (size_t)T * npix);
+size_t fwd_lds(int npix, int strict) { return sizeof(float) * ((4 + (strict ? 1 : 0)) * (size_t)npix + 16); }
+size_t bwd_lds(int npix, int Kt, int T, int strict) {
+  return sizeof(float) * ((6 + (strict ? 1 : 0)) * (size_t)npix + 16 + ((Kt + 3) & ~3) + (size_t)T * npix);
 }
 
 int fill_args(LossArgs& a, const float* A, int res, int Kt, int first, int last, const ga_token_t* tokens, int T,
@@ -322,6 +402,7 @@ int fill_args(LossArgs& a, const float* A, int res, int Kt, int first, int last,
   a.T = T;
   a.ksize = hp->smooth ? hp->ksize : 1;
   a.smooth = hp->smooth ? 1 : 0;
+  a.strict = hp->strict ? 1 : 0;
   a.w_in = hp->inside_scale;
   a.w_out3 = hp->outside_scale * 3.0f;
   a.w_c = hp->center_weight;
@@ -363,7 +444,7 @@ extern "C" int ga_smooth_loss_fwd(const float* A, int res, int Kt, int first, in
   LossArgs a;
   int rc = fill_args(a, A, res, Kt, first, last, tokens, T, hp);
   if (rc != GA_OK) return rc;
-  const size_t lds = fwd_lds(res * res);
+  const size_t lds = fwd_lds(res * res, a.strict);
   if (lds > 150 * 1024) return GA_ERR_SHAPE;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(smooth_loss_fwd_kernel),
@@ -392,7 +473,7 @@ extern "C" int ga_smooth_loss_bwd(const float* A, int res, int Kt, int first, in
   LossArgs a;
   int rc = fill_args(a, A, res, Kt, first, last, tokens, T, hp);
   if (rc != GA_OK) return rc;
-  const size_t lds = bwd_lds(res * res, Kt, T);
+  const size_t lds = bwd_lds(res * res, Kt, T, a.strict);
   if (lds > 150 * 1024) return GA_ERR_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {

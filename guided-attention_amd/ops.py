@@ -283,9 +283,13 @@ class LossPlan:
     # the hyper-parameters a plan reads (what its cache key must cover)
     HYPER_KEYS = ("strict", "inside_loss_scale", "outside_loss_scale", "bb_center_weight", "shrink_factor")
 
-    def __init__(self, entries, hyper, smooth=True, sigma=0.5, kernel_size=3, sub_prompt_avg_within=False):
+    def __init__(self, entries, hyper, smooth=True, sigma=0.5, kernel_size=3, sub_prompt_avg_within=False,
+                 check_geometry=True):
         """entries: list of dict(index, kind 'BOX'|'COOR', geom, subprompt)."""
         self.entries = list(entries)
+        self.check_geometry = check_geometry
+        self._checked_res = set()
+        self.shrink = float(hyper["shrink_factor"]) if "shrink_factor" in hyper else 0.0
         T = len(self.entries)
         self.T = T
         if T == 0:  # only custom (Python) losses are active: nothing for the fused kernel to do
@@ -304,9 +308,8 @@ class LossPlan:
             for j in range(4):
                 tk.geom[j] = float(geom[j])
             tk.weight = w
-        if hyper.get("strict", False):
-            raise GaError("strict bounding-box loss is not implemented (off by default in the reference)")
         self.params = _lib.ga_loss_params_t()
+        self.params.strict = 1 if hyper.get("strict", False) else 0
         self.params.inside_scale = hyper["inside_loss_scale"]
         self.params.outside_scale = hyper["outside_loss_scale"]
         self.params.center_weight = hyper.get("bb_center_weight", .05)
@@ -317,10 +320,29 @@ class LossPlan:
         self.T = T
 
 
+def _check_boxes(plan, res):
+    """The reference divides by the number of pixel centres inside the (shrunk) box (helpers.py:249,266:
+    `at_most = 1.0 / num_inside`): a box that contains none raises ZeroDivisionError there, and so it does here
+    (host-side, once per (plan, res))."""
+    if not plan.check_geometry or res in plan._checked_res:
+        return
+    for e in plan.entries:
+        if e["kind"] != "BOX":
+            continue
+        x, y, w, h = (float(v) * float(res) for v in e["geom"])
+        ox, oy = plan.shrink * w, plan.shrink * h
+        n_in = sum(1 for ii in range(res) for jj in range(res)
+                   if x + ox <= jj + 0.5 <= x + w - ox and y + oy <= ii + 0.5 <= y + h - oy)
+        if n_in == 0:
+            raise ZeroDivisionError("float division by zero")
+    plan._checked_res.add(res)
+
+
 def smooth_loss_fwd(A, res, first, last, plan):
     require_cuda(A)
     if plan.T == 0:
         raise GaError("no guided tokens")
+    _check_boxes(plan, res)
     if A.dtype != torch.float32:
         raise GaError("aggregated maps must be float32")
     A = A.contiguous()

@@ -145,13 +145,56 @@ def inside_mask(rect, res):
     return torch.tensor([[inside_box(jj, ii, rect) for jj in range(res)] for ii in range(res)], dtype=torch.bool)
 
 
+def get_corresponding_weight(x):
+    import numpy as np
+    return np.interp(x, [0, .333, .666, 1.0], [3, 2.5, 1, .2])  # hard drop off near edges (reference :159-162)
+
+
+def distance_from_center(cur_x, cur_y, rect, normalized):
+    import math
+    if sample_center:
+        cur_x += 0.5
+        cur_y += 0.5
+    if normalized:  # each dimension separately; 0 == at the centre, 1 == at the furthest corner
+        return math.sqrt(math.pow(2 * (rect.center()[0] - cur_x) / rect.width, 2) +
+                         math.pow(2 * (rect.center()[1] - cur_y) / rect.height, 2)) / math.sqrt(2)
+    return math.sqrt(math.pow(rect.center()[0] - cur_x, 2) + math.pow(rect.center()[1] - cur_y, 2))
+
+
+def strict_weight_table(r, res):
+    """The per-pixel weights of the strict mode (reference helpers.py:216-246) for a Rect scaled with of_size(res):
+    (weights (res, res) fp32 normalised separately over inside / outside, inside mask, number of inside pixels)."""
+    mask = inside_mask(r, res)
+    w = torch.ones(res, res)
+    for ii in range(res):
+        for jj in range(res):
+            if mask[ii, jj]:
+                w[ii, jj] = float(get_corresponding_weight(distance_from_center(jj, ii, r, True)))
+    s_in = torch.zeros(())
+    s_out = torch.zeros(())
+    for ii in range(res):      # fp32 sums in pixel order, as the reference accumulates them
+        for jj in range(res):
+            if mask[ii, jj]:
+                s_in = s_in + w[ii, jj]
+            else:
+                s_out = s_out + w[ii, jj]
+    w = torch.where(mask, w / s_in, w / s_out)
+    return w, mask, int(mask.sum())
+
+
 def calculate_bounding_box_losses(r, imageSoftmax):
-    """Non-strict form of reference helpers.py:215-277: (1 - mass inside, mass outside) of the
-    sum-normalised map.  Stand-alone operator; the hot path computes the same two numbers inside
-    ga_smooth_loss_fwd."""
-    if state.curHyperParams["strict"]:
-        raise NotImplementedError("strict bounding-box loss is off by default in the reference and not provided")
+    """reference helpers.py:215-277 — (inside loss, outside loss) of the sum-normalised map for a Rect scaled to the
+    map.  Non-strict: (1 - mass inside, mass outside).  Strict: the weighted hinge terms.  Stand-alone operator on any
+    device; the hot path computes the same two numbers inside ga_smooth_loss_fwd."""
     res = imageSoftmax.shape[0]
+    if state.curHyperParams["strict"]:
+        w, mask, n_in = strict_weight_table(r, res)
+        w, mask = w.to(imageSoftmax.device, imageSoftmax.dtype), mask.to(imageSoftmax.device)
+        at_most = 1.0 / n_in
+        zero = imageSoftmax.new_zeros(())
+        inside = torch.where(mask, w * 2. * torch.clamp(at_most - imageSoftmax, min=0), zero).sum().reshape(1)
+        outside = torch.where(mask, zero, w * torch.clamp(imageSoftmax, min=0)).sum().reshape(1)
+        return (inside, outside)
     mask = inside_mask(r, res).to(imageSoftmax.device)
     zero = imageSoftmax.new_zeros(())
     inside = torch.where(mask, imageSoftmax, zero).sum().reshape(1)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GA_VERSION 100 /* 0.1.0 */
+#define GA_VERSION 110 /* 0.1.1: ga_loss_params_t.strict */
 
 typedef void* ga_stream_t; /* hipStream_t */
 
@@ -83,7 +83,7 @@ int ga_aggregate_maps(const void* const* maps, const int* heads, int n_maps, int
  * K3+K4  the Gaussian-smoothed box loss.
  * Replaces pipeline_guided_attention.py:201-296 (_compute_max_attention_per_index),
  * utils/gaussian_smoothing.py:21-71, utils/helpers.py:164-173,215-277 (inside_box,
- * calculate_bounding_box_losses, non-strict) and pipeline_guided_attention.py:359-451
+ * calculate_bounding_box_losses, strict and non-strict) and pipeline_guided_attention.py:359-451
  * (_compute_loss / get_centering_loss / group_losses_by_sumprompt).
  */
 typedef enum { GA_TOK_COOR = 0, GA_TOK_BOX = 1 } ga_token_kind;
@@ -104,6 +104,8 @@ typedef struct {
   double shrink;        /* curHyperParams["shrink_factor"] */
   int32_t ksize;        /* Gaussian kernel size (odd, <= 7; the reference only runs 3) */
   int32_t smooth;       /* smooth_attentions */
+  int32_t strict;       /* curHyperParams["strict"]: the weighted hinge form of helpers.py:216-264 */
+  int32_t _pad;
 } ga_loss_params_t;
 
 #define GA_TERMS 8 /* per token: max, col, row, inside, outside, token_loss, unscaled, sum(M) */

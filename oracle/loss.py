@@ -128,10 +128,15 @@ def loss_torch(A, plan, smooth=True, sigma=0.5, kernel_size=3, normalize_eot=Fal
         out["row"].append(row)
         if e["kind"] == "BOX":
             mask = torch.from_numpy(inside_mask(e["geom"], res, hp["shrink_factor"]))
-            if hp.get("strict", False):
-                raise NotImplementedError("strict bbox loss is off by default and out of scope (SURVEY section 5)")
-            inside = 1.0 - Pn[mask].sum()                                      # helpers.py:265-277
-            outside = Pn[~mask].sum()
+            if hp.get("strict", False):                                        # helpers.py:216-264
+                Wn, _, n_in = strict_weights(e["geom"], res, hp["shrink_factor"])
+                Wt = torch.from_numpy(Wn).to(dtype)
+                at_most = 1.0 / n_in
+                inside = (Wt * 2.0 * torch.clamp(at_most - Pn, min=0))[mask].sum()
+                outside = (Wt * torch.clamp(Pn, min=0))[~mask].sum()
+            else:
+                inside = 1.0 - Pn[mask].sum()                                  # helpers.py:265-277
+                outside = Pn[~mask].sum()
             center = rect_center(e["geom"])
         else:
             inside = torch.zeros((), dtype=dtype)
@@ -322,10 +327,18 @@ def loss_and_grad_numpy(A, plan, smooth=True, sigma=0.5, kernel_size=3, normaliz
         Pn = M / s
         col = (jj * Pn).sum()
         row = (ii * Pn).sum()
+        Wn = at_most = None
         if e["kind"] == "BOX":
             mask = inside_mask(e["geom"], res, hp["shrink_factor"])
-            inside = 1.0 - Pn[mask].sum()
-            outside = Pn[~mask].sum()
+            if hp.get("strict", False):
+                Wn, _, n_in = strict_weights(e["geom"], res, hp["shrink_factor"])
+                Wn = Wn.astype(np.float64)
+                at_most = float(np.float32(1.0 / n_in))
+                inside = (Wn * 2.0 * np.maximum(at_most - Pn, 0.0))[mask].sum()
+                outside = (Wn * np.maximum(Pn, 0.0))[~mask].sum()
+            else:
+                inside = 1.0 - Pn[mask].sum()
+                outside = Pn[~mask].sum()
             cx, cy = rect_center(e["geom"])
             w_in, w_out, w_c = hp["inside_loss_scale"], 3.0 * hp["outside_loss_scale"], (cw if cw > 0 else 0.0)
         else:
@@ -345,7 +358,10 @@ def loss_and_grad_numpy(A, plan, smooth=True, sigma=0.5, kernel_size=3, normaliz
         # d item / d Pn
         g = w_c * (np.sign(dc) / (res - 1.) * jj + 4. * np.sign(dr) / (res - 1.) * ii) * np.ones((res, res))
         if e["kind"] == "BOX":
-            g = g + np.where(mask, -w_in, w_out)
+            if Wn is not None:  # hinge terms: gradient only where the hinge is open
+                g = g + np.where(mask, np.where(at_most - Pn > 0, -2.0 * w_in * Wn, 0.0), np.where(Pn > 0, w_out * Wn, 0.0))
+            else:
+                g = g + np.where(mask, -w_in, w_out)
         gM = (g - (g * Pn).sum()) / s                  # through Pn = M / sum(M)
         dS[:, :, k] += w_tok * (Rm.T @ gM @ Rm)        # adjoint of reflect-pad + correlation
         for name, v in (("max", M.max()), ("col", col), ("row", row), ("inside", inside), ("outside", outside),

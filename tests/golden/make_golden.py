@@ -28,6 +28,7 @@ from pathlib import Path
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 REF = Path("/root/reference")
 OUT = Path(__file__).resolve().parent
@@ -325,6 +326,11 @@ def g4_loss():
         # kernel_size 5 is not runnable in the reference (pad is hard-coded to 1: IndexError at
         # pipeline_guided_attention.py:267), so only sigma varies here
         ("s1_bos", BASE_PROMPT, "bos", 12, True, False, False, {"_sigma": 1.0, "_ksize": 3}),
+        # strict bounding-box mode (helpers.py:216-264: weight table + hinge terms)
+        ("strict_bos", BASE_PROMPT, "bos", 13, True, False, False, {"strict": True}),
+        ("strict_sharp_noshrink", BASE_PROMPT, "sharp", 14, True, False, False, {"strict": True, "shrink_factor": 0.0}),
+        ("strict_mixed_flat", "a [robot:.6,.3,.4,.55] and a [vase:.2,.45] on the [moon:.35,.05,.35,.35]", "flat", 15,
+         False, True, False, {"strict": True, "inside_loss_scale": .7, "outside_loss_scale": .4}),
     ]
     meta = []
     arrs = {}
@@ -529,16 +535,61 @@ def hash_init_(module, seed):
     return module
 
 
-class _UNetShim:
-    """Plain callable around the build's UNet module (the reference assigns `unet.__dict__['forward']`,
-    :854, which must stay inert here) with the attributes register_attention_control / __call__ read."""
+class _DiffusersFacade:
+    """The build's UNet blocks behind the diffusers-0.12.1 call signatures that the REFERENCE's own UNet forward
+    (pipeline_guided_attention.py:583-743) uses, so that this forward — time embedding, conv_in, the down / mid / up
+    sequence with its skip-tuple slicing and `upsample_size` rule, norm / act / conv_out — is what runs, not the
+    build's `UNet2DConditionModel.forward`.  The reference installs it with `unet.__dict__['forward'] = self.forward`
+    (:854); calling the facade dispatches to that entry exactly as `nn.Module.__call__` would.
+
+    What is adapted (block-internal conventions of diffusers, restated; absent from /root/reference):
+      * blocks receive the raw time embedding `temb`; the build's ResnetBlock2D takes SiLU(temb) (the SiLU sits
+        inside diffusers' ResnetBlock2D);
+      * up blocks receive `res_hidden_states_tuple` and consume it from its END;
+      * `conv_norm_out` and `conv_act` are separate callables (the build fuses the SiLU into the norm layer)."""
+
+    class _Down:
+        def __init__(self, blk):
+            self.blk, self.has_cross_attention = blk, blk.has_cross_attention
+
+        def __call__(self, hidden_states, temb, encoder_hidden_states=None, attention_mask=None,
+                     cross_attention_kwargs=None):
+            x, outs = self.blk(hidden_states, F.silu(temb), encoder_hidden_states)
+            return x, tuple(outs)
+
+    class _Up:
+        def __init__(self, blk):
+            self.blk, self.has_cross_attention, self.resnets = blk, blk.has_cross_attention, blk.resnets
+
+        def __call__(self, hidden_states, temb, res_hidden_states_tuple, encoder_hidden_states=None,
+                     cross_attention_kwargs=None, upsample_size=None, attention_mask=None):
+            skips = list(res_hidden_states_tuple)
+            out = self.blk(hidden_states, skips, F.silu(temb), encoder_hidden_states, upsample_size)
+            assert not skips, "an up block must consume exactly len(resnets) skip tensors"
+            return out
 
     def __init__(self, real):
+        from guided_attention_amd.unet import timestep_embedding
         self.real = real
-        self.config = types.SimpleNamespace(sample_size=real.config.sample_size,
-                                            cross_attention_dim=real.config.cross_attention_dim,
-                                            block_out_channels=list(real.config.block_out_channels))
+        cfg = real.config
+        self.config = types.SimpleNamespace(sample_size=cfg.sample_size, cross_attention_dim=cfg.cross_attention_dim,
+                                            block_out_channels=list(cfg.block_out_channels),
+                                            center_input_sample=cfg.center_input_sample, class_embed_type=None)
         self.in_channels = real.in_channels
+        self.num_upsamplers = real.num_upsamplers
+        self.dtype = real.dtype
+        self.class_embedding = None
+        self.time_proj = lambda timesteps: timestep_embedding(timesteps, cfg.block_out_channels[0])
+        self.time_embedding = real.time_embedding
+        self.conv_in = real.conv_in
+        self.down_blocks = [self._Down(b) for b in real.down_blocks]
+        self.mid_block = lambda sample, emb, encoder_hidden_states=None, attention_mask=None, \
+            cross_attention_kwargs=None: real.mid_block(sample, F.silu(emb), encoder_hidden_states)
+        self.up_blocks = [self._Up(b) for b in real.up_blocks]
+        n = real.conv_norm_out
+        self.conv_norm_out = lambda x: F.group_norm(x, n.num_groups, n.weight, n.bias, n.eps)
+        self.conv_act = F.silu
+        self.conv_out = real.conv_out
         self.calls = []
 
     @property
@@ -553,7 +604,8 @@ class _UNetShim:
 
     def __call__(self, sample, t, encoder_hidden_states=None, cross_attention_kwargs=None):
         self.calls.append((int(sample.shape[0]), bool(torch.is_grad_enabled() and sample.requires_grad)))
-        return self.real(sample, int(t), encoder_hidden_states=encoder_hidden_states)
+        out = self.__dict__["forward"](sample, t, encoder_hidden_states, return_dict=False)   # installed at :854
+        return types.SimpleNamespace(sample=out[0])
 
 
 def g9_loop():
@@ -639,7 +691,7 @@ def g9_loop():
         real = hash_init_(UNet2DConditionModel(cfgu), 9000 + 1000 * ci).float()
         for p in real.parameters():
             p.requires_grad_(False)
-        shim = _UNetShim(real)
+        shim = _DiffusersFacade(real)   # the loop runs the reference's OWN UNet forward (:583-743) on the build's blocks
         embeds = torch.from_numpy(hashrand.normalish((2, 77, 48), 9100 + ci))
         h = LoopHarness(shim, embeds)
         cfg = setup_prompt(h, BASE_PROMPT, hyper, only_update_on_threshold_steps=only_thr)
@@ -704,6 +756,56 @@ def g10_custom_loss():
                                                          "meta_info": ser_meta(cfg.meta_info)}))
 
 
+# ----------------------------------------------------------------------------- G11 the reference's own UNet forward
+def g11_unet_forward():
+    """`GuidedAttention.forward` (pipeline_guided_attention.py:583-743) of the reference, driven on the build's blocks
+    through `_DiffusersFacade`: pins the top-level wiring of guided_attention_amd/unet.py:forward (time path, skip
+    order and slicing, `forward_upsample_size` / `upsample_size`, `center_input_sample`, the output head)."""
+    sys.path.insert(0, str(OUT.parent.parent))
+    from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig
+    from oracle.attention import OracleStore
+    from oracle.pipeline import install_processors
+    cases = [
+        # name, config, latent (H, W), batch, timestep, seed
+        ("tiny_32", UNetConfig.tiny(32, 48), (32, 32), 1, 981, 11000),
+        ("tiny_36x28_b2", UNetConfig.tiny(32, 48), (36, 28), 2, 441, 11100),     # not multiples of 8: upsample_size path
+        ("tiny_centered", UNetConfig(sample_size=16, block_out_channels=(32, 64, 128, 128), attention_head_dim=2,
+                                     cross_attention_dim=48, center_input_sample=True), (16, 16), 1, 1, 11200),
+        ("sd21_like_24", UNetConfig(sample_size=24, block_out_channels=(32, 64, 128, 128), attention_head_dim=(1, 2, 4, 4),
+                                    cross_attention_dim=40, use_linear_projection=True), (24, 24), 1, 721.5, 11300),
+    ]
+    arrs, meta = {}, []
+    for name, cfg, (H, W), B, t, seed in cases:
+        real = hash_init_(UNet2DConditionModel(cfg), seed).float()
+        with torch.no_grad():   # non-zero biases so that every bias path of the wiring is visible
+            for pi, (pn, p) in enumerate(real.named_parameters()):
+                if pn.endswith("bias"):
+                    p.copy_(torch.from_numpy(hashrand.normalish(tuple(p.shape), seed + 5000 + pi) * np.float32(0.05)))
+        for p in real.parameters():
+            p.requires_grad_(False)
+        install_processors(real, OracleStore())
+        fac = _DiffusersFacade(real)
+        h = Harness()
+        h.unet = fac
+        x = torch.from_numpy(hashrand.normalish((B, 4, H, W), seed + 1))
+        ctx = torch.from_numpy(hashrand.normalish((B, 77, cfg.cross_attention_dim), seed + 2))
+        with torch.no_grad():
+            (y,) = pga.GuidedAttention.forward(h, x, t, ctx, return_dict=False)
+            y_t = pga.GuidedAttention.forward(h, x, torch.tensor(t), ctx, return_dict=False)[0]   # 0-d tensor timestep
+        assert torch.equal(y, y_t)
+        arrs[f"{name}.out"] = f32(y)
+        meta.append({"name": name, "seed": seed, "shape": [B, 4, H, W], "timestep": t,
+                     "config": {"sample_size": cfg.sample_size, "block_out_channels": list(cfg.block_out_channels),
+                                "attention_head_dim": cfg.attention_head_dim if isinstance(cfg.attention_head_dim, int)
+                                else list(cfg.attention_head_dim), "cross_attention_dim": cfg.cross_attention_dim,
+                                "use_linear_projection": cfg.use_linear_projection,
+                                "center_input_sample": cfg.center_input_sample},
+                     "out_abs_mean": float(y.abs().mean())})
+        print("g11", name, tuple(y.shape), meta[-1]["out_abs_mean"])
+    np.savez_compressed(OUT / "g11_unet_forward.npz", **arrs)
+    (OUT / "g11_unet_forward.json").write_text(json.dumps(meta, indent=1))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(1)  # deterministic reductions
@@ -717,6 +819,7 @@ def main():
     g8_update()
     g9_loop()
     g10_custom_loss()
+    g11_unet_forward()
     for p in sorted(OUT.glob("g*")):
         print(f"{p.name:32s} {p.stat().st_size:9d} B")
 

@@ -46,10 +46,29 @@ def test_version_and_strerror(lib):
     assert lib.ga_strerror(-999) == b"unknown status"
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+    """The ctypes mirrors against what a C compiler makes of include/ga_hip.h (sizes and every field offset)."""
+    import subprocess
     from guided_attention_amd import _lib
     assert ctypes.sizeof(_lib.ga_token_t) == 48      # 2*int32 + 4*double + 2*float
-    assert ctypes.sizeof(_lib.ga_loss_params_t) == 32
+    assert ctypes.sizeof(_lib.ga_loss_params_t) == 40
+    fields = {"ga_token_t": ["token", "kind", "geom", "weight"],
+              "ga_loss_params_t": ["inside_scale", "outside_scale", "center_weight", "sigma", "shrink", "ksize", "smooth",
+                                   "strict"]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "ga_hip.h"', "int main(void) {"]
+    for st, fs in fields.items():
+        src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        src += [f'  printf("{st}.{f} %zu\\n", offsetof({st}, {f}));' for f in fs]
+    src += ["  return 0;", "}"]
+    (tmp_path / "layout.c").write_text("\n".join(src))
+    subprocess.run(["gcc", "-I", str(HEADER.parent), str(tmp_path / "layout.c"), "-o", str(tmp_path / "layout")], check=True)
+    out = dict(line.split() for line in subprocess.run([str(tmp_path / "layout")], capture_output=True, text=True,
+                                                       check=True).stdout.splitlines())
+    for st, fs in fields.items():
+        cls = getattr(_lib, st)
+        assert int(out[st]) == ctypes.sizeof(cls)
+        for f in fs:
+            assert int(out[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)
 
 
 def test_gaussian_weights_host_entry(lib):

@@ -68,9 +68,15 @@ def test_calculate_bounding_box_losses_cpu_tensor():
     assert mask.sum() == 24
     np.testing.assert_allclose(float(inside), 1 - float(P[mask].sum()), rtol=1e-6)
     np.testing.assert_allclose(float(inside), float(outside), rtol=1e-5)  # both equal 1 - mass inside
+    # strict mode (helpers.py:216-264) against the oracle's pixel-loop restatement (itself pinned to g4 strict_*)
+    from oracle import loss as oloss
     state.curHyperParams["strict"] = True
-    with pytest.raises(NotImplementedError):
-        helpers.calculate_bounding_box_losses(helpers.Rect(0, 0, 1, 1, 1).of_size(16.0), P)
+    s_in, s_out = helpers.calculate_bounding_box_losses(helpers.Rect(.6, .3, .4, .55, 1).of_size(16.0), P)
+    Wn, m2, n_in = oloss.strict_weights((.6, .3, .4, .55), 16, state.curHyperParams["shrink_factor"])
+    assert n_in == 24 and np.array_equal(m2, mask.numpy())
+    ref_in = (Wn * 2 * np.maximum(1.0 / n_in - P.numpy(), 0))[m2].sum()
+    ref_out = (Wn * P.numpy())[~m2].sum()
+    np.testing.assert_allclose([float(s_in), float(s_out)], [ref_in, ref_out], rtol=2e-6)
     state.curHyperParams["strict"] = False
 
 

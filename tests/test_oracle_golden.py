@@ -228,3 +228,22 @@ def test_update_latent():
     np.testing.assert_allclose(grad.numpy(), g["grad"], rtol=1e-6, atol=1e-9)
     new = lat.detach() - float(g["step"]) * grad  # pipeline_guided_attention.py:466-469
     np.testing.assert_allclose(new.numpy(), g["out"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["base_bos", "base_bos_eot", "coor_bos", "mixed_sharp", "hyper2_flat", "strict_bos",
+                                  "strict_mixed_flat"])
+def test_loss_reference_loop_form_is_bit_exact(name):
+    """The pixel-loop form (what bench.py times as 'reference-style loop loss', and the second checker of the strict
+    mode) executes the reference's own fp32 operation sequence: values and autograd gradient equal the fixture's."""
+    g = load_npz("g4_loss.npz")
+    meta = next(m for m in G4_META if m["name"] == name)
+    plan = oloss.TokenPlan.from_golden(meta)
+    A = torch.from_numpy(g[f"{name}.A"]).requires_grad_(True)
+    r = oloss.loss_reference_loops(A * 1.0, plan, smooth=meta["smooth"], sigma=meta["sigma"],
+                                   kernel_size=meta["kernel_size"], normalize_eot=meta["normalize_eot"],
+                                   n_prompt_tokens=meta["n_prompt_tokens"])
+    assert float(r["loss"]) == float(g[f"{name}.loss"])
+    np.testing.assert_array_equal(np.array([float(v) for v in r["inside"]], np.float32), g[f"{name}.inside"])
+    np.testing.assert_array_equal(np.array([float(v) for v in r["outside"]], np.float32), g[f"{name}.outside"])
+    (dA,) = torch.autograd.grad(r["loss"], [A])
+    np.testing.assert_array_equal(dA.numpy(), g[f"{name}.dA"])

@@ -310,3 +310,68 @@ def test_sd21_768_shapes_one_guidance_step():
     np.testing.assert_allclose(terms[:, 5].cpu().numpy(), [float(v) for v in r["token_loss"]], rtol=2e-4, atol=1e-6)
     err = (g_hip.cpu() - g_ref).abs().max().item() / g_ref.abs().max().item()
     assert err < 3e-3, err
+
+
+def test_execute_reuses_graphs_across_seeds_and_survives_eager_images(tmp_path):
+    """`run.execute` (the reference's entry point) builds a fresh token_dict per (seed, hyper-parameter state): the
+    content-keyed loss plan must let both seeds replay ONE set of captured hipGraphs.  Eager images with other prompts
+    in between must not disturb the text K/V tensors the graphs read (they are pinned in the per-layer cache)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from guided_attention_amd import run
+    from guided_attention_amd.config import RunConfig
+    from guided_attention_amd.graphs import GraphRunner
+    from guided_attention_amd.pipeline_guided_attention import GuidedAttention
+    from guided_attention_amd.utils import shared_state as state
+    from guided_attention_amd.unet import UNetConfig
+    pipe = GuidedAttention.from_pretrained("random", random_init=True, unet_config=UNetConfig.tiny(32, 48), seed=5)
+    pipe.to("cuda", torch.float32)
+    pipe.use_graphs = True
+    cfg = RunConfig(meta_prompt="a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55]", seeds=[3, 4],
+                    n_inference_steps=3, output_path=tmp_path)
+    cfg.stable = pipe
+    state.config = cfg
+    state.hyperParameterIterations = [{}]
+    before = GraphRunner.captures
+    run.execute(cfg)
+    assert GraphRunner.captures == before + 1          # two seeds, one capture
+    first = [t.clone() for t in state.last_results["latents"]]
+    assert len(first) == 2 and (first[0] - first[1]).abs().max() > 1e-3
+    runner = next(iter(pipe._graph_cache.values()))
+    assert runner.pinned > 0
+    # eager, unguided images with several other prompts (each adds contexts to every layer's K/V cache)
+    for k in range(4):
+        cfg2 = RunConfig(meta_prompt=f"plain prompt number {k} with no annotations at all", seeds=[9],
+                         n_inference_steps=1, output_path=tmp_path, run_standard_sd=True)
+        cfg2.stable = pipe
+        state.config = cfg2
+        run.execute(cfg2, save=False)
+    state.config = cfg
+    run.execute(cfg, save=False)
+    assert GraphRunner.captures == before + 1          # still the same graphs
+    for a, b in zip(first, state.last_results["latents"]):
+        assert (a - b).abs().max().item() < 2e-4 * a.abs().max().item()
+    assert (tmp_path / "a _robot__6,_3,_4,_55_ and a _blue vase__2,_3,_4,_55_" / "3_strict_False_inside_loss_scale_0.2"
+            "_outside_loss_scale_0.2_shrink_factor_0.15_thresholds__0_1.0_use_optimizer_False_recurse_until_14"
+            "_recurse_steps_3.png").exists()
+
+
+def test_strict_mode_pipeline_vs_oracle():
+    """curHyperParams['strict'] = True through the whole product path (fused kernel fwd + bwd, UNet backward, latent
+    update), fp32, against the CPU oracle loop with the same hyper-parameters."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    meta = dict(G9[2], steps=2, hyper=dict(G9[2]["hyper"], strict=True))
+    thr = {0: 0.05}   # strict losses are ~0.1-0.3: forces refinement at step 0
+    unet, embeds, lat0, noise, _ = g9_setup(meta)
+    plan = oloss.TokenPlan(BASE_ENTRIES, meta["hyper"])
+    s = GuidedSampler(unet, plan, thresholds=thr, only_update_on_threshold_steps=meta["only_update_on_threshold_steps"],
+                      max_iter_to_alter=meta["max_iter_to_alter"], steps=meta["steps"], scale_factor=meta["scale_factor"])
+    ref = s.sample(lat0, embeds, noise).numpy()
+    import copy
+    pipe = build_product(copy.deepcopy(unet), torch.float32)
+    out, _ = run_product(pipe, meta, embeds, lat0, noise, thr)
+    assert s.calls["bwd"] >= 1
+    assert (out.unet_calls["fwd_b1_grad"], out.unet_calls["bwd"]) == (s.calls["fwd_b1_grad"], s.calls["bwd"])
+    err = np.abs(out.latents.float().cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < 5e-3, err
