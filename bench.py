@@ -150,6 +150,11 @@ def build_pipeline(args, device, rank, world):
     nbytes = sum(p.numel() * p.element_size() for p in unet.parameters())
     pipe = GuidedAttention(unet, None, None, SyntheticTextEncoder(cfg.cross_attention_dim), WordTokenizer())
     pipe.to(device, dtype)
+    if cfg.addition_embed_type == "text_time":   # SDXL: synthetic pooled text embeddings + the 1024^2 size/crop ids
+        g = torch.Generator("cpu").manual_seed(4321)
+        pooled = torch.randn(2, cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim, generator=g)
+        side = float(cfg.sample_size * 8)
+        unet.set_added_cond(pooled, torch.tensor([[side, side, 0.0, 0.0, side, side]] * 2))
     pipe.guidance_forward = args.guidance_forward
     pipe.skip_unused_guidance = args.skip_unused_guidance
     pipe.use_graphs = not args.eager
@@ -326,6 +331,12 @@ def cpu_baseline(args, cfg, calls, rc, reps=3):
     unet = UNet2DConditionModel(cfg).init_weights_(seed=0).float()
     for p in unet.parameters():
         p.requires_grad_(False)
+    if cfg.addition_embed_type == "text_time":
+        g0 = torch.Generator("cpu").manual_seed(4321)
+        pooled = torch.randn(2, cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim, generator=g0)
+        side = float(cfg.sample_size * 8)
+        unet.set_added_cond(pooled, torch.tensor([[side, side, 0.0, 0.0, side, side]] * 2))
+        reps = 1   # a 2.6 B-parameter fp32 forward takes the better part of a minute on the host: one repetition
     from guided_attention_amd.utils import helpers
     entries = []      # the guided tokens of the GPU run's own meta-prompt (rc.token_dict), as plain data
     for idx, info in rc.token_dict.items():

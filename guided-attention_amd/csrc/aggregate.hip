@@ -9,7 +9,7 @@ using namespace ga;
 
 namespace {
 
-constexpr int kMaxMaps = 32;
+constexpr int kMaxMaps = 128;  // SDXL at 1024^2: 60 stored 32x32 cross maps (AggArgs stays under the 4 KB kernarg limit)
 
 struct AggArgs {
   const void* maps[kMaxMaps];

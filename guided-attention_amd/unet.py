@@ -34,6 +34,10 @@ class UNetConfig:
     norm_eps: float = 1e-5
     use_linear_projection: bool = False
     center_input_sample: bool = False
+    transformer_layers_per_block: Union[int, Tuple[int, ...]] = 1   # BasicTransformerBlocks per Transformer2DModel, per level
+    addition_embed_type: Optional[str] = None                       # "text_time": SDXL's pooled-text + size/crop conditioning
+    addition_time_embed_dim: int = 256
+    projection_class_embeddings_input_dim: int = 2816
 
     @classmethod
     def sd15(cls):
@@ -43,6 +47,27 @@ class UNetConfig:
     def sd21(cls, sample_size=96):
         return cls(sample_size=sample_size, attention_head_dim=(5, 10, 20, 20), cross_attention_dim=1024,
                    use_linear_projection=True)
+
+    @classmethod
+    def sdxl(cls, sample_size=128):
+        """SDXL-base UNet shapes (BASELINE config 5; no reference behaviour exists — diffusers 0.12.1 predates SDXL):
+        3 levels 320/640/1280, no attention on the top level, 2 / 10 transformer blocks per attention on the lower two,
+        head_dim 64 (5/10/20 heads), 2048-wide text context, linear projections, text_time added conditioning."""
+        return cls(sample_size=sample_size, block_out_channels=(320, 640, 1280),
+                   down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                   up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                   attention_head_dim=(5, 10, 20), cross_attention_dim=2048, use_linear_projection=True,
+                   transformer_layers_per_block=(1, 2, 10), addition_embed_type="text_time")
+
+    @classmethod
+    def tiny_sdxl(cls, sample_size=32, cross_attention_dim=64):
+        """The SDXL layout at reduced width / depth, for tests."""
+        return cls(sample_size=sample_size, block_out_channels=(32, 64, 128),
+                   down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                   up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                   attention_head_dim=(1, 2, 4), cross_attention_dim=cross_attention_dim, use_linear_projection=True,
+                   transformer_layers_per_block=(1, 2, 3), addition_embed_type="text_time", addition_time_embed_dim=8,
+                   projection_class_embeddings_input_dim=6 * 8 + 40)
 
     @classmethod
     def tiny(cls, sample_size=64, cross_attention_dim=64):
@@ -181,7 +206,7 @@ class BasicTransformerBlock(nn.Module):
 
 
 class Transformer2DModel(nn.Module):
-    def __init__(self, heads, dim_head, in_channels, cross_attention_dim, groups, use_linear_projection):
+    def __init__(self, heads, dim_head, in_channels, cross_attention_dim, groups, use_linear_projection, depth=1):
         super().__init__()
         inner = heads * dim_head
         self.use_linear_projection = use_linear_projection
@@ -192,7 +217,8 @@ class Transformer2DModel(nn.Module):
         else:
             self.proj_in = nn.Conv2d(in_channels, inner, 1)
             self.proj_out = nn.Conv2d(inner, in_channels, 1)
-        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)
+                                                 for _ in range(depth)])
 
     def forward(self, x, context):
         b, c, h, w = x.shape
@@ -260,14 +286,14 @@ class Upsample2D(nn.Module):
 
 
 class DownBlock(nn.Module):
-    def __init__(self, cfg, in_c, out_c, temb_c, heads, add_downsample, has_attn):
+    def __init__(self, cfg, in_c, out_c, temb_c, heads, add_downsample, has_attn, depth=1):
         super().__init__()
         self.has_cross_attention = has_attn
         self.resnets = nn.ModuleList([ResnetBlock2D(in_c if i == 0 else out_c, out_c, temb_c, cfg.norm_num_groups,
                                                     cfg.norm_eps) for i in range(cfg.layers_per_block)])
         if has_attn:
             self.attentions = nn.ModuleList([Transformer2DModel(heads, out_c // heads, out_c, cfg.cross_attention_dim,
-                                                                cfg.norm_num_groups, cfg.use_linear_projection)
+                                                                cfg.norm_num_groups, cfg.use_linear_projection, depth)
                                              for _ in range(cfg.layers_per_block)])
         self.downsamplers = nn.ModuleList([Downsample2D(out_c)]) if add_downsample else None
 
@@ -285,13 +311,13 @@ class DownBlock(nn.Module):
 
 
 class MidBlock(nn.Module):
-    def __init__(self, cfg, channels, temb_c, heads):
+    def __init__(self, cfg, channels, temb_c, heads, depth=1):
         super().__init__()
         self.has_cross_attention = True
         self.resnets = nn.ModuleList([ResnetBlock2D(channels, channels, temb_c, cfg.norm_num_groups, cfg.norm_eps)
                                       for _ in range(2)])
         self.attentions = nn.ModuleList([Transformer2DModel(heads, channels // heads, channels, cfg.cross_attention_dim,
-                                                            cfg.norm_num_groups, cfg.use_linear_projection)])
+                                                            cfg.norm_num_groups, cfg.use_linear_projection, depth)])
 
     def forward(self, x, temb_act, context):
         x = self.resnets[0](x, temb_act)
@@ -300,7 +326,7 @@ class MidBlock(nn.Module):
 
 
 class UpBlock(nn.Module):
-    def __init__(self, cfg, in_c, out_c, prev_c, temb_c, heads, add_upsample, has_attn):
+    def __init__(self, cfg, in_c, out_c, prev_c, temb_c, heads, add_upsample, has_attn, depth=1):
         super().__init__()
         self.has_cross_attention = has_attn
         n = cfg.layers_per_block + 1
@@ -312,7 +338,7 @@ class UpBlock(nn.Module):
         self.resnets = nn.ModuleList(resnets)
         if has_attn:
             self.attentions = nn.ModuleList([Transformer2DModel(heads, out_c // heads, out_c, cfg.cross_attention_dim,
-                                                                cfg.norm_num_groups, cfg.use_linear_projection)
+                                                                cfg.norm_num_groups, cfg.use_linear_projection, depth)
                                              for _ in range(n)])
         self.upsamplers = nn.ModuleList([Upsample2D(out_c)]) if add_upsample else None
 
@@ -359,6 +385,8 @@ class UNet2DConditionModel(nn.Module):
         cfg = self.config = config or UNetConfig()
         ch = cfg.block_out_channels
         heads = cfg.attention_head_dim if isinstance(cfg.attention_head_dim, (tuple, list)) else (cfg.attention_head_dim,) * len(ch)
+        tl = cfg.transformer_layers_per_block
+        depth = tuple(tl) if isinstance(tl, (tuple, list)) else (tl,) * len(ch)
         temb_c = ch[0] * 4
         self.in_channels = cfg.in_channels
         self.conv_in = nn.Conv2d(cfg.in_channels, ch[0], 3, padding=1)
@@ -368,17 +396,24 @@ class UNet2DConditionModel(nn.Module):
         for i, kind in enumerate(cfg.down_block_types):
             in_c, out_c = out_c, ch[i]
             self.down_blocks.append(DownBlock(cfg, in_c, out_c, temb_c, heads[i], i != len(ch) - 1,
-                                              kind == "CrossAttnDownBlock2D"))
-        self.mid_block = MidBlock(cfg, ch[-1], temb_c, heads[-1])
+                                              kind == "CrossAttnDownBlock2D", depth[i]))
+        self.mid_block = MidBlock(cfg, ch[-1], temb_c, heads[-1], depth[-1])
         self.up_blocks = nn.ModuleList()
-        rev, rev_heads = list(reversed(ch)), list(reversed(heads))
+        rev, rev_heads, rev_depth = list(reversed(ch)), list(reversed(heads)), list(reversed(depth))
         out_c = rev[0]
         for i, kind in enumerate(cfg.up_block_types):
             prev_c, out_c = out_c, rev[i]
             in_c = rev[min(i + 1, len(ch) - 1)]
             self.up_blocks.append(UpBlock(cfg, in_c, out_c, prev_c, temb_c, rev_heads[i], i != len(ch) - 1,
-                                          kind == "CrossAttnUpBlock2D"))
+                                          kind == "CrossAttnUpBlock2D", rev_depth[i]))
         self.num_upsamplers = len(ch) - 1
+        self.add_embedding = None
+        if cfg.addition_embed_type == "text_time":   # SDXL: emb += add_embedding([pooled text | sinusoid(time_ids)])
+            self.add_embedding = TimestepEmbedding(cfg.projection_class_embeddings_input_dim, temb_c)
+        elif cfg.addition_embed_type is not None:
+            raise ValueError(f"addition_embed_type {cfg.addition_embed_type!r} is not supported")
+        self._added = None      # (2, temb_c) rows [uncond, cond] of add_embedding(...), set by set_added_cond
+        self._added_version = 0
         self.conv_norm_out = GroupNormAct(cfg.norm_num_groups, ch[0], eps=cfg.norm_eps, act=True)
         self.conv_out = nn.Conv2d(ch[0], cfg.out_channels, 3, padding=1)
 
@@ -422,6 +457,34 @@ class UNet2DConditionModel(nn.Module):
         parts = F.linear(temb_act, w, bias).split(sizes, dim=1)
         return {id(b): p for b, p in zip(blocks, parts)}
 
+    # rows of the [uncond, cond] added conditioning each batch layout of the pipeline uses: guidance pass (cond),
+    # CFG pass (uncond, cond), joint pass (cond | uncond, cond)
+    ADDED_ROWS = {1: (1,), 2: (0, 1), 3: (1, 0, 1)}
+
+    def set_added_cond(self, text_embeds, time_ids):
+        """SDXL added conditioning (`added_cond_kwargs` of the published UNet): text_embeds (2, P) pooled text
+        embeddings and time_ids (2, 6) = (orig h, w, crop top, left, target h, w) for [uncond, cond].  They are
+        constant over an image, so add_embedding(...) is evaluated once here and folded into the time projection."""
+        if self.add_embedding is None:
+            raise ValueError("this UNet has no added conditioning (addition_embed_type is None)")
+        with torch.no_grad():
+            ids = timestep_embedding(time_ids.reshape(-1).to(self.device), self.config.addition_time_embed_dim)
+            aug = torch.cat([text_embeds.to(self.device, torch.float32), ids.reshape(time_ids.shape[0], -1)], dim=-1)
+            if aug.shape != (2, self.config.projection_class_embeddings_input_dim):
+                raise ValueError(f"added conditioning has shape {tuple(aug.shape)}, expected "
+                                 f"(2, {self.config.projection_class_embeddings_input_dim})")
+            self._added = self.add_embedding(aug.to(self.dtype))
+        self._added_version += 1
+
+    def _added_rows(self, batch):
+        if self.add_embedding is None:
+            return None
+        if self._added is None:
+            raise ValueError("set_added_cond(text_embeds, time_ids) must be called before running this UNet")
+        if batch not in self.ADDED_ROWS:
+            raise ValueError(f"no added-conditioning layout for batch {batch}")
+        return self._added[list(self.ADDED_ROWS[batch])]
+
     def time_projection(self, timestep, batch):
         """Everything the UNet derives from the timestep alone — sinusoid, the 2-layer time MLP, SiLU and the 22
         per-block projections (with conv1's bias) — as ONE flat buffer laid out block-major, [block][batch][C_block],
@@ -438,14 +501,18 @@ class UNet2DConditionModel(nn.Module):
         cache = self.__dict__.setdefault("_tp_cache", {"key": None, "items": {}})
         if cache["key"] != wkey:
             cache["key"], cache["items"] = wkey, {}
-        k = (float(timestep), int(batch), self.dtype)
+        k = (float(timestep), int(batch), self.dtype, self._added_version)
         flat = cache["items"].get(k)
         if flat is None:
             with torch.no_grad():
                 t = torch.tensor([timestep], dtype=torch.int64 if float(timestep).is_integer() else torch.float64,
                                  device=self.device)
                 t_emb = timestep_embedding(t, self.config.block_out_channels[0]).to(self.dtype)
-                parts = self._time_projections(F.silu(self.time_embedding(t_emb)))
+                emb = self.time_embedding(t_emb)
+                added = self._added_rows(batch)
+                if added is not None:
+                    emb = emb + added          # (batch, temb_c): per-sample added conditioning
+                parts = self._time_projections(F.silu(emb))
                 flat = torch.cat([parts[id(b)].expand(batch, -1).reshape(-1) for b in blocks])
             cache["items"][k] = flat
         return flat
@@ -511,7 +578,11 @@ class UNet2DConditionModel(nn.Module):
                 timestep = timestep[None].to(sample.device)
             timestep = timestep.expand(sample.shape[0])
             t_emb = timestep_embedding(timestep, cfg.block_out_channels[0]).to(self.dtype)
-            temb_act = self._time_projections(F.silu(self.time_embedding(t_emb)))
+            emb = self.time_embedding(t_emb)
+            added = self._added_rows(sample.shape[0])
+            if added is not None:
+                emb = emb + added
+            temb_act = self._time_projections(F.silu(emb))
 
         x = self.conv_in(sample)
         skips = [x]

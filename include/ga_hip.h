@@ -73,7 +73,7 @@ int ga_attn_capture_bwd(const void* Q, const void* K, const void* V, const void*
 /* ---------------------------------------------------------------------------------------------
  * K2  aggregate_attention (utils/ptp_utils.py:273-289, select = 0): the mean over every head-map of
  * every stored tensor with npix pixels, summed in list order.
- *   maps[i]  device pointer to [heads[i]][npix][Kt] T   (host array of n_maps pointers, n_maps <= 32)
+ *   maps[i]  device pointer to [heads[i]][npix][Kt] T   (host array of n_maps pointers, n_maps <= 128)
  *   A        [npix][Kt] f32
  */
 int ga_aggregate_maps(const void* const* maps, const int* heads, int n_maps, int npix, int Kt,

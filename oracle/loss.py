@@ -197,14 +197,14 @@ def loss_reference_loops(A, plan, smooth=True, sigma=0.5, kernel_size=3, normali
     first, last = text_slice(ntok, normalize_eot, n_prompt_tokens)
     hp = plan.hyper
     text = A[:, :, first:last]
-    text = text * 100
+    text *= 100          # in place on the view, as the reference does (pipeline:217-218)
     S = torch.nn.functional.softmax(text, dim=-1)
     G = torch.from_numpy(gaussian_weights(kernel_size, sigma))
     pad = kernel_size // 2
     cw = hp.get("bb_center_weight", .05)
     out = {"max": [], "col": [], "row": [], "inside": [], "outside": [], "token_loss": [], "unscaled": []}
-    total = None
-    for e, w_tok in zip(plan.entries, plan.token_weights()):
+    groups = OrderedDict()
+    for e in plan.entries:
         image = S[:, :, e["index"] - 1]
         if smooth:
             inp = torch.nn.functional.pad(image[None, None], (pad, pad, pad, pad), mode="reflect")
@@ -255,8 +255,15 @@ def loss_reference_loops(A, plan, smooth=True, sigma=0.5, kernel_size=3, normali
         for k, v in (("col", col), ("row", row), ("inside", inside), ("outside", outside), ("token_loss", item),
                      ("unscaled", unscaled)):
             out[k].append(v)
-        total = w_tok * item if total is None else total + w_tok * item
-    out["loss"] = total if total is not None else torch.zeros(1)
+        groups.setdefault(e["subprompt"], []).append(item)
+    # group_losses_by_sumprompt (pipeline:359-387): per sub-prompt 0 + v/cnt (or v) in order, then 0 + the group totals
+    total = torch.zeros(1)
+    for vals in groups.values():
+        sub = torch.zeros(1)
+        for v in vals:
+            sub = sub + (v / len(vals) if plan.avg_within else v)
+        total = total + sub
+    out["loss"] = total
     return out
 
 

@@ -375,3 +375,59 @@ def test_strict_mode_pipeline_vs_oracle():
     assert (out.unet_calls["fwd_b1_grad"], out.unet_calls["bwd"]) == (s.calls["fwd_b1_grad"], s.calls["bwd"])
     err = np.abs(out.latents.float().cpu().numpy() - ref).max() / np.abs(ref).max()
     assert err < 5e-3, err
+
+
+@pytest.mark.parametrize("dt,tol_maps,tol_grad", [("f32", 1e-4, 3e-3), ("bf16", 4e-2, 3.5e-1)])
+def test_sdxl_layout_one_guidance_step(dt, tol_maps, tol_grad):
+    """BASELINE config 5 layout (no reference oracle exists: diffusers 0.12.1 predates SDXL): 3 levels, no attention on
+    the top level, 2 / 3 transformer blocks per attention below (SDXL: 2 / 10), per-level head counts, linear
+    projections, text_time added conditioning, attention_res = latent / 4, two guided tokens.  One guidance evaluation
+    + latent gradient, HIP vs the CPU oracle on the same module."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import copy
+    from guided_attention_amd import ops
+    from guided_attention_amd.pipeline_guided_attention import GuidedAttention
+    from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig
+    from guided_attention_amd.utils import ptp_utils, shared_state as state
+    from oracle import attention as oattn
+    from oracle.pipeline import install_processors
+    cfg = UNetConfig.tiny_sdxl(sample_size=32, cross_attention_dim=64)
+    unet = UNet2DConditionModel(cfg).init_weights_(seed=31).float()
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    pooled = torch.from_numpy(hashrand.normalish((2, 40), 3100))
+    time_ids = torch.tensor([[256., 256., 0., 0., 256., 256.]] * 2)
+    embeds = torch.from_numpy(hashrand.normalish((1, 77, 64), 3101))
+    lat = torch.from_numpy(hashrand.normalish((1, 4, 32, 32), 3102))
+    entries = [{"index": 2, "kind": "BOX", "geom": (.6, .3, .4, .55), "subprompt": "robot"},
+               {"index": 6, "kind": "BOX", "geom": (.2, .3, .4, .55), "subprompt": "vase"}]
+    res = 8
+    cpu_unet = copy.deepcopy(unet)
+    cpu_unet.set_added_cond(pooled, time_ids)
+    store = oattn.OracleStore()
+    install_processors(cpu_unet, store)
+    assert store.num_att_layers == 2 * (2 * 2 + 2 * 3 + 3 + 3 * 3 + 3 * 2)   # self + cross per transformer block
+    lat_c = lat.clone().requires_grad_(True)
+    cpu_unet(lat_c, 981, encoder_hidden_states=embeds)
+    A_ref = oattn.aggregate(store.attention_store, res, ("up", "down", "mid"), True)
+    r = oloss.loss_torch(A_ref, oloss.TokenPlan(entries))
+    (g_ref,) = torch.autograd.grad(r["loss"], [lat_c])
+    dtype = {"f32": torch.float32, "bf16": torch.bfloat16}[dt]
+    pipe = GuidedAttention(unet).to("cuda", dtype)
+    pipe.unet.set_added_cond(pooled, time_ids)
+    state.curHyperParams = dict(state.hyperParameterOverrides)
+    ctrl = ptp_utils.AttentionStore(attention_res=res)
+    ptp_utils.register_attention_control(pipe, ctrl)
+    lat_g = lat.cuda().to(dtype).requires_grad_(True)
+    pipe.unet(lat_g, 981, encoder_hidden_states=embeds.cuda().to(dtype))
+    # the 8x8 level holds down_blocks.2 (2 x 3), the mid block (3) and up_blocks.0 (3 x 3) cross maps
+    assert {k: len(v) for k, v in ctrl.attention_store.items() if v} == {"down_cross": 6, "mid_cross": 3, "up_cross": 9}
+    A = ptp_utils.aggregate_attention(ctrl, res, ("up", "down", "mid"), True, 0)
+    plan = ops.LossPlan(entries, state.curHyperParams)
+    terms, loss = ops.SmoothLoss.apply(A.reshape(res * res, 77), res, 1, 76, plan)
+    (g_hip,) = torch.autograd.grad(loss, [lat_g])
+    assert np.abs(A.detach().cpu().numpy() - A_ref.detach().numpy()).max() < tol_maps * A_ref.max().item()
+    np.testing.assert_allclose(loss.item(), float(r["loss"]), rtol=1e-4 if dt == "f32" else 3e-2)
+    err = (g_hip.float().cpu() - g_ref).abs().max().item() / g_ref.abs().max().item()
+    assert err < tol_grad, err
