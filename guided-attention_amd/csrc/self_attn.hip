@@ -26,6 +26,18 @@ namespace {
 
 constexpr int kThreads = 256;  // 4 waves
 
+// Ablation switches for tools/sa_variants.py (micro-benchmark builds only; the product build leaves GA_ABL at 0):
+// bit 0 no v_exp, bit 1 no staging inside the loop (tile 0 is re-read), bit 2 no barriers inside the loop,
+// bit 3 no P.V product, bit 4 no lazy-maximum test.  Results are wrong by construction; only the time is read.
+#ifndef GA_ABL
+#define GA_ABL 0
+#endif
+#ifndef GA_SCHED
+#define GA_SCHED 0
+#endif
+constexpr bool kAblNoExp = (GA_ABL & 1) != 0, kAblNoStage = (GA_ABL & 2) != 0, kAblNoBarrier = (GA_ABL & 4) != 0,
+               kAblNoPV = (GA_ABL & 8) != 0, kAblNoMax = (GA_ABL & 16) != 0;
+
 // KT = rows of the swept tile (keys in fwd / dq, queries in dk_dv): 64, or 128 where the registers allow it
 // (fewer barriers and loop overheads per key: the 16-query forward ran 111 -> 91 us on the 4096-token layer).
 template <typename T, int KT>
@@ -36,13 +48,13 @@ using TL = TileLds<T, KT>;
 // PRE = true keeps the per-lane global addresses in registers (computed once; full tiles load without exec-mask
 // branches): fastest where registers are free (forward).  PRE = false recomputes them per tile and costs no
 // registers: the backward kernels sit at the VGPR limit and lost 15 % with the resident addresses.
-template <typename T, int NK, int KT, bool PRE>
+template <typename T, int NK, int KT, bool PRE, int NT = kThreads>
 struct Stage {
   static constexpr int VEC = TL<T, KT>::VEC;
   static constexpr int DP = NK * 16;
   static constexpr int VPR = DP / VEC;                                    // vectors per row
   static constexpr int TOTAL = KT * VPR;                                  // vectors per tile
-  static constexpr int PER = (TOTAL + kThreads - 1) / kThreads;           // vectors per thread
+  static constexpr int PER = (TOTAL + NT - 1) / NT;           // vectors per thread
   static constexpr int NP = PRE ? PER : 1;
   uint4 v[PER];
   const T* base;      // the [rows][D] slice (wave-uniform: the loads take it as their scalar base)
@@ -54,7 +66,7 @@ struct Stage {
     if (PRE) {
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
-        const int idx = u * kThreads + (threadIdx.x & (kThreads - 1));
+        const int idx = u * NT + (threadIdx.x & (NT - 1));
         const int r = idx / VPR, d = (idx - r * VPR) * VEC;
         const bool live = idx < TOTAL && d < D;
         // Idle lanes (the columns D..DP of a row, or beyond the tile) read a valid vector of the same tile instead:
@@ -100,7 +112,7 @@ struct Stage {
       const int D = aux[0];
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
-        const int idx = u * kThreads + (threadIdx.x & (kThreads - 1));
+        const int idx = u * NT + (threadIdx.x & (NT - 1));
         const int r = idx / VPR, d = (idx - r * VPR) * VEC;
         v[u] = uint4{0, 0, 0, 0};
         if (idx < TOTAL && row0 + r < N && d < D)
@@ -109,21 +121,29 @@ struct Stage {
     }
   }
   __device__ __forceinline__ uint4 value(int u) const { return v[u]; }
+  // ones_d >= 0: the 16-byte vector that starts at column ones_d (the first pad vector of a head size that is not a
+  // multiple of 16) is stored as {1, 0, 0, ...} instead of what was loaded: a column of ones in the V image makes the
+  // P.V product deliver the softmax row sum in output row ones_d — no VALU adds for it (forward, 16-bit types).
+  // live_rows: rows of this tile below the sequence end; the dead rows of a partial last tile get a ZERO there (they
+  // are zero everywhere else too), so dead keys add nothing to numerator or row sum whatever their probability is.
   template <int STRIDE>
-  __device__ __forceinline__ void store_rows(T* img) const {  // row-major image with an explicit row stride
+  __device__ __forceinline__ void store_rows(T* img, int ones_d = -1, int live_rows = 1 << 30) const {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int idx = u * kThreads + (threadIdx.x & (kThreads - 1));
+      const int idx = u * NT + (threadIdx.x & (NT - 1));
       if (idx >= TOTAL) continue;
       const int r = idx / VPR, d = (idx - r * VPR) * VEC;
-      *reinterpret_cast<uint4*>(img + r * STRIDE + d) = value(u);
+      uint4 val = value(u);
+      if (d == ones_d) val = uint4{sizeof(T) == 2 ? (Traits<T>::kDtype == GA_F16 ? 0x3C00u : 0x3F80u) : 0x3F800000u, 0, 0, 0};
+      if (d == ones_d && r >= live_rows) val = uint4{0, 0, 0, 0};
+      *reinterpret_cast<uint4*>(img + r * STRIDE + d) = val;
     }
   }
   __device__ __forceinline__ void store(T* rowmaj, T* transposed) const {
     constexpr int KS = DP + VEC;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int idx = u * kThreads + (threadIdx.x & (kThreads - 1));
+      const int idx = u * NT + (threadIdx.x & (NT - 1));
       if (idx >= TOTAL) continue;
       const int r = idx / VPR, d = (idx - r * VPR) * VEC;
       const uint4 val = value(u);
@@ -164,9 +184,13 @@ struct RowFrags {
 // row block rb + 1 fly while rb's MFMAs issue; cheap in registers), NRB = the whole tile up front (the LDS latency
 // is paid once per tile instead of once per row block; 2 VGPRs per fragment).  The compiler, left alone, reuses one
 // register set and exposes the latency every row block.
-template <typename T, int NK, int NRB, int CB, int AHEAD = 1>
+// INIT: the first k-step of every row block takes init[cb] (ROWINIT: init_rows[rb], one value per accumulator row) as its
+// C operand instead of acc — row constants such as -max, -LSE or -delta enter through the MFMA for free, and acc needs
+// no zeroing.
+template <typename T, int NK, int NRB, int CB, int AHEAD = 1, bool INIT = false, bool ROWINIT = false>
 __device__ __forceinline__ void rows_times_cols(const T* img, const typename Traits<T>::frag (&x)[CB][NK], int c, int g,
-                                                f32x4 (&acc)[NRB][CB]) {
+                                                f32x4 (&acc)[NRB][CB], const f32x4* init = nullptr,
+                                                const f32x4* init_rows = nullptr) {
   constexpr int KS = NK * 16 + TileLds<T, 64>::VEC;
   constexpr int NS = AHEAD + 1 < NRB ? AHEAD + 1 : NRB;  // fragment register sets
   const typename Traits<T>::frag z = zero_frag<T>();
@@ -183,12 +207,13 @@ __device__ __forceinline__ void rows_times_cols(const T* img, const typename Tra
     const RowFrags<T, NK>& f = fr[rb % NS];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
+      const f32x4 cin = (INIT && kc == 0) ? (ROWINIT ? init_rows[rb] : init[cb]) : acc[rb][cb];
       if (kc + 1 < NK) {
-        acc[rb][cb] = Traits<T>::mma16x2(f.a[kc], f.a[kc + 1], x[cb][kc], x[cb][kc + 1], acc[rb][cb]);
+        acc[rb][cb] = Traits<T>::mma16x2(f.a[kc], f.a[kc + 1], x[cb][kc], x[cb][kc + 1], cin);
       } else if constexpr ((NK & 1) != 0) {  // the odd last chunk
         constexpr int L = RowFrags<T, NK>::NF - 1;  // index of the filler (16-bit types)
-        if constexpr (sizeof(T) == 2) acc[rb][cb] = Traits<T>::mma16x2(f.a[NK - 1], f.a[L], x[cb][NK - 1], z, acc[rb][cb]);
-        else acc[rb][cb] = Traits<T>::mma16(f.a[NK - 1], x[cb][NK - 1], acc[rb][cb]);
+        if constexpr (sizeof(T) == 2) acc[rb][cb] = Traits<T>::mma16x2(f.a[NK - 1], f.a[L], x[cb][NK - 1], z, cin);
+        else acc[rb][cb] = Traits<T>::mma16(f.a[NK - 1], x[cb][NK - 1], cin);
       }
     }
   };
@@ -302,11 +327,11 @@ __host__ __device__ constexpr int col_img() {
 }
 
 // stage one tile into the image read by rows (may be null) and the image read by columns
-template <typename T, int NK, int KT, bool PRE>
-__device__ __forceinline__ void store_tile(const Stage<T, NK, KT, PRE>& st, T* row_image, T* col_image) {
+template <typename T, int NK, int KT, bool PRE, int NT>
+__device__ __forceinline__ void store_tile(const Stage<T, NK, KT, PRE, NT>& st, T* row_image, T* col_image, int ones_d = -1) {
   if constexpr (kTrRead<T>) {
     if (row_image) st.store(row_image, nullptr);
-    st.template store_rows<trs<NK>()>(col_image);
+    st.template store_rows<trs<NK>()>(col_image, ones_d);
   } else {
     st.store(row_image, col_image);
   }
@@ -336,6 +361,17 @@ __device__ __forceinline__ void load_col_frags(const T* __restrict__ base, size_
 }
 
 // out^T accumulators [NK][CB] (feature rows, this lane's column) -> global rows [col][d], scaled per column block
+// x *= f, rounded once to T (the softmax scale folded into the Q operand: the MFMA then delivers log2-domain scores)
+template <typename T, int NK, int CB>
+__device__ __forceinline__ void scale_frags(typename Traits<T>::frag (&x)[CB][NK], float f) {
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[cb][kc][r] = Traits<T>::from_f32(Traits<T>::to_f32(x[cb][kc][r]) * f);
+}
+
 template <typename T, int NK, int CB>
 __device__ __forceinline__ void store_colsT(T* __restrict__ base, size_t row_stride, int row0, int N, int D, int c,
                                             int g, const f32x4 (&acc)[NK][CB], const float (&mul)[CB]) {
@@ -394,8 +430,18 @@ __device__ __forceinline__ float scale_of(int E) { return __uint_as_float((unsig
 constexpr float kLazy = 8.0f;  // forward: the running maximum is only raised when a score tops it by > 2^kLazy
 
 // =================================================================================================== forward
-template <typename T, int NK, int QB, int NBUF, int KT>
-__global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+// Softmax on a diet (the loop is VALU-issue bound at head_dim 40: 3.5 MFMAs per 16x16 score block against the vector
+// instructions of 4 scores per lane):
+//   * Q is pre-multiplied by scale * log2(e) once, so the MFMA delivers log2-domain scores;
+//   * the running maximum enters as the C operand of each score chain (C = -m): the accumulators come out as s - m,
+//     ready for v_exp_f32 — no subtract, no zeroing of the accumulators;
+//   * ONES (head sizes that are not a multiple of 16, e.g. 40): the first pad column of the V image holds 1.0, so the
+//     P.V product itself accumulates the row sum (of the same rounded P that multiplies V) in output row D;
+//   * what is left per score: v_exp_f32, half a v_cvt_pk, half a v_max3 (the lazy-maximum test).
+// Lazy maximum: m only moves when a score would exceed it by more than 2^kLazy (wave ballot; forced on the first
+// tile, where m starts at 0); then O, the sums and this tile's scores are rescaled by the same factor.
+template <typename T, int NK, int QB, int NBUF, int KT, bool ONES, int NW>
+__global__ __launch_bounds__(64 * NW) void self_attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                                  const T* __restrict__ V, T* __restrict__ O,
                                                                  float* __restrict__ LSE, int H, int N, int D, int nqt,
                                                                  int ldq, float scale) {
@@ -415,28 +461,30 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
   const T* Qb = Q + (size_t)b * N * rs + (size_t)head * D;
   const T* Kb = K + (size_t)b * N * rs + (size_t)head * D;
   const T* Vb = V + (size_t)b * N * rs + (size_t)head * D;
-  const int q0 = qt * (4 * QB * 16) + wave * (QB * 16);
-  const float c1 = scale * 1.4426950408889634f;
+  const int q0 = qt * (NW * QB * 16) + wave * (QB * 16);
+  const int ones_d = ONES ? D : -1;
 
   typename Tr::frag qf[QB][NK];
   load_col_frags<T, NK, QB>(Qb, rs, q0, N, D, c, g, qf);
+  scale_frags<T, NK, QB>(qf, scale * 1.4426950408889634f);
 
   const int ntiles = (N + KT - 1) / KT;
-  Stage<T, NK, KT, true> sk, sv;
+  Stage<T, NK, KT, true, 64 * NW> sk, sv;
   sk.init(Kb, D, rs);
   sv.init(Vb, D, rs);
   sk.load(0, N, rs);
   sv.load(0, N, rs);
   sk.store(lds, nullptr);
-  store_tile<T, NK, KT, true>(sv, nullptr, lds + kVoff);
+  store_tile(sv, (T*)nullptr, lds + kVoff, ones_d);
   __syncthreads();
 
-  f32x4 o[NK][QB];
+  f32x4 o[NK][QB], negm[QB];
   float m[QB], l[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    m[qb] = -INFINITY;
+    m[qb] = 0.f;
     l[qb] = 0.f;
+    negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < NK; ++dt) o[dt][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -453,13 +501,13 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
     sv.load(KT, N, rs);
   }
   for (int kt = 0; kt < ntiles; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < ntiles;
+    const int cur = kAblNoStage ? 0 : (kt & 1);
+    const bool more = !kAblNoStage && kt + 1 < ntiles;
     if (NBUF == 2) {
       if (more) {
         T* nxt = lds + (cur ^ 1) * kBuf;
         sk.store(nxt, nullptr);
-        store_tile<T, NK, KT, true>(sv, nullptr, nxt + kVoff);
+        store_tile(sv, (T*)nullptr, nxt + kVoff, ones_d);
         if (kt + 2 < ntiles) {
           sk.load((kt + 2) * KT, N, rs);
           sv.load((kt + 2) * KT, N, rs);
@@ -471,16 +519,12 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
     }
     {  // the tile's scores and probabilities live in registers inside this scope only
       f32x4 s[KT / 16][QB];
-#pragma unroll
-      for (int kb = 0; kb < KT / 16; ++kb)
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) s[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
       const T* kimg = lds + cur * kBuf;
       const T* vimg = kimg + kVoff;
       // 16 queries per wave leave the registers for whole-tile read-ahead (K before the score MFMAs, V under the
       // softmax); the 32-query variant keeps the depth-2 pipelines
       constexpr bool kAhead = kTrRead<T> && ((QB == 1 && NK <= 5) || (QB == 2 && NK <= 3));
-      rows_times_cols<T, NK, KT / 16, QB, kAhead ? KT / 16 : 1>(kimg, qf, c, g, s);
+      rows_times_cols<T, NK, KT / 16, QB, kAhead ? KT / 16 : 1, true>(kimg, qf, c, g, s, negm);  // s = q.k - m
       ColFrags<T, NK, kAhead ? KT / 16 : 2> vfr;
       if constexpr (kAhead) vfr.load(vimg, lane);
       const int key0 = kt * KT;
@@ -493,72 +537,327 @@ __global__ __launch_bounds__(kThreads) void self_attn_fwd_kernel(const T* __rest
             for (int r = 0; r < 4; ++r)
               if (key0 + kb * 16 + 4 * g + r >= N) s[kb][qb][r] = -INFINITY;
       }
-      typename Tr::frag pf[KT / 16][QB];
-      // Lazy running maximum: the reference exponent m[] (log2 domain, identical on the 4 lanes of a column) only
-      // moves when some score of the tile would exceed it by more than 2^kLazy; otherwise the tile needs no
-      // cross-lane traffic at all (each lane keeps its own partial row sum, reduced once after the sweep) and no
-      // rescale of O.  p <= 2^kLazy = 256 stays well inside fp16 / bf16 range; the sums are f32.
-      float lmax[QB];
-      bool grow = false;
+      float tmax[QB];
+      bool grow = kt == 0;
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         float mx = -INFINITY;
+        if (!kAblNoMax || kt == 0) {
+          // four independent chains (one per accumulator element), joined at the end: a single running maximum is a
+          // dependent chain of KT/8 v_max3 — serial latency the wave cannot hide at two waves per SIMD
+          float m4[4] = {s[0][qb][0], s[0][qb][1], s[0][qb][2], s[0][qb][3]};
 #pragma unroll
-        for (int kb = 0; kb < KT / 16; ++kb)
+          for (int kb = 1; kb + 1 < KT / 16; kb += 2)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
-        lmax[qb] = mx * c1;
-        grow |= lmax[qb] > m[qb] + kLazy;
+            for (int r = 0; r < 4; ++r) m4[r] = fmaxf(fmaxf(m4[r], s[kb][qb][r]), s[kb + 1][qb][r]);
+          if constexpr ((KT / 16) % 2 == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m4[r] = fmaxf(m4[r], s[KT / 16 - 1][qb][r]);
+          }
+          mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        }
+        tmax[qb] = mx;
+        grow |= mx > kLazy;
       }
       if (__builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform; typically the first tile or two only
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-          const float mn = fmaxf(m[qb], quad_max(lmax[qb]));
-          const float alpha = fast_exp2(m[qb] - mn);  // exp2(-inf) = 0 on the first tile
-          const f32x2 av = {alpha, alpha};
+          float d = quad_max(tmax[qb]);      // by how much this column's maximum moves (the first tile: from 0, any sign)
+          if (kt != 0) d = fmaxf(d, 0.f);
+          const float alpha = kt != 0 ? fast_exp2(-d) : 1.0f;
+          m[qb] += d;
           l[qb] *= alpha;
-          m[qb] = mn;
+          negm[qb] = f32x4{-m[qb], -m[qb], -m[qb], -m[qb]};
 #pragma unroll
-          for (int dt = 0; dt < NK; ++dt) {
-            o[dt][qb].xy *= av;
-            o[dt][qb].zw *= av;
-          }
+          for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][qb][r] *= alpha;
+#pragma unroll
+          for (int kb = 0; kb < KT / 16; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kb][qb][r] -= d;
         }
       }
+      typename Tr::frag pf[KT / 16][QB];
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        // two scores per VALU instruction where the ISA has packed f32 forms (v_pk_fma_f32, v_pk_add_f32)
-        const f32x2 c1v = {c1, c1}, mcv = {m[qb], m[qb]};
-        f32x2 sum2 = {0.f, 0.f};
+        float sum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < KT / 16; ++kb) {
-          const f32x2 t0 = s[kb][qb].xy * c1v - mcv, t1 = s[kb][qb].zw * c1v - mcv;
-          const f32x2 p0 = {fast_exp2(t0.x), fast_exp2(t0.y)}, p1 = {fast_exp2(t1.x), fast_exp2(t1.y)};
-          sum2 += p0;
-          sum2 += p1;
-          pf[kb][qb][0] = Tr::from_f32(p0.x);
-          pf[kb][qb][1] = Tr::from_f32(p0.y);
-          pf[kb][qb][2] = Tr::from_f32(p1.x);
-          pf[kb][qb][3] = Tr::from_f32(p1.y);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = kAblNoExp ? s[kb][qb][r] : fast_exp2(s[kb][qb][r]);
+            if (!ONES) sum += pr;
+            pf[kb][qb][r] = Tr::from_f32(pr);
+          }
         }
-        l[qb] += sum2.x + sum2.y;  // this lane's share of the row sum
+        if (!ONES) l[qb] += sum;  // this lane's share of the row sum
       }
-      if constexpr (kAhead) vfr.template apply<QB>(pf, o);
+      if constexpr (kAblNoPV) {  // keep the probabilities (and the V fragments) alive without the product
+#pragma unroll
+        for (int kb = 0; kb < KT / 16; ++kb)
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) asm volatile("" ::"v"(pf[kb][qb]));
+        if constexpr (kAhead) asm volatile("" ::"v"(vfr.a[0][0][0]));
+      } else if constexpr (kAhead) vfr.template apply<QB>(pf, o);
       else tileT_times_frags<T, NK, KT / 16, QB>(vimg, pf, lane, o);
     }
     if (NBUF == 1) {
       __syncthreads();  // single buffer: everyone is done reading before it is overwritten
       if (more) {
         sk.store(lds, nullptr);
-        store_tile<T, NK, KT, true>(sv, nullptr, lds + kVoff);
+        store_tile(sv, (T*)nullptr, lds + kVoff, ones_d);
       }
     }
-    __syncthreads();
+    if (!kAblNoBarrier) __syncthreads();
   }
   float inv[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    const float lsum = quad_sum(l[qb]);  // the 4 lanes of a column each hold a share
+    // ONES: output row D of O^T (feature block NK - 1, row D % 16 = 8 -> lanes g = 2, element 0) holds the row sum
+    const float lsum = ONES ? __shfl(o[NK - 1][qb][0], c + 32, 64) : quad_sum(l[qb]);
+    inv[qb] = 1.0f / lsum;
+    const int q = q0 + qb * 16 + c;
+    if (LSE != nullptr && g == 0 && q < N) LSE[((size_t)b * H + head) * N + q] = m[qb] + log2f(lsum);
+  }
+  store_colsT<T, NK, QB>(O + ((size_t)b * N * H + head) * D, rso, q0, N, D, c, g, o, inv);
+}
+
+// =================================================================================================== forward, pipelined
+// The same forward as a two-stage software pipeline inside each wave (16-bit types): while the VALU works on the
+// probabilities of tile k (v_exp, v_cvt_pk), the matrix pipe already computes the scores of tile k + 1, and the lazy-
+// maximum scan of tile k + 1 runs under the P.V MFMAs of tile k.  A wave issues in order, so the overlap has to be in
+// the instruction stream itself: the source interleaves one score row block (2 x QB MFMAs) with the softmax of one
+// row block (4 x QB v_exp + 2 x QB v_cvt_pk), which is also about the ratio the issue port sustains (an MFMA 16x16x32
+// holds vector issue for 8 of its 16 cycles).  At batch 1 the 64x64 layer has ONE wave per SIMD: without this every
+// phase of the loop (LDS reads, QK^T, softmax, P.V) ran back to back (measured: removing any one phase removed its
+// full time).  LDS: K is staged two tiles ahead (ring of 2: the scores of tile k + 1 are taken while V of tile k is
+// still in use), V one tile ahead; one barrier per tile.
+template <typename T, int NK, int QB, int KT, bool ONES, int NW>
+__global__ __launch_bounds__(64 * NW) void self_attn_fwd_pipe_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                                      const T* __restrict__ V, T* __restrict__ O,
+                                                                      float* __restrict__ LSE, int H, int N, int D,
+                                                                      int nqt, int ldq, float scale) {
+  using Tr = Traits<T>;
+  static_assert(sizeof(T) == 2, "transposing LDS reads: 16-bit types");
+  constexpr int NRB = KT / 16;
+  constexpr int KS = NK * 16 + TL<T, KT>::VEC;   // K row stride (elements): conflict-free 8-byte row reads
+  constexpr int VS = trs<NK>();                  // V row stride: conflict-free transposing reads
+  constexpr int kKimg = KT * KS, kVimg = KT * VS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const kring = reinterpret_cast<T*>(smem);   // [2][kKimg]
+  T* const vring = kring + 2 * kKimg;            // [2][kVimg]
+
+  const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const size_t rs = (size_t)ldq, rso = (size_t)H * D;
+  const T* Qb = Q + (size_t)b * N * rs + (size_t)head * D;
+  const T* Kb = K + (size_t)b * N * rs + (size_t)head * D;
+  const T* Vb = V + (size_t)b * N * rs + (size_t)head * D;
+  const int q0 = qt * (NW * QB * 16) + wave * (QB * 16);
+  const int ones_d = ONES ? D : -1;
+  const int nt = (N + KT - 1) / KT;
+
+  typename Tr::frag qf[QB][NK];
+  load_col_frags<T, NK, QB>(Qb, rs, q0, N, D, c, g, qf);
+  scale_frags<T, NK, QB>(qf, scale * 1.4426950408889634f);
+
+  Stage<T, NK, KT, true, 64 * NW> sk, sv;
+  sk.init(Kb, D, rs);
+  sv.init(Vb, D, rs);
+  // prologue: K0, V0 (and K1) into LDS; the staging registers then hold K2 / V1
+  sk.load(0, N, rs);
+  sv.load(0, N, rs);
+  sk.store(kring, nullptr);
+  sv.template store_rows<VS>(vring, ones_d, N);
+  if (nt > 1) {
+    sk.load(KT, N, rs);
+    sv.load(KT, N, rs);
+    sk.store(kring + kKimg, nullptr);
+    if (nt > 2) sk.load(2 * KT, N, rs);
+  }
+  __syncthreads();
+
+  f32x4 o[NK][QB], negm[QB];
+  float m[QB], l[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m[qb] = 0.f;
+    l[qb] = 0.f;
+    negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) o[dt][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const T* krow0 = kring + c * KS + 4 * g;   // this lane's fragment address inside a K image (row c, chunk offset 4g)
+  const int vi = lane & 15;
+  const T* vbase = vring + (4 * (lane >> 4) + (vi >> 2)) * VS + 4 * (vi & 3);   // transposing-read address (see T10)
+  const typename Tr::frag z = zero_frag<T>();
+
+  // scores of one K image into s (C operand of each chain = -m), no interleaving: prologue only
+  auto scores = [&](const T* kimg, f32x4 (&s)[NRB][QB]) {
+    rows_times_cols<T, NK, NRB, QB, 1, true>(kimg, qf, c, g, s, negm);
+  };
+  auto mask_tail = [&](int key0, f32x4 (&s)[NRB][QB]) {
+    if (key0 + KT > N) {  // only the last, partial tile (uniform branch)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + kb * 16 + 4 * g + r >= N) s[kb][qb][r] = -INFINITY;
+    }
+  };
+  // lazy maximum of a score tile (already relative to m): rescale everything at the old maximum by the same factor
+  auto renew_max = [&](const float (&tmax)[QB], bool first, f32x4 (&s)[NRB][QB]) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float d = quad_max(tmax[qb]);
+      if (!first) d = fmaxf(d, 0.f);
+      const float alpha = first ? 1.0f : fast_exp2(-d);
+      m[qb] += d;
+      l[qb] *= alpha;
+      negm[qb] = f32x4{-m[qb], -m[qb], -m[qb], -m[qb]};
+#pragma unroll
+      for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][qb][r] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kb][qb][r] -= d;
+    }
+  };
+  auto tile_max = [&](const f32x4 (&s)[NRB][QB], float (&tmax)[QB]) -> bool {
+    bool grow = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float m4[4] = {s[0][qb][0], s[0][qb][1], s[0][qb][2], s[0][qb][3]};
+#pragma unroll
+      for (int kb = 1; kb < NRB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m4[r] = fmaxf(m4[r], s[kb][qb][r]);
+      tmax[qb] = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      grow |= tmax[qb] > kLazy;
+    }
+    return grow;
+  };
+
+  // One pipeline stage: tile k's probabilities from s_cur (interleaved with tile k + 1's scores into s_nxt), then
+  // O += V(k)^T P (interleaved with the maximum scan of s_nxt), then the rare rescale.
+  auto stage = [&](int k, const T* kimg_next, const T* vimg_cur, f32x4 (&s_cur)[NRB][QB], f32x4 (&s_nxt)[NRB][QB]) {
+    // (on the last tile the "next" scores are taken from whatever the other K buffer holds and never used: one
+    // straight-line body, so that the softmax stays between the MFMAs instead of being hoisted out of a branch)
+    typename Tr::frag pf[NRB][QB];
+    {
+      RowFrags<T, NK> fr[2];
+      fr[0].load(kimg_next + (krow0 - kring));
+#pragma unroll
+      for (int kb = 0; kb < NRB; ++kb) {
+        if (kb + 1 < NRB) fr[(kb + 1) & 1].load(kimg_next + (krow0 - kring) + (kb + 1) * 16 * KS);
+        const RowFrags<T, NK>& f = fr[kb & 1];
+#pragma unroll
+        for (int kc = 0; kc < NK; kc += 2) {
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            const f32x4 cin = kc == 0 ? negm[qb] : s_nxt[kb][qb];
+            if (kc + 1 < NK) s_nxt[kb][qb] = Tr::mma16x2(f.a[kc], f.a[kc + 1], qf[qb][kc], qf[qb][kc + 1], cin);
+            else s_nxt[kb][qb] = Tr::mma16x2(f.a[NK - 1], f.a[RowFrags<T, NK>::NF - 1], qf[qb][NK - 1], z, cin);
+          }
+        }
+        // softmax of row block kb of the CURRENT tile: independent of the MFMAs above
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          float sum = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = fast_exp2(s_cur[kb][qb][r]);
+            if (!ONES) sum += pr;
+            pf[kb][qb][r] = Tr::from_f32(pr);
+          }
+          if (!ONES) l[qb] += sum;
+        }
+#if GA_SCHED
+        // pin the interleave: per row block 2*QB MFMAs, each followed by its share of the 4*QB v_exp + 2*QB v_cvt_pk
+#pragma unroll
+        for (int i = 0; i < ((NK + 1) / 2) * QB; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU (v_exp / v_cvt_pk)
+        }
+#endif
+      }
+      if (!ONES) mask_tail((k + 1) * KT, s_nxt);  // ONES: dead keys meet zero V rows and a zero in the ones column
+    }
+    // O^T += V^T P over pairs of row blocks (transposing reads), with the maximum scan of the next tile in between
+    const T* vb = vimg_cur + (vbase - vring);
+    float tmax[QB];
+    float m4[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m4[qb][r] = s_nxt[0][qb][r];
+#pragma unroll
+    for (int rb = 0; rb < NRB; rb += 2) {
+      typename Tr::frag a0[NK], a1[NK];
+#pragma unroll
+      for (int dt = 0; dt < NK; ++dt) {
+        a0[dt] = tr_read<T>(vb + rb * 16 * VS + dt * 16);
+        a1[dt] = tr_read<T>(vb + (rb + 1) * 16 * VS + dt * 16);
+      }
+#pragma unroll
+      for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) o[dt][qb] = Tr::mma16x2(a0[dt], a1[dt], pf[rb][qb], pf[rb + 1][qb], o[dt][qb]);
+      // the maximum scan of the NEXT tile's rows rb, rb + 1 (four independent chains per column block)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          m4[qb][r] = rb == 0 ? fmaxf(m4[qb][r], s_nxt[1][qb][r]) : fmaxf(fmaxf(m4[qb][r], s_nxt[rb][qb][r]), s_nxt[rb + 1][qb][r]);
+    }
+    bool grow = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      tmax[qb] = fmaxf(fmaxf(m4[qb][0], m4[qb][1]), fmaxf(m4[qb][2], m4[qb][3]));
+      grow |= tmax[qb] > kLazy;
+    }
+    if (k + 1 < nt && __builtin_amdgcn_ballot_w64(grow) != 0) renew_max(tmax, false, s_nxt);
+  };
+
+  f32x4 sa[NRB][QB], sb[NRB][QB];
+  scores(kring, sa);
+  if (!ONES || nt == 1) mask_tail(0, sa);   // a single, partial tile: its dead keys must not set the maximum
+  {
+    float tmax[QB];
+    (void)tile_max(sa, tmax);
+    renew_max(tmax, true, sa);   // the first tile sets m (from 0, any sign)
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the Q fragments have landed; do not wait for the prefetch later
+  // iteration k reads K(k+1) from kring[(k+1)&1] and V(k) from vring[k&1]; at its top the staging registers (K(k+2),
+  // V(k+1), loaded one iteration earlier) go to kring[k&1] / vring[(k+1)&1], both free since the last barrier
+  auto top = [&](int k) {
+    if (k + 2 < nt) sk.store(kring + (k & 1) * kKimg, nullptr);
+    if (k + 1 < nt) sv.template store_rows<VS>(vring + ((k + 1) & 1) * kVimg, ones_d, N - (k + 1) * KT);
+    if (k + 3 < nt) sk.load((k + 3) * KT, N, rs);
+    if (k + 2 < nt) sv.load((k + 2) * KT, N, rs);
+  };
+  int k = 0;
+  for (; k + 1 < nt; k += 2) {
+    top(k);
+    stage(k, kring + kKimg, vring, sa, sb);
+    __syncthreads();
+    top(k + 1);
+    stage(k + 1, kring, vring + kVimg, sb, sa);
+    __syncthreads();
+  }
+  if (k < nt) {  // odd tile count: the last tile's scores are in sa
+    top(k);
+    stage(k, kring + kKimg, vring, sa, sb);
+  }
+  float inv[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float lsum = ONES ? __shfl(o[NK - 1][qb][0], c + 32, 64) : quad_sum(l[qb]);
     inv[qb] = 1.0f / lsum;
     const int q = q0 + qb * 16 + c;
     if (LSE != nullptr && g == 0 && q < N) LSE[((size_t)b * H + head) * N + q] = m[qb] + log2f(lsum);
@@ -611,41 +910,63 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
       if (g == 0 && q < N) delta[((size_t)b * H + head) * N + q] = dl[qb];
     }
   }
-  Stage<T, NK, KT, false> sk, sv;
+  scale_frags<T, NK, QB>(qf, c1);  // log2-domain scores straight out of the MFMA (as in the forward)
+  // staging as in the forward (double buffer): the registers hold tile kt + 1 at the top of iteration kt, go to the
+  // other LDS buffer there (under the tile's math, not between math and barrier) and are refilled with tile kt + 2
+  constexpr bool kPre = NBUF == 2;
+  Stage<T, NK, KT, kPre> sk, sv;
   sk.init(K + off, D, rs);
   sv.init(V + off, D, rs);
   sk.load(0, N, rs);
   sv.load(0, N, rs);
-  store_tile<T, NK, KT, false>(sk, lds, lds + kToff);
+  store_tile(sk, lds, lds + kToff);
   sv.store(lds + kVoff, nullptr);
   __syncthreads();
 
-  f32x4 acc[NK][QB];
+  // Row constants as initial accumulators: the score chain starts from -LSE (+ E: the power-of-two scale of dS for
+  // the 16-bit MFMA, so p * 2^E = exp2(s - LSE + E) costs nothing), the dP chain from -delta.  Per score that leaves
+  // v_exp_f32, one multiply, half a v_max3 (|dS| against the renewal threshold) and half a v_cvt_pk.
+  constexpr bool kScaled = sizeof(T) == 2;
+  f32x4 acc[NK][QB], cs[QB], cdp[QB];
   int E[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    E[qb] = kNoExp;
+    E[qb] = kScaled ? kNoExp : 0;
+    const float c0 = (float)E[qb] - lse[qb];
+    cs[qb] = f32x4{c0, c0, c0, c0};
+    cdp[qb] = f32x4{-dl[qb], -dl[qb], -dl[qb], -dl[qb]};
 #pragma unroll
     for (int dt = 0; dt < NK; ++dt) acc[dt][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int ntiles = (N + KT - 1) / KT;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q / dO / O fragments have landed (see the forward)
+  if (NBUF == 2 && ntiles > 1) {
+    sk.load(KT, N, rs);
+    sv.load(KT, N, rs);
+  }
   for (int kt = 0; kt < ntiles; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < ntiles) {
+    if (NBUF == 2) {
+      if (kt + 1 < ntiles) {
+        T* nxt = lds + (cur ^ 1) * kBuf;
+        store_tile(sk, nxt, nxt + kToff);
+        sv.store(nxt + kVoff, nullptr);
+        if (kt + 2 < ntiles) {
+          sk.load((kt + 2) * KT, N, rs);
+          sv.load((kt + 2) * KT, N, rs);
+        }
+      }
+    } else if (kt + 1 < ntiles) {
       sk.load((kt + 1) * KT, N, rs);
       sv.load((kt + 1) * KT, N, rs);
     }
     f32x4 s[KT / 16][QB], dp[KT / 16][QB];
-#pragma unroll
-    for (int kb = 0; kb < KT / 16; ++kb)
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) s[kb][qb] = dp[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const T* buf = lds + cur * kBuf;
     // 16 columns per wave leave registers for whole-tile read-ahead (see the forward)
     constexpr bool kAhead = kTrRead<T> && QB == 1 && NK <= 5;
     constexpr int kA = kAhead ? KT / 16 : 1;
-    rows_times_cols<T, NK, KT / 16, QB, kA>(buf, qf, c, g, s);
-    rows_times_cols<T, NK, KT / 16, QB, kA>(buf + kVoff, dof, c, g, dp);
+    rows_times_cols<T, NK, KT / 16, QB, kA, true>(buf, qf, c, g, s, cs);            // s  = q.k - LSE + E
+    rows_times_cols<T, NK, KT / 16, QB, kA, true>(buf + kVoff, dof, c, g, dp, cdp);  // dp = dO.v - delta
     ColFrags<T, NK, kAhead ? KT / 16 : 2> kcol;
     if constexpr (kAhead) kcol.load(buf + kToff, lane);
     const int key0 = kt * KT;
@@ -658,59 +979,69 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
           for (int r = 0; r < 4; ++r)
             if (key0 + kb * 16 + 4 * g + r >= N) s[kb][qb][r] = -INFINITY;
     }
-    typename Tr::frag dsf[KT / 16][QB];
     float amax[QB];
     bool grow = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      // dS = P o (dP - delta), two scores per packed f32 instruction
-      const f32x2 c1v = {c1, c1}, lv = {lse[qb], lse[qb]}, dv = {dl[qb], dl[qb]};
       float am = 0.f;
 #pragma unroll
       for (int kb = 0; kb < KT / 16; ++kb) {
-        const f32x2 t0 = s[kb][qb].xy * c1v - lv, t1 = s[kb][qb].zw * c1v - lv;
-        const f32x2 p0 = {fast_exp2(t0.x), fast_exp2(t0.y)}, p1 = {fast_exp2(t1.x), fast_exp2(t1.y)};
-        const f32x2 d0 = p0 * (dp[kb][qb].xy - dv), d1 = p1 * (dp[kb][qb].zw - dv);
-        s[kb][qb].xy = d0;
-        s[kb][qb].zw = d1;
-        am = fmaxf(am, fmaxf(fabsf(d0.x), fabsf(d0.y)));
-        am = fmaxf(am, fmaxf(fabsf(d1.x), fabsf(d1.y)));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kb][qb][r] = fast_exp2(s[kb][qb][r]) * dp[kb][qb][r];  // dS * 2^E
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(s[kb][qb][0]), fabsf(s[kb][qb][1]))), fmaxf(fabsf(s[kb][qb][2]), fabsf(s[kb][qb][3])));
       }
       amax[qb] = am;
-      grow |= am * scale_of(E[qb]) > kGrow;
+      grow |= am > kGrow;
     }
-    // lazy power-of-two scale (16-bit operands): only when some |dS| outgrows the current scale by 2^4 does the
-    // wave reduce the column maxima across lanes and rescale its accumulators
-    if (sizeof(T) == 2 && __builtin_amdgcn_ballot_w64(grow) != 0) {
+    // lazy power-of-two scale (16-bit operands): only when some |dS| * 2^E outgrows 2^4 (always on the first tile,
+    // where E starts at 2^100) does the wave reduce the column maxima across lanes and renew the scale
+    if (kScaled && __builtin_amdgcn_ballot_w64(grow) != 0) {
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) rescale_running<NK, QB>(quad_max(amax[qb]), qb, E[qb], acc);
-    }
+      for (int qb = 0; qb < QB; ++qb) {
+        const float am = quad_max(amax[qb]);
+        if (am > 0.f && am < INFINITY) {
+          int e;
+          (void)frexpf(am, &e);  // am = mant * 2^e, mant in [0.5, 1): the new scale brings it back to [0.5, 1)
+          int want = E[qb] - e;
+          want = want < -120 ? -120 : (want > 99 ? 99 : want);
+          if (want < E[qb]) {
+            const float f = ldexpf(1.0f, want - E[qb]);
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      const float f = sizeof(T) == 2 ? scale_of(E[qb]) : 1.0f;
-      const f32x2 fv = {f, f};
+            for (int dt = 0; dt < NK; ++dt)
 #pragma unroll
-      for (int kb = 0; kb < KT / 16; ++kb) {
-        const f32x2 a = s[kb][qb].xy * fv, b = s[kb][qb].zw * fv;
-        dsf[kb][qb][0] = Tr::from_f32(a.x);
-        dsf[kb][qb][1] = Tr::from_f32(a.y);
-        dsf[kb][qb][2] = Tr::from_f32(b.x);
-        dsf[kb][qb][3] = Tr::from_f32(b.y);
+              for (int r = 0; r < 4; ++r) acc[dt][qb][r] *= f;
+#pragma unroll
+            for (int kb = 0; kb < KT / 16; ++kb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) s[kb][qb][r] *= f;
+            E[qb] = want;
+            const float c0 = (float)want - lse[qb];
+            cs[qb] = f32x4{c0, c0, c0, c0};
+          }
+        }
       }
     }
+    typename Tr::frag dsf[KT / 16][QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < KT / 16; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsf[kb][qb][r] = Tr::from_f32(s[kb][qb][r]);
     if constexpr (kAhead) kcol.template apply<QB>(dsf, acc);
     else tileT_times_frags<T, NK, KT / 16, QB>(buf + kToff, dsf, lane, acc);
-    if (NBUF == 1) __syncthreads();
-    if (kt + 1 < ntiles) {
-      T* nxt = lds + (cur ^ 1) * kBuf;
-      store_tile<T, NK, KT, false>(sk, nxt, nxt + kToff);
-      sv.store(nxt + kVoff, nullptr);
+    if (NBUF == 1) {
+      __syncthreads();
+      if (kt + 1 < ntiles) {
+        store_tile(sk, lds, lds + kToff);
+        sv.store(lds + kVoff, nullptr);
+      }
     }
     __syncthreads();
   }
   float mul[QB];
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) mul[qb] = (sizeof(T) == 2 && E[qb] != kNoExp) ? scale * ldexpf(1.0f, -E[qb]) : scale;
+  for (int qb = 0; qb < QB; ++qb) mul[qb] = (kScaled && E[qb] != kNoExp) ? scale * ldexpf(1.0f, -E[qb]) : scale;
   store_colsT<T, NK, QB>(dQ + off, rs, q0, N, D, c, g, acc, mul);
 }
 
@@ -745,14 +1076,16 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
   typename Tr::frag kf[KB][NK], vf[KB][NK];
   load_col_frags<T, NK, KB>(K + off, rs, k0, N, D, c, g, kf);
   load_col_frags<T, NK, KB>(V + off, rs, k0, N, D, c, g, vf);
+  scale_frags<T, NK, KB>(kf, c1);  // S = Q . (c1 K): log2-domain scores out of the MFMA (the forward scaled Q instead)
 
-  Stage<T, NK, KT, false> sq, sd;
-  float pl = 0.f, pd = 0.f;  // this thread's prefetched LSE / delta entry (threads 0..63)
+  constexpr bool kPre = NBUF == 2;
+  Stage<T, NK, KT, kPre> sq, sd;
+  float pl = 0.f, pd = 0.f;  // this thread's prefetched -LSE / -delta entry (threads 0..63)
   auto load_stats = [&](int q0t) {
     if (threadIdx.x < KT) {
       const int q = q0t + threadIdx.x;
-      pl = q < N ? LSE[soff + q] : 0.f;
-      pd = q < N ? delta[soff + q] : 0.f;
+      pl = q < N ? -LSE[soff + q] : 0.f;
+      pd = q < N ? -delta[soff + q] : 0.f;
     }
   };
   sq.init(Q + off, D, rs);
@@ -760,43 +1093,70 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
   sq.load(0, N, rs);
   sd.load(0, N, rso);
   load_stats(0);
-  store_tile<T, NK, KT, false>(sq, lds, lds + kQt);
-  store_tile<T, NK, KT, false>(sd, lds + kDr, lds + kDt);
+  store_tile(sq, lds, lds + kQt);
+  store_tile(sd, lds + kDr, lds + kDt);
   if (threadIdx.x < KT) {
     stats[threadIdx.x] = pl;
     stats[KT + threadIdx.x] = pd;
   }
   __syncthreads();
 
+  constexpr bool kScaled = sizeof(T) == 2;
   f32x4 dk[NK][KB], dv[NK][KB];
   int E[KB];
+  float fE[KB];  // 2^E
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
-    E[kb] = kNoExp;
+    E[kb] = kScaled ? kNoExp : 0;
+    fE[kb] = kScaled ? scale_of(kNoExp) : 1.0f;
 #pragma unroll
     for (int dt = 0; dt < NK; ++dt) dk[dt][kb] = dv[dt][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int ntiles = (N + KT - 1) / KT;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the K / V fragments have landed
+  if (NBUF == 2 && ntiles > 1) {
+    sq.load(KT, N, rs);
+    sd.load(KT, N, rso);
+    load_stats(KT);
+  }
   for (int qt = 0; qt < ntiles; ++qt) {
     const int cur = qt & 1;
-    if (qt + 1 < ntiles) {
+    if (NBUF == 2) {
+      if (qt + 1 < ntiles) {   // registers -> the other buffer (free since the last barrier), then refill them
+        T* nxt = lds + (cur ^ 1) * kBuf;
+        store_tile(sq, nxt, nxt + kQt);
+        store_tile(sd, nxt + kDr, nxt + kDt);
+        if (threadIdx.x < KT) {
+          stats[(cur ^ 1) * kSbuf + threadIdx.x] = pl;
+          stats[(cur ^ 1) * kSbuf + KT + threadIdx.x] = pd;
+        }
+        if (qt + 2 < ntiles) {
+          sq.load((qt + 2) * KT, N, rs);
+          sd.load((qt + 2) * KT, N, rso);
+          load_stats((qt + 2) * KT);
+        }
+      }
+    } else if (qt + 1 < ntiles) {
       sq.load((qt + 1) * KT, N, rs);
       sd.load((qt + 1) * KT, N, rso);
       load_stats((qt + 1) * KT);
     }
-    // S[q rows][key cols] and dP[q rows][key cols]
+    // S[q rows][key cols] and dP[q rows][key cols]; the query rows' -LSE / -delta (f32x4 per row block, straight from
+    // LDS) are the initial accumulators of the two chains
     f32x4 s[KT / 16][KB], dp[KT / 16][KB];
-#pragma unroll
-    for (int qb = 0; qb < KT / 16; ++qb)
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) s[qb][kb] = dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const T* buf = lds + cur * kBuf;
     const float* Lq = stats + cur * kSbuf;
     const float* Dq = Lq + KT;
+    f32x4 cl[KT / 16], cd[KT / 16];
+#pragma unroll
+    for (int qb = 0; qb < KT / 16; ++qb) {
+      cl[qb] = *reinterpret_cast<const f32x4*>(Lq + qb * 16 + 4 * g);
+      cd[qb] = *reinterpret_cast<const f32x4*>(Dq + qb * 16 + 4 * g);
+    }
     constexpr bool kAhead = kTrRead<T> && KB == 1 && NK <= 5;
     constexpr int kA = kAhead ? KT / 16 : 1;
-    rows_times_cols<T, NK, KT / 16, KB, kA>(buf, kf, c, g, s);
-    rows_times_cols<T, NK, KT / 16, KB, kA>(buf + kDr, vf, c, g, dp);
+    rows_times_cols<T, NK, KT / 16, KB, kA, true, true>(buf, kf, c, g, s, nullptr, cl);         // s  = q.k - LSE
+    rows_times_cols<T, NK, KT / 16, KB, kA, true, true>(buf + kDr, vf, c, g, dp, nullptr, cd);  // dp = dO.v - delta
     ColFrags<T, NK, kAhead ? KT / 16 : 2> docol, qcol;
     if constexpr (kAhead) {
       docol.load(buf + kDt, lane);
@@ -804,56 +1164,68 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
     }
     const int q0t = qt * KT;
     typename Tr::frag pf[KT / 16][KB], dsf[KT / 16][KB];
-    const bool edge = q0t + KT > N;  // wave-uniform: only the last query tile has dead rows
+    // wave-uniform: only the last query tile has dead rows, only the last key block of a ragged sequence dead columns
+    const bool edge = q0t + KT > N || k0 + KB * 16 > N;
+    if (edge) {  // dead rows / columns contribute nothing: p = exp2(-inf) = 0
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const bool key_live = k0 + kb * 16 + c < N;
+#pragma unroll
+        for (int qb = 0; qb < KT / 16; ++qb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (!key_live || q0t + qb * 16 + 4 * g + r >= N) s[qb][kb][r] = -INFINITY;
+      }
+    }
     float amax[KB];
     bool grow = false;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      const bool key_live = k0 + kb * 16 + c < N;
-      const f32x2 c1v = {c1, c1};
       float am = 0.f;
 #pragma unroll
       for (int qb = 0; qb < KT / 16; ++qb) {
-        const int qi = qb * 16 + 4 * g;
-        const f32x4 L = *reinterpret_cast<const f32x4*>(Lq + qi), Dl = *reinterpret_cast<const f32x4*>(Dq + qi);
-        const f32x2 t0 = s[qb][kb].xy * c1v - L.xy, t1 = s[qb][kb].zw * c1v - L.zw;
-        f32x2 p0 = {fast_exp2(t0.x), fast_exp2(t0.y)}, p1 = {fast_exp2(t1.x), fast_exp2(t1.y)};
-        if (edge || !key_live) {  // dead query rows / dead key columns contribute nothing
-          p0.x = (key_live && q0t + qi + 0 < N) ? p0.x : 0.f;
-          p0.y = (key_live && q0t + qi + 1 < N) ? p0.y : 0.f;
-          p1.x = (key_live && q0t + qi + 2 < N) ? p1.x : 0.f;
-          p1.y = (key_live && q0t + qi + 3 < N) ? p1.y : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = fast_exp2(s[qb][kb][r]);
+          pf[qb][kb][r] = Tr::from_f32(pr);
+          s[qb][kb][r] = (pr * fE[kb]) * dp[qb][kb][r];  // dS * 2^E
         }
-        const f32x2 d0 = p0 * (dp[qb][kb].xy - Dl.xy), d1 = p1 * (dp[qb][kb].zw - Dl.zw);
-        pf[qb][kb][0] = Tr::from_f32(p0.x);
-        pf[qb][kb][1] = Tr::from_f32(p0.y);
-        pf[qb][kb][2] = Tr::from_f32(p1.x);
-        pf[qb][kb][3] = Tr::from_f32(p1.y);
-        s[qb][kb].xy = d0;
-        s[qb][kb].zw = d1;
-        am = fmaxf(am, fmaxf(fabsf(d0.x), fabsf(d0.y)));
-        am = fmaxf(am, fmaxf(fabsf(d1.x), fabsf(d1.y)));
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(s[qb][kb][0]), fabsf(s[qb][kb][1]))), fmaxf(fabsf(s[qb][kb][2]), fabsf(s[qb][kb][3])));
       }
       amax[kb] = am;
-      grow |= am * scale_of(E[kb]) > kGrow;
+      grow |= am > kGrow;
     }
-    if (sizeof(T) == 2 && __builtin_amdgcn_ballot_w64(grow) != 0) {
+    if (kScaled && __builtin_amdgcn_ballot_w64(grow) != 0) {
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) rescale_running<NK, KB>(quad_max(amax[kb]), kb, E[kb], dk);
-    }
+      for (int kb = 0; kb < KB; ++kb) {
+        const float am = quad_max(amax[kb]);
+        if (am > 0.f && am < INFINITY) {
+          int e;
+          (void)frexpf(am, &e);
+          int want = E[kb] - e;
+          want = want < -120 ? -120 : (want > 99 ? 99 : want);
+          if (want < E[kb]) {
+            const float f = ldexpf(1.0f, want - E[kb]);
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const float f = sizeof(T) == 2 ? scale_of(E[kb]) : 1.0f;
-      const f32x2 fv = {f, f};
+            for (int dt = 0; dt < NK; ++dt)
 #pragma unroll
-      for (int qb = 0; qb < KT / 16; ++qb) {
-        const f32x2 a = s[qb][kb].xy * fv, b = s[qb][kb].zw * fv;
-        dsf[qb][kb][0] = Tr::from_f32(a.x);
-        dsf[qb][kb][1] = Tr::from_f32(a.y);
-        dsf[qb][kb][2] = Tr::from_f32(b.x);
-        dsf[qb][kb][3] = Tr::from_f32(b.y);
+              for (int r = 0; r < 4; ++r) dk[dt][kb][r] *= f;
+#pragma unroll
+            for (int qb = 0; qb < KT / 16; ++qb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) s[qb][kb][r] *= f;
+            E[kb] = want;
+            fE[kb] = scale_of(want);
+          }
+        }
       }
     }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int qb = 0; qb < KT / 16; ++qb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsf[qb][kb][r] = Tr::from_f32(s[qb][kb][r]);
     if constexpr (kAhead) {
       docol.template apply<KB>(pf, dv);   // dV^T += dO^T P
       qcol.template apply<KB>(dsf, dk);   // dK^T += Q^T dS
@@ -861,14 +1233,15 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
       tileT_times_frags<T, NK, KT / 16, KB>(buf + kDt, pf, lane, dv);
       tileT_times_frags<T, NK, KT / 16, KB>(buf + kQt, dsf, lane, dk);
     }
-    if (NBUF == 1) __syncthreads();
-    if (qt + 1 < ntiles) {
-      T* nxt = lds + (cur ^ 1) * kBuf;
-      store_tile<T, NK, KT, false>(sq, nxt, nxt + kQt);
-      store_tile<T, NK, KT, false>(sd, nxt + kDr, nxt + kDt);
-      if (threadIdx.x < KT) {
-        stats[(cur ^ 1) * kSbuf + threadIdx.x] = pl;
-        stats[(cur ^ 1) * kSbuf + KT + threadIdx.x] = pd;
+    if (NBUF == 1) {
+      __syncthreads();
+      if (qt + 1 < ntiles) {
+        store_tile(sq, lds, lds + kQt);
+        store_tile(sd, lds + kDr, lds + kDt);
+        if (threadIdx.x < KT) {   // the row statistics are double-buffered in both modes
+          stats[(cur ^ 1) * kSbuf + threadIdx.x] = pl;
+          stats[(cur ^ 1) * kSbuf + KT + threadIdx.x] = pd;
+        }
       }
     }
     __syncthreads();
@@ -876,7 +1249,8 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
   float mk[KB], one[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
-    mk[kb] = (sizeof(T) == 2 && E[kb] != kNoExp) ? scale * ldexpf(1.0f, -E[kb]) : scale;
+    // dK = scale * sum dS^T Q; the scores used c1 K, the product here used the unscaled Q image: only `scale` is left
+    mk[kb] = (kScaled && E[kb] != kNoExp) ? scale * ldexpf(1.0f, -E[kb]) : scale;
     one[kb] = 1.0f;
   }
   store_colsT<T, NK, KB>(dK + off, rs, k0, N, D, c, g, dk, mk);
@@ -913,18 +1287,59 @@ bool wide_columns(int B, int H, int N, bool backward) {
   return NK <= 5 && (long long)B * H * ((N + 127) / 128) >= (backward ? 512 : 192);
 }
 
+template <typename T, int NK, int KT>
+size_t fwd_pipe_lds() { return sizeof(T) * 2 * (KT * (NK * 16 + TL<T, KT>::VEC) + KT * trs<NK>()); }
+
+#ifndef GA_FWD_PIPE
+#define GA_FWD_PIPE 0
+#endif
+
+template <typename T, int NK, int QB>
+int launch_fwd_pipe(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D,
+                    int ldq, float scale, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    constexpr int KT = 64, NW = 4;
+    const size_t lds = fwd_pipe_lds<T, NK, KT>();
+    if (lds > kLdsLimit) return GA_ERR_SHAPE;
+    const int nqt = (N + 16 * NW * QB - 1) / (16 * NW * QB);
+    constexpr bool kCanOnes = (NK & 1) != 0;
+    auto k = self_attn_fwd_pipe_kernel<T, NK, QB, KT, false, NW>;
+    if constexpr (kCanOnes) {
+      if ((D & 15) != 0) k = self_attn_fwd_pipe_kernel<T, NK, QB, KT, true, NW>;
+    }
+    int rc = set_dyn_lds(k, lds);
+    if (rc != GA_OK) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)(B * H * nqt)), dim3(64 * NW), lds, s, (const T*)Q, (const T*)K, (const T*)V,
+                       (T*)O, LSE, H, N, D, nqt, ldq, scale);
+    return check_launch();
+  } else {
+    return GA_ERR_UNSUPPORTED;
+  }
+}
+
 template <typename T, int NK, int QB>
 int launch_fwd_cb(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D,
                   int ldq, float scale, hipStream_t s) {
+  if constexpr (sizeof(T) == 2 && NK <= 5 && GA_FWD_PIPE) return launch_fwd_pipe<T, NK, QB>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
   // 128-key tiles for the 16-query forward at small head sizes (register budget allows it), 64 otherwise
   constexpr int KT = (QB == 1 && NK <= 5 && sizeof(T) == 2) ? 128 : 64;
+#ifdef GA_FWD_NW
+  constexpr int NW = GA_FWD_NW;
+#else
+  constexpr int NW = 4;
+#endif
   const size_t lds = fwd_lds<T, NK, KT>();
   if (lds > kLdsLimit) return GA_ERR_SHAPE;
-  const int nqt = (N + 64 * QB - 1) / (64 * QB);
-  auto k = self_attn_fwd_kernel<T, NK, QB, Bufs<T, NK>::value, KT>;
+  const int nqt = (N + 16 * NW * QB - 1) / (16 * NW * QB);
+  // the row sum rides on the P.V product when the head size leaves a pad column in the V image (D % 16 == 8)
+  constexpr bool kCanOnes = sizeof(T) == 2 && (NK & 1);   // head sizes 8, 24, 40, 72: the odd chunk counts built here
+  auto k = self_attn_fwd_kernel<T, NK, QB, Bufs<T, NK>::value, KT, false, NW>;
+  if constexpr (kCanOnes) {
+    if ((D & 15) != 0) k = self_attn_fwd_kernel<T, NK, QB, Bufs<T, NK>::value, KT, true, NW>;
+  }
   int rc = set_dyn_lds(k, lds);
   if (rc != GA_OK) return rc;
-  hipLaunchKernelGGL(k, dim3((unsigned)(B * H * nqt)), dim3(kThreads), lds, s, (const T*)Q, (const T*)K, (const T*)V,
+  hipLaunchKernelGGL(k, dim3((unsigned)(B * H * nqt)), dim3(64 * NW), lds, s, (const T*)Q, (const T*)K, (const T*)V,
                      (T*)O, LSE, H, N, D, nqt, ldq, scale);
   return check_launch();
 }
@@ -932,10 +1347,14 @@ int launch_fwd_cb(const void* Q, const void* K, const void* V, void* O, float* L
 template <typename T, int NK>
 int launch_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int D, int ldq,
                float scale, hipStream_t s) {
+#ifdef GA_FWD_QB
+  return launch_fwd_cb<T, NK, GA_FWD_QB>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
+#else
   if constexpr (NK <= 5) {
     if (wide_columns<NK>(B, H, N, false)) return launch_fwd_cb<T, NK, 2>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
   }
   return launch_fwd_cb<T, NK, 1>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
+#endif
 }
 
 template <typename T, int NK, int CB>
@@ -964,13 +1383,25 @@ template <typename T, int NK>
 int launch_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                float* delta, void* dQ, void* dK, void* dV, int B, int H, int N, int D, int ldq, float scale,
                hipStream_t s) {
+#ifdef GA_BWD_CB
+  return launch_bwd_cb<T, NK, GA_BWD_CB>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);
+#else
   if constexpr (NK <= 5) {
     if (wide_columns<NK>(B, H, N, true))
       return launch_bwd_cb<T, NK, 2>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);
   }
   return launch_bwd_cb<T, NK, 1>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);
+#endif
 }
 
+#ifdef GA_SA_MICRO   /* micro-benchmark builds: one head-size class, fast to compile */
+#define GA_SA_NK(CALL)                                  \
+  do {                                                  \
+    const int nk = (D + 15) / 16;                       \
+    if (nk == GA_SA_MICRO) return CALL(GA_SA_MICRO);    \
+    return GA_ERR_SHAPE;                                \
+  } while (0)
+#else
 #define GA_SA_NK(CALL)                                  \
   do {                                                  \
     const int nk = (D + 15) / 16;                       \
@@ -983,6 +1414,7 @@ int launch_bwd(const void* Q, const void* K, const void* V, const void* O, const
     if (nk <= 10) return CALL(10);                      \
     return GA_ERR_SHAPE;                                \
   } while (0)
+#endif
 
 int check_args(int B, int H, int N, int D) {
   if (B <= 0 || H <= 0 || N <= 0 || D <= 0 || D > 160) return GA_ERR_SHAPE;
@@ -1020,8 +1452,10 @@ extern "C" int ga_self_attn_fwd(const void* Q, const void* K, const void* V, voi
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case GA_F16: return fwd_t<_Float16>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
+#ifndef GA_SA_MICRO
     case GA_BF16: return fwd_t<bf16_t>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
     case GA_F32: return fwd_t<float>(Q, K, V, O, LSE, B, H, N, D, ldq, scale, s);
+#endif
     default: return GA_ERR_DTYPE;
   }
 }
@@ -1039,8 +1473,10 @@ extern "C" int ga_self_attn_bwd(const void* Q, const void* K, const void* V, con
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case GA_F16: return bwd_t<_Float16>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);
+#ifndef GA_SA_MICRO
     case GA_BF16: return bwd_t<bf16_t>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);
     case GA_F32: return bwd_t<float>(Q, K, V, O, dO, LSE, delta, dQ, dK, dV, B, H, N, D, ldq, scale, s);
+#endif
     default: return GA_ERR_DTYPE;
   }
 }

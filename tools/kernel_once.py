@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Launch ONE hand-written kernel a few times on a given shape (for `rocprofv3 --pmc ... -- python3 tools/kernel_once.py`).
+  kernel_once.py sa_fwd|sa_bwd B H N D [dtype]        self-attention forward / backward (needs a forward first)
+  kernel_once.py cap_fwd|cap_bwd B H N D [dtype]      cross-attention capture (Kt = 77; fwd stores P)
+  kernel_once.py gn_fwd|gn_bwd B C HW [dtype]         GroupNorm(+SiLU), 32 groups, channels-last
+Inputs are resident in HBM before the launches; 5 launches each."""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from guided_attention_amd import ops  # noqa: E402
+
+kind = sys.argv[1]
+nums = [int(x) for x in sys.argv[2:] if x.lstrip("-").isdigit()]
+dt = {"f16": torch.half, "bf16": torch.bfloat16, "f32": torch.float32}[next((x for x in sys.argv[2:] if x in ("f16", "bf16", "f32")), "f16")]
+dev = "cuda"
+reps = 5
+if kind.startswith("sa_"):
+    B, H, N, D = nums
+    q, k, v, do = (torch.randn(B, N, H * D, device=dev, dtype=dt) for _ in range(4))
+    o, lse = ops.self_attn_fwd(q, k, v, H, D ** -0.5)
+    torch.cuda.synchronize()
+    for _ in range(reps):
+        if kind == "sa_fwd":
+            ops.self_attn_fwd(q, k, v, H, D ** -0.5)
+        else:
+            ops.self_attn_bwd(q, k, v, o, do, lse, H, D ** -0.5)
+elif kind.startswith("cap_"):
+    B, H, N, D = nums
+    q = torch.randn(B, N, H * D, device=dev, dtype=dt)
+    k, v = (torch.randn(B, 77, H * D, device=dev, dtype=dt) for _ in range(2))
+    do = torch.randn_like(q)
+    dp = (torch.randn(N, 77, device=dev, dtype=dt) * 1e-3).unsqueeze(0).expand(B * H, N, 77)
+    for _ in range(reps):
+        if kind == "cap_fwd":
+            ops.attn_capture_fwd(q, k, v, H, D ** -0.5, True)
+        else:
+            ops.attn_capture_bwd(q, k, v, do, dp, H, D ** -0.5)
+elif kind.startswith("gn_"):
+    B, C, HW = nums
+    side = int(round(HW ** 0.5))
+    x = torch.randn(B, C, side, HW // side, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w, b_ = torch.ones(C, device=dev, dtype=dt), torch.zeros(C, device=dev, dtype=dt)
+    g = torch.randn_like(x)
+    for _ in range(reps):
+        y = ops.group_norm_act(x, w, b_, 32, 1e-5, True)
+        if kind == "gn_bwd":
+            y.backward(g)
+else:
+    raise SystemExit(f"unknown kernel kind {kind}")
+torch.cuda.synchronize()
