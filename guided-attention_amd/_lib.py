@@ -42,6 +42,9 @@ PROTOTYPES = {
     "ga_strerror": [_i],
     "ga_attn_capture_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ga_attn_capture_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "ga_attn_scores_max": [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp],
+    "ga_attn_capture_fwd_biased": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "ga_attn_capture_bwd_biased": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ga_aggregate_maps": [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i, _i, _vp, _i, _vp],
     "ga_smooth_loss_fwd": [_vp, _i, _i, _i, _i, ctypes.POINTER(ga_token_t), _i, ctypes.POINTER(ga_loss_params_t), _vp,
                            _vp, _vp],

@@ -167,11 +167,104 @@ __device__ __forceinline__ void softmax_keys(f32x4 (&acc)[NT], int Kt, int g, fl
     for (int r = 0; r < 4; ++r) acc[t][r] *= inv;
 }
 
+// paint-with-words (utils/ptp_utils.py:113-138): scores' = scale * q.k + bias[n][key] * coef, then the same softmax.
+// in place: acc (raw q.k) -> normalised probabilities of the biased scores
+template <typename T, int NT>
+__device__ __forceinline__ void softmax_keys_biased(f32x4 (&acc)[NT], const T* __restrict__ bias_row, float coef, int Kt,
+                                                    int g, float scale, f32x4 (&bias_out)[NT]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = t * 16 + 4 * g + r;
+      const float bv = key < Kt ? Traits<T>::to_f32(bias_row[key]) : 0.f;
+      bias_out[t][r] = bv;
+      acc[t][r] = acc[t][r] * scale + bv * coef;
+      if (key < Kt) m = fmaxf(m, acc[t][r]);
+    }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = (t * 16 + 4 * g + r < Kt) ? __builtin_amdgcn_exp2f((acc[t][r] - m) * 1.4426950408889634f) : 0.f;
+      acc[t][r] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] *= inv;
+}
+
+// monotonic map f32 -> u32 (so that an unsigned atomic max orders floats)
+__device__ __forceinline__ unsigned ordered_bits(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// max over EVERY scaled score of the layer call (all batches, heads, queries, keys) and where it sits — the
+// `attention_scores.max()` of utils/ptp_utils.py:134, whose value scales the paint-with-words bias and through
+// which the reference's autograd also sends a gradient.  packed[0] = (ordered bits << 32) | flat index into
+// [B*H][N][Kt]; the caller zeroes it first.
 template <typename T, int NT, int WAVES, int NK>
+__global__ __launch_bounds__(WAVES * 64) void attn_scores_max_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                                     unsigned long long* __restrict__ packed, int H,
+                                                                     int N, int Kt, int D, int DP, float scale) {
+  using Tr = Traits<T>;
+  constexpr int ROWS = WAVES * 16;
+  const int KS = Lds<T, NT>::ks(DP);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* Ks = reinterpret_cast<T*>(smem);
+  const int b = blockIdx.z, head = blockIdx.y, q_wg = blockIdx.x * ROWS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const size_t kv_off = ((size_t)b * Kt * H + head) * D;
+  const int q = q_wg + wave * 16 + c;
+  const bool ok = q < N;
+  const size_t row_off = (((size_t)b * N + (ok ? q : 0)) * H + head) * D;
+  typename Tr::frag xq[NK];
+  load_row_frags<T, NK>(Q + row_off, ok, D, g, xq);
+  stage_kv2<T, NT, NK, WAVES * 64>(K + kv_off, Ks, nullptr, nullptr, nullptr, nullptr, H, Kt, D);
+  __syncthreads();
+  f32x4 acc[NT];
+  qk_tiles<T, NT, NK>(xq, Ks, KS, c, g, acc);
+  unsigned long long best = 0;
+  if (ok) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + 4 * g + r;
+        if (key < Kt) {
+          // the reference's scores are rounded to the activation type by baddbmm: so is the value compared here
+          const float sv = Tr::to_f32(Tr::from_f32(acc[t][r] * scale));
+          const unsigned long long idx = ((unsigned long long)(b * H + head) * N + q) * Kt + key;
+          const unsigned long long cand = ((unsigned long long)ordered_bits(sv) << 32) | (idx & 0xffffffffull);
+          best = cand > best ? cand : best;
+        }
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(best, o, 64);
+    best = other > best ? other : best;
+  }
+  if (lane == 0 && best != 0) atomicMax(packed, best);
+}
+
+template <typename T, int NT, int WAVES, int NK, bool BIAS = false>
 __global__ __launch_bounds__(WAVES * 64) void attn_capture_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                                       const T* __restrict__ V, T* __restrict__ O,
                                                                       T* __restrict__ P, int H, int N, int Kt, int D,
-                                                                      int DP, float scale) {
+                                                                      int DP, float scale,
+                                                                      const T* __restrict__ bias = nullptr,
+                                                                      const float* __restrict__ coef = nullptr) {
   using Tr = Traits<T>;
   constexpr int KP = Lds<T, NT>::KP;
   constexpr int ROWS = WAVES * 16;
@@ -194,7 +287,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_fwd_kernel(const T* _
 
   f32x4 acc[NT];
   qk_tiles<T, NT, NK>(xq, Ks, KS, c, g, acc);
-  softmax_keys<NT>(acc, Kt, g, scale);
+  if constexpr (BIAS) {
+    f32x4 unused[NT];
+    softmax_keys_biased<T, NT>(acc, bias + (size_t)(ok ? q : 0) * Kt, coef[0], Kt, g, scale, unused);
+  } else {
+    softmax_keys<NT>(acc, Kt, g, scale);
+  }
 
   typename Tr::frag pf[NT];  // P^T as the B operand of O^T = V^T P^T (and the value stored in P)
 #pragma unroll
@@ -244,11 +342,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_fwd_kernel(const T* _
   }
 }
 
-template <typename T, int NT, int WAVES, int NK>
+template <typename T, int NT, int WAVES, int NK, bool BIAS = false>
 __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
     const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ V, const T* __restrict__ dO,
     const T* __restrict__ dP, long long dP_sb, long long dP_sn, T* __restrict__ dQ, int H, int N, int Kt, int D, int DP,
-    float scale) {
+    float scale, const T* __restrict__ bias = nullptr, const float* __restrict__ coef = nullptr,
+    float* __restrict__ bias_grad = nullptr) {
   using Tr = Traits<T>;
   constexpr int KP = Lds<T, NT>::KP;
   constexpr int ROWS = WAVES * 16;
@@ -270,9 +369,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
   stage_kv2<T, NT, NK, WAVES * 64>(K + kv_off, Ks, Ktr, V + kv_off, Vs, nullptr, H, Kt, D);
   __syncthreads();
 
-  f32x4 p[NT], dp[NT];
+  f32x4 p[NT], dp[NT], bv[NT];
   qk_tiles<T, NT, NK>(xq, Ks, KS, c, g, p);
-  softmax_keys<NT>(p, Kt, g, scale);           // identical instruction sequence to the forward
+  if constexpr (BIAS) softmax_keys_biased<T, NT>(p, bias + (size_t)(ok ? q : 0) * Kt, coef[0], Kt, g, scale, bv);
+  else softmax_keys<NT>(p, Kt, g, scale);      // identical instruction sequence to the forward
   qk_tiles<T, NT, NK>(xdo, Vs, KS, c, g, dp);  // dP^T[key][q] = sum_d V[key][d] dO[q][d]
 
   if (dP != nullptr && ok) {
@@ -301,6 +401,21 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
       p[t][r] = ds;
       amax = fmaxf(amax, fabsf(ds));
     }
+  if constexpr (BIAS) {
+    // d loss / d coef = sum over every score of dS * bias: what the reference's autograd sends on through
+    // `attention_scores.max()` (utils/ptp_utils.py:134).  One float atomic per wave.
+    if (bias_grad != nullptr) {
+      float gsum = 0.f;
+      if (ok) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gsum += p[t][r] * bv[t][r];
+      }
+      gsum = wave_reduce_sum(gsum);
+      if (lane == 0 && gsum != 0.f) atomicAdd(bias_grad, gsum);
+    }
+  }
   // dS feeds the MFMA in T: rescale each query row by a power of two so its largest |dS| sits in
   // [0.5, 1) (fp16 would otherwise put the ~1e-5 loss gradients in the subnormal range); exact undo below
   float undo = scale;
@@ -363,7 +478,7 @@ int launch_fwd_nk(const void* Q, const void* K, const void* V, void* O, void* P,
   int rc = set_dyn_lds(k, lds);
   if (rc != GA_OK) return rc;
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)Q, (const T*)K, (const T*)V, (T*)O, (T*)P, H, N, Kt, D, DP,
-                     scale);
+                     scale, (const T*)nullptr, (const float*)nullptr);
   return check_launch();
 }
 
@@ -378,7 +493,52 @@ int launch_bwd_nk(const void* Q, const void* K, const void* V, const void* dO, c
   int rc = set_dyn_lds(k, lds);
   if (rc != GA_OK) return rc;
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)Q, (const T*)K, (const T*)V, (const T*)dO, (const T*)dP,
-                     (long long)sb, (long long)sn, (T*)dQ, H, N, Kt, D, DP, scale);
+                     (long long)sb, (long long)sn, (T*)dQ, H, N, Kt, D, DP, scale, (const T*)nullptr,
+                     (const float*)nullptr, (float*)nullptr);
+  return check_launch();
+}
+
+template <typename T, int NK>
+int launch_max_nk(const void* Q, const void* K, unsigned long long* packed, int B, int H, int N, int Kt, int D, float scale,
+                  hipStream_t s) {
+  constexpr int NT = 5;
+  const size_t lds = sizeof(T) * (size_t)Lds<T, NT>::KP * Lds<T, NT>::ks(NK * 16);
+  if (lds > kLdsLimit) return GA_ERR_SHAPE;
+  auto k = attn_scores_max_kernel<T, NT, 4, NK>;
+  int rc = set_dyn_lds(k, lds);
+  if (rc != GA_OK) return rc;
+  hipLaunchKernelGGL(k, dim3((N + 63) / 64, H, B), dim3(256), lds, s, (const T*)Q, (const T*)K, packed, H, N, Kt, D,
+                     NK * 16, scale);
+  return check_launch();
+}
+
+template <typename T, int NK>
+int launch_fwd_biased_nk(const void* Q, const void* K, const void* V, void* O, void* P, const void* bias, const float* coef,
+                         int B, int H, int N, int Kt, int D, float scale, hipStream_t s) {
+  constexpr int NT = 5;
+  const size_t lds = fwd_lds_bytes<T, NT, NK>(Kt, 4, P != nullptr);
+  if (lds > kLdsLimit) return GA_ERR_SHAPE;
+  auto k = attn_capture_fwd_kernel<T, NT, 4, NK, true>;
+  int rc = set_dyn_lds(k, lds);
+  if (rc != GA_OK) return rc;
+  hipLaunchKernelGGL(k, dim3((N + 63) / 64, H, B), dim3(256), lds, s, (const T*)Q, (const T*)K, (const T*)V, (T*)O, (T*)P,
+                     H, N, Kt, D, NK * 16, scale, (const T*)bias, coef);
+  return check_launch();
+}
+
+template <typename T, int NK>
+int launch_bwd_biased_nk(const void* Q, const void* K, const void* V, const void* dO, const void* dP, int64_t sb,
+                         int64_t sn, void* dQ, const void* bias, const float* coef, float* bias_grad, int B, int H, int N,
+                         int Kt, int D, float scale, hipStream_t s) {
+  constexpr int NT = 5;
+  const size_t lds = bwd_lds_bytes<T, NT, NK>();
+  if (lds > kLdsLimit) return GA_ERR_SHAPE;
+  auto k = attn_capture_bwd_kernel<T, NT, 4, NK, true>;
+  int rc = set_dyn_lds(k, lds);
+  if (rc != GA_OK) return rc;
+  hipLaunchKernelGGL(k, dim3((N + 63) / 64, H, B), dim3(256), lds, s, (const T*)Q, (const T*)K, (const T*)V,
+                     (const T*)dO, (const T*)dP, (long long)sb, (long long)sn, (T*)dQ, H, N, Kt, D, NK * 16, scale,
+                     (const T*)bias, coef, bias_grad);
   return check_launch();
 }
 
@@ -478,4 +638,70 @@ extern "C" int ga_attn_capture_bwd(const void* Q, const void* K, const void* V, 
     default:
       return GA_ERR_DTYPE;
   }
+}
+
+// ---- paint-with-words entry points (utils/ptp_utils.py:113-138; off by default in the reference) ---------------------
+namespace {
+int check_biased(int B, int H, int N, int Kt, int D) {
+  int rc = check_common(B, H, N, Kt, D);
+  if (rc != GA_OK) return rc;
+  if (Kt > 80) return GA_ERR_UNSUPPORTED;  // the reference applies the mask to the 77-token text context only
+  if ((unsigned long long)B * H * N * Kt > 0xffffffffull) return GA_ERR_SHAPE;
+  return GA_OK;
+}
+}  // namespace
+
+extern "C" int ga_attn_scores_max(const void* Q, const void* K, int B, int H, int N, int Kt, int D, float scale, int dtype,
+                                  unsigned long long* packed, ga_stream_t stream) {
+  if (!Q || !K || !packed) return GA_ERR_NULL;
+  int rc = check_biased(B, H, N, Kt, D);
+  if (rc != GA_OK) return rc;
+  if (!aligned16(Q) || !aligned16(K)) return GA_ERR_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define GA_CALL(NKV) launch_max_nk<T_, NKV>(Q, K, packed, B, H, N, Kt, D, scale, s)
+  switch (dtype) {
+    case GA_F16: { using T_ = _Float16; GA_NK_DISPATCH_COARSE(GA_CALL); }
+    case GA_BF16: { using T_ = bf16_t; GA_NK_DISPATCH_COARSE(GA_CALL); }
+    case GA_F32: { using T_ = float; GA_NK_DISPATCH_COARSE(GA_CALL); }
+    default: return GA_ERR_DTYPE;
+  }
+#undef GA_CALL
+}
+
+extern "C" int ga_attn_capture_fwd_biased(const void* Q, const void* K, const void* V, void* O, void* P, const void* bias,
+                                          const float* coef, int B, int H, int N, int Kt, int D, float scale, int dtype,
+                                          ga_stream_t stream) {
+  if (!Q || !K || !V || !O || !bias || !coef) return GA_ERR_NULL;
+  int rc = check_biased(B, H, N, Kt, D);
+  if (rc != GA_OK) return rc;
+  if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return GA_ERR_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define GA_CALL(NKV) launch_fwd_biased_nk<T_, NKV>(Q, K, V, O, P, bias, coef, B, H, N, Kt, D, scale, s)
+  switch (dtype) {
+    case GA_F16: { using T_ = _Float16; GA_NK_DISPATCH_COARSE(GA_CALL); }
+    case GA_BF16: { using T_ = bf16_t; GA_NK_DISPATCH_COARSE(GA_CALL); }
+    case GA_F32: { using T_ = float; GA_NK_DISPATCH_COARSE(GA_CALL); }
+    default: return GA_ERR_DTYPE;
+  }
+#undef GA_CALL
+}
+
+extern "C" int ga_attn_capture_bwd_biased(const void* Q, const void* K, const void* V, const void* dO, const void* dP,
+                                          int64_t dP_stride_bh, int64_t dP_stride_n, void* dQ, const void* bias,
+                                          const float* coef, float* bias_grad, int B, int H, int N, int Kt, int D,
+                                          float scale, int dtype, ga_stream_t stream) {
+  if (!Q || !K || !V || !dO || !dQ || !bias || !coef) return GA_ERR_NULL;
+  int rc = check_biased(B, H, N, Kt, D);
+  if (rc != GA_OK) return rc;
+  if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(dO) || !aligned16(dQ)) return GA_ERR_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define GA_CALL(NKV) \
+  launch_bwd_biased_nk<T_, NKV>(Q, K, V, dO, dP, dP_stride_bh, dP_stride_n, dQ, bias, coef, bias_grad, B, H, N, Kt, D, scale, s)
+  switch (dtype) {
+    case GA_F16: { using T_ = _Float16; GA_NK_DISPATCH_COARSE(GA_CALL); }
+    case GA_BF16: { using T_ = bf16_t; GA_NK_DISPATCH_COARSE(GA_CALL); }
+    case GA_F32: { using T_ = float; GA_NK_DISPATCH_COARSE(GA_CALL); }
+    default: return GA_ERR_DTYPE;
+  }
+#undef GA_CALL
 }

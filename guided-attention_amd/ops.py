@@ -245,6 +245,101 @@ class AttnCapture(torch.autograd.Function):
         return dq, None, None, None, None, None
 
 
+# --------------------------------------------------------------------------------------- K1 + paint-with-words
+def attn_scores_max(q, k, heads, scale):
+    """-> (max over every scaled score of the call, f32 [1]; its flat index into [B*heads][N][Kt], int64 [1]), both
+    on the device (no synchronisation): the `attention_scores.max()` of utils/ptp_utils.py:134."""
+    require_cuda(q, k)
+    q, k = q.contiguous(), k.contiguous()
+    B, N, C = q.shape
+    Kt = k.shape[1]
+    packed = torch.zeros(1, dtype=torch.int64, device=q.device)
+    check(load().ga_attn_scores_max(_ptr(q), _ptr(k), B, heads, N, Kt, C // heads, float(scale), dtype_code(q),
+                                    _ptr(packed), stream_ptr()), "ga_attn_scores_max")
+    hi = (packed >> 32) & 0xFFFFFFFF
+    bits = torch.where((hi & 0x80000000) == 0, (~hi) & 0xFFFFFFFF, hi ^ 0x80000000)   # undo the order-preserving map
+    value = (bits - ((bits >> 31) << 32)).to(torch.int32).view(torch.float32)
+    return value, packed & 0xFFFFFFFF
+
+
+def attn_capture_fwd_biased(q, k, v, heads, scale, want_probs, bias, coef):
+    """ga_attn_capture_fwd with scores + bias[n][k] * coef[0] (bias (N, Kt) in q's dtype, coef f32 [1] on the device)."""
+    require_cuda(q, k, v, bias, coef)
+    q, k, v, bias = q.contiguous(), k.contiguous(), v.contiguous(), bias.to(q.dtype).contiguous()
+    B, N, C = q.shape
+    Kt = k.shape[1]
+    if tuple(bias.shape) != (N, Kt) or coef.dtype != torch.float32:
+        raise GaError(f"bias must be (N, Kt) = {(N, Kt)} and coef a float32 device scalar")
+    o = torch.empty_like(q)
+    probs = torch.empty((B * heads, N, Kt), dtype=q.dtype, device=q.device) if want_probs else None
+    check(load().ga_attn_capture_fwd_biased(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(probs), _ptr(bias), _ptr(coef), B,
+                                            heads, N, Kt, C // heads, float(scale), dtype_code(q), stream_ptr()),
+          "ga_attn_capture_fwd_biased")
+    return o, probs
+
+
+def attn_capture_bwd_biased(q, k, v, d_o, d_probs, heads, scale, bias, coef):
+    """-> (dq, d loss / d coef (f32 [1])) for the biased scores (see ga_hip.h)."""
+    require_cuda(q, k, v, d_o, d_probs, bias, coef)
+    B, N, C = q.shape
+    Kt = k.shape[1]
+    d_o, bias = d_o.contiguous(), bias.to(q.dtype).contiguous()
+    sb = sn = 0
+    if d_probs is not None:
+        if d_probs.dtype != q.dtype:
+            d_probs = d_probs.to(q.dtype)
+        if d_probs.stride(2) != 1 or (d_probs.stride(0) != 0 and not d_probs.is_contiguous()):
+            d_probs = d_probs.contiguous()
+        sb, sn = d_probs.stride(0), d_probs.stride(1)
+    dq = torch.empty_like(q)
+    gsum = torch.zeros(1, dtype=torch.float32, device=q.device)
+    check(load().ga_attn_capture_bwd_biased(_ptr(q), _ptr(k), _ptr(v), _ptr(d_o), _ptr(d_probs), sb, sn, _ptr(dq),
+                                            _ptr(bias), _ptr(coef), _ptr(gsum), B, heads, N, Kt, C // heads, float(scale),
+                                            dtype_code(q), stream_ptr()), "ga_attn_capture_bwd_biased")
+    return dq, gsum
+
+
+class AttnCapturePaintWithWords(torch.autograd.Function):
+    """softmax(scale q k^T + mask * mult * max(scale q k^T)) v with the probabilities as a second output — the
+    paint-with-words branch of the reference's get_attention_scores (utils/ptp_utils.py:113-138; mult =
+    0.4 * log(1 + sigma_t)).  The maximum is taken over the whole call and carries a gradient, as in the reference."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale, want_probs, mask, mult):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        smax, arg = attn_scores_max(q, k, heads, scale)
+        coef = smax * float(mult)
+        o, probs = attn_capture_fwd_biased(q, k, v, heads, scale, want_probs, mask, coef)
+        ctx.save_for_backward(q, k, v, mask, coef, arg)
+        ctx.meta = (heads, scale, float(mult))
+        if probs is None:
+            probs = q.new_empty(0)
+            ctx.mark_non_differentiable(probs)
+        return o, probs
+
+    @staticmethod
+    def backward(ctx, d_o, d_probs):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise GaError("gradients w.r.t. the attention context (K/V) are not part of the guided-attention path")
+        q, k, v, mask, coef, arg = ctx.saved_tensors
+        heads, scale, mult = ctx.meta
+        if d_probs is not None and d_probs.numel() == 0:
+            d_probs = None
+        if d_o is None:
+            d_o = torch.zeros_like(q)
+        dq, gsum = attn_capture_bwd_biased(q, k, v, d_o, d_probs, heads, scale, mask, coef)
+        # the gradient that reaches the scores through `.max()`: (mult * sum dS * mask) at the maximum's position
+        B, N, C = q.shape
+        Kt, D = k.shape[1], C // heads
+        bh, rem = arg // (N * Kt), arg % (N * Kt)
+        n, kk = rem // Kt, rem % Kt
+        b, h = bh // heads, bh % heads
+        krow = k.view(B * Kt * heads, D).index_select(0, (b * Kt + kk) * heads + h)           # (1, D)
+        add = (krow.float() * (gsum * (mult * scale))).to(dq.dtype)
+        dq.view(B * N * heads, D).index_add_(0, (b * N + n) * heads + h, add)
+        return dq, None, None, None, None, None, None, None
+
+
 # --------------------------------------------------------------------------------------- K2
 def aggregate_maps(maps):
     """maps: list of (heads_i, npix, Kt) tensors of one dtype -> A (npix, Kt) f32."""

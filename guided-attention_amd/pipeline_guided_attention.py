@@ -61,6 +61,12 @@ class GuidedAttention:
         # logged), run the guidance forward (cond) and the CFG pair (uncond, cond) — three independent evaluations of
         # the same latents — as ONE batch-3 pass.  Nothing is skipped; False runs them as two passes (B=1, B=2).
         self.batch_loss_only_guidance = True
+        # The reference writes per-token attention-map PNGs at EVERY loss evaluation (:243-246), predicted-x0 PNGs for the
+        # steps in shared_state.always_save_iter (:1036-1037) and latent statistics at every step (:1031), whatever
+        # config.diagnostic_level says.  Here those side effects are opt-in: True reproduces them (each costs device
+        # syncs and host I/O; hipGraph replay is bypassed for such a run).  config.diagnostic_level > 0 switches them on
+        # as well.  Off by default, never inside a timed benchmark region.
+        self.reference_side_effects = False
         self._runner = None
         self._graph_cache = {}
         self.unet_calls = {"fwd_b1_grad": 0, "bwd": 0, "fwd_b2": 0, "loss_evals": 0, "joint_b3": 0}
@@ -248,6 +254,8 @@ class GuidedAttention:
             terms = attention_maps.new_zeros((0, 8))
             loss = attention_maps.new_zeros(1)
         custom = None
+        if self._dump:
+            self._dump_token_maps(attention_maps, last_idx)
         if hasattr(state.config, "custom_loss") and state.config.custom_loss:
             text_maps = torch.softmax(attention_maps[:, :, 1:last_idx] * 100, dim=-1)
             for _name, (fn, args) in state.config.custom_loss.items():
@@ -281,10 +289,78 @@ class GuidedAttention:
         results of ga_smooth_loss_fwd (reference :201-296)."""
         return self._loss_host(*self._loss_device(attention_maps, smooth_attentions, sigma, kernel_size, normalize_eot))
 
+    _dump = False  # True while a run reproduces the reference's PNG / log side effects (set per __call__)
+
+    # ------------------------------------------------------------------ diagnostics (reference :243-246, 316-346, 1090-1123)
+    def get_innermost_folder(self):
+        return str(state.cur_seed)
+
+    def _dump_dir(self):
+        d = state.config.output_path / helpers.get_inner_folder_name() / self.get_innermost_folder()
+        d.mkdir(exist_ok=True, parents=True)
+        return d
+
+    def save_viridis(self, tensor1, tag):
+        """Min-max normalised map as a viridis PNG (reference :1096-1103)."""
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        with torch.no_grad():
+            x = tensor1.float() - tensor1.float().min()
+            x = x / x.max()
+            fname = (tag + "_" + helpers.get_meta_prompt_clean() + state.get_name() + "_subiter_" +
+                     "{:02d}".format(state.sub_iteration) + ".png")
+            plt.imsave(self._dump_dir() / fname, x.detach().cpu().numpy())
+
+    def save_numpy(self, tensor1, tag):
+        fname = tag + "_" + helpers.get_meta_prompt_clean() + "_" + str(state.cur_time_step_iter)
+        np.save(self._dump_dir() / fname, tensor1.detach().float().cpu().numpy())
+
+    def save_image(self, latent, tag):
+        """Decode latents and save the (annotated) image (reference :1114-1123)."""
+        image = self.numpy_to_pil(self.decode_latents(latent.detach()))
+        fname = helpers.get_meta_prompt_clean() + state.get_name() + "_" + tag
+        for ch in "[]:.":
+            fname = fname.replace(ch, "_")
+        helpers.annotate_image(image[0])
+        image[0].save(self._dump_dir() / (fname + ".png"))
+
+    def _dump_token_maps(self, attention_maps, last_idx):
+        """Per-token maps of softmax(100 * A[:, :, 1:last]) as PNGs + their sums in the log (reference :238-246)."""
+        with torch.no_grad():
+            text = torch.softmax(attention_maps.detach()[:, :, 1:last_idx] * 100, dim=-1)
+            if getattr(state.config, "save_all_maps", False):
+                indices = range(0, len(self.tokenizer(state.config.prompt)["input_ids"][1:-1]))
+            else:
+                indices = [index - 1 for index in state.config.token_dict.keys()]
+            for index_i in indices:
+                image = text[:, :, index_i]
+                self.save_viridis(image, "_attnmap_" + self.get_token(index_i + 1))
+                helpers.log(self.get_token(index_i + 1) + ": " + str(image.sum().item()))
+
+    def _dump_individual_ca_maps(self, attention_store, attention_maps, from_where):
+        """config.save_individual_CA_maps at step 12: every head of every stored cross map (token 1), the head mean
+        and the aggregate (reference :316-346)."""
+        for location in from_where:
+            for map_iter, item in enumerate(attention_store.get_average_attention()[f"{location}_cross"], start=1):
+                if not torch.is_tensor(item):
+                    continue
+                res = int(item.shape[1] ** .5)
+                cross_maps = item.reshape(-1, res, res, item.shape[-1])
+                for head in range(0, min(8, cross_maps.shape[0])):
+                    map1 = cross_maps[head, :, :, 1]
+                    tag = (f"{location}_res_{res}_head_{head}_mapiter_{map_iter}_avg_{map1.mean().item():.3}"
+                           f"_max_{map1.max().item():.3}")
+                    self.save_viridis(map1, tag)
+                self.save_viridis((cross_maps.sum(0) / 8)[:, :, 1], f"{location}_res_{res}_avgheads_mapiter_{map_iter}")
+        self.save_viridis(attention_maps[:, :, 1], "final")
+
     def _aggregate_and_get_max_attention_per_token(self, attention_store, attention_res=16, smooth_attentions=False,
                                                    sigma=0.5, kernel_size=3, normalize_eot=False):
         attention_maps = aggregate_attention(attention_store=attention_store, res=attention_res,
                                              from_where=("up", "down", "mid"), is_cross=True, select=0)
+        if self._dump and getattr(state.config, "save_individual_CA_maps", False) and state.cur_time_step_iter == 12:
+            self._dump_individual_ca_maps(attention_store, attention_maps, ("up", "down", "mid"))
         return self._compute_max_attention_per_index(attention_maps, smooth_attentions, sigma, kernel_size,
                                                      normalize_eot)
 
@@ -492,7 +568,10 @@ class GuidedAttention:
         cond = prompt_embeds[1:2] if do_cfg else prompt_embeds[0:1]
         guided = bool(getattr(state.config, "token_dict", None)) or bool(getattr(state.config, "custom_loss", None))
         self._runner = None
-        if self.use_graphs and do_cfg and guided and not run_standard_sd:
+        self._dump = bool(self.reference_side_effects or getattr(state.config, "diagnostic_level", 0) > 0)
+        # paint-with-words changes the attention kernels' arguments from step to step (sigma_t, on / off): eager
+        paint = bool((state.curHyperParams or {}).get("paint_with_words_stop", 0))
+        if self.use_graphs and do_cfg and guided and not run_standard_sd and not self._dump and not paint:
             from .graphs import GraphRunner
             self._runner = GraphRunner.for_run(self, attention_store, prompt_embeds, latents, attention_res,
                                                smooth_attentions, sigma, kernel_size, sd_2_1)
@@ -566,9 +645,16 @@ class GuidedAttention:
                         noise_pred = self.unet(model_in, t_int, encoder_hidden_states=prompt_embeds).sample
                 if do_cfg:
                     eps_uncond, eps_text = noise_pred.chunk(2)
-                    latents, _x0 = ops.cfg_ddim_step(eps_uncond, eps_text, guidance_scale, latents, a_t, a_prev)
+                    latents, _x0 = ops.cfg_ddim_step(eps_uncond, eps_text, guidance_scale, latents, a_t, a_prev, self._dump)
                 else:
-                    latents, _x0 = ops.cfg_ddim_step(noise_pred, noise_pred, 1.0, latents, a_t, a_prev)
+                    latents, _x0 = ops.cfg_ddim_step(noise_pred, noise_pred, 1.0, latents, a_t, a_prev, self._dump)
+                if self._dump:  # reference :1031-1037 (each of these synchronises with the device)
+                    helpers.log_latent_stats(latents, True)
+                    if state.config.diagnostic_level > 1:
+                        self.save_image(latents, "xt")
+                    if (state.config.diagnostic_level > 0 or state.cur_time_step_iter in state.always_save_iter) \
+                            and self.vae is not None:
+                        self.save_image(_x0, "pred")
                 if callback is not None and i % callback_steps == 0:
                     callback(i, t_int, latents)
                 if i > recurse_until or not did_we_update:

@@ -1,7 +1,7 @@
 """Entry points with the reference's names (run.py): `setup`, `load_model`, `parseMetaPrompt`,
 `overrideConfig`, `run_on_prompt`, `execute`, the custom-loss plugin API (`CustomLossBase`,
 `register_custom_loss`, `ToLeftOf`) and a `main()` CLI taking the RunConfig fields as `--flags` (argparse:
-pyrallis is not available here).  The Flask front-end is out of scope."""
+pyrallis is not available here).  `--interactive true` starts the Flask front-end of gui.py."""
 import argparse
 import dataclasses
 import sys
@@ -250,9 +250,11 @@ def main(argv=None):
     config = _parse_cli(sys.argv[1:] if argv is None else argv)
     setup(config)
     register_custom_loss("toLeftOf", ToLeftOf())  # as the reference's main() does (run.py:240)
-    if config.interactive:
-        raise NotImplementedError("the Flask front-end is out of scope; POST the meta-prompt to your own service")
-    execute(config)
+    if config.interactive:   # reference run.py:242-244
+        from . import gui
+        gui.run()
+    else:
+        execute(config)
 
 
 if __name__ == "__main__":

@@ -25,6 +25,57 @@ from . import shared_state as state
 MAX_CAPTURE_KEYS = 128  # ga_attn_capture_* keep the whole key axis on chip up to this length
 
 
+# ---- notebook helpers of the reference (utils/ptp_utils.py:14-56), host-side, off the hot path.  The reference draws
+# with OpenCV and shows through IPython; neither is required here: PIL draws, and `display` is used when importable.
+def text_under_image(image, text, text_color=(0, 0, 0)):
+    """(h, w, 3) uint8 -> (h + 20 %, w, 3) with `text` centred in the white strip below (reference :14-23)."""
+    import numpy as np
+    from PIL import Image, ImageDraw
+    from . import helpers
+    h, w, c = image.shape
+    offset = int(h * .2)
+    img = np.ones((h + offset, w, c), dtype=np.uint8) * 255
+    img[:h] = image
+    pil = Image.fromarray(img)
+    draw = ImageDraw.Draw(pil)
+    font = helpers._font(max(10, offset // 2))
+    box = draw.textbbox((0, 0), text, font=font)
+    tw, th = box[2] - box[0], box[3] - box[1]
+    draw.text(((w - tw) // 2, h + (offset - th) // 2 - box[1]), text, fill=tuple(text_color), font=font)
+    return np.asarray(pil).copy()
+
+
+def view_images(images, num_rows=1, offset_ratio=0.02, display_image=True):
+    """Grid of equally sized (h, w, 3) images, white gutters (reference :26-56); returns the PIL image."""
+    import numpy as np
+    from PIL import Image
+    if type(images) is list:
+        num_empty = len(images) % num_rows
+    elif images.ndim == 4:
+        num_empty = images.shape[0] % num_rows
+    else:
+        images = [images]
+        num_empty = 0
+    empty = np.ones(images[0].shape, dtype=np.uint8) * 255
+    images = [im.astype(np.uint8) for im in images] + [empty] * num_empty
+    num_items = len(images)
+    h, w, _ = images[0].shape
+    offset = int(h * offset_ratio)
+    num_cols = num_items // num_rows
+    canvas = np.ones((h * num_rows + offset * (num_rows - 1), w * num_cols + offset * (num_cols - 1), 3), dtype=np.uint8) * 255
+    for i in range(num_rows):
+        for j in range(num_cols):
+            canvas[i * (h + offset): i * (h + offset) + h, j * (w + offset): j * (w + offset) + w] = images[i * num_cols + j]
+    pil_img = Image.fromarray(canvas)
+    if display_image:
+        try:
+            from IPython.display import display
+            display(pil_img)
+        except ImportError:
+            pass
+    return pil_img
+
+
 class ProbsNotCaptured:
     """Shape-only stand-in for a probability tensor that was deliberately not materialised."""
 
@@ -130,6 +181,37 @@ def refresh_context_projections(unet):
         cache.update(fresh)
 
 
+_pww_cache = {}
+
+
+def paint_with_words_bias(n_pixels, n_keys, dtype, device):
+    """The additive mask of the reference's paint-with-words branch (utils/ptp_utils.py:113-131) for the current
+    step, or None when it is off: -> (mask (N, 77) with `paint_with_words_weight` inside each BOX token's (shrunk)
+    rectangle at that layer's resolution, multiplier 0.4 * log(1 + sigma_t)).  Active while
+    cur_time_step_iter < curHyperParams["paint_with_words_stop"] (0 = off, the default), for 77-key layers only."""
+    import math
+    hp = state.curHyperParams or {}
+    stop = hp.get("paint_with_words_stop", 0)
+    if not stop or n_keys != 77 or not state.cur_time_step_iter < stop:
+        return None
+    from . import helpers
+    w = hp.get("paint_with_words_weight", 1.0)
+    hw = int(n_pixels ** .5)
+    boxes = tuple((idx, info["loss"].as_tuple()) for idx, info in state.config.token_dict.items()
+                  if info["loss_type"] == helpers.AnnotationType.BOX)
+    key = (hw, n_pixels, boxes, float(hp["shrink_factor"]), float(w), dtype, str(device))
+    mask = _pww_cache.get(key)
+    if mask is None:
+        m = torch.zeros((hw, hw, 77))
+        for idx, geom in boxes:
+            m[:, :, idx][helpers.inside_mask(helpers.Rect(*geom, 1).of_size(hw), hw)] = w
+        mask = m.reshape(hw * hw, 77).to(device=device, dtype=dtype)
+        if len(_pww_cache) > 64:
+            _pww_cache.clear()
+        _pww_cache[key] = mask
+    return mask, .4 * math.log(1 + float(state.get_sigma()))
+
+
 class AttendExciteCrossAttnProcessor:
     """proc(attn, hidden_states, encoder_hidden_states=None, attention_mask=None) -> hidden_states"""
 
@@ -140,8 +222,6 @@ class AttendExciteCrossAttnProcessor:
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None):
         if attention_mask is not None:
             raise GaError("attention masks are not part of the guided-attention path")
-        if state.curHyperParams is not None and state.curHyperParams.get("paint_with_words_stop", 0):
-            raise NotImplementedError("paint-with-words (off by default in the reference) is not provided")
         is_cross = encoder_hidden_states is not None
         store = self.attnstore
         if not is_cross:
@@ -166,7 +246,14 @@ class AttendExciteCrossAttnProcessor:
         want = store is not None and store.wants_probs(is_cross, n_pix)
         probs = None
         ctx_needs_grad = torch.is_grad_enabled() and (key.requires_grad or value.requires_grad)
-        if n_keys <= MAX_CAPTURE_KEYS and not ctx_needs_grad:
+        pww = paint_with_words_bias(n_pix, n_keys, query.dtype, query.device) if is_cross else None
+        if pww is not None and not ctx_needs_grad:
+            if int(n_pix ** .5) ** 2 != n_pix:
+                raise GaError("paint-with-words needs a square attention map (reference: int(N ** .5))")
+            out, probs = ops.AttnCapturePaintWithWords.apply(query, key, value, attn.heads, attn.scale, want, *pww)
+            if not want:
+                probs = None
+        elif n_keys <= MAX_CAPTURE_KEYS and not ctx_needs_grad:
             # the capture kernels: whole key axis on chip; context (text) carries no gradient
             out, probs = ops.AttnCapture.apply(query, key, value, attn.heads, attn.scale, want)
             if not want:

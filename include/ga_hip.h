@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GA_VERSION 110 /* 0.1.1: ga_loss_params_t.strict */
+#define GA_VERSION 120 /* 0.1.2: strict bbox mode, paint-with-words entry points */
 
 typedef void* ga_stream_t; /* hipStream_t */
 
@@ -69,6 +69,30 @@ int ga_attn_capture_bwd(const void* Q, const void* K, const void* V, const void*
                         const void* dP, int64_t dP_stride_bh, int64_t dP_stride_n,
                         void* dQ, void* dK, void* dV,
                         int B, int H, int N, int Kt, int D, float scale, int dtype, ga_stream_t stream);
+
+/* K1 with the paint-with-words bias (utils/ptp_utils.py:113-138; off by default, curHyperParams
+ * "paint_with_words_stop" / "paint_with_words_weight"): the reference adds
+ *     mask[n][k] * 0.4 * attention_scores.max() * log(1 + sigma_t)
+ * to the scaled scores of the 77-token cross-attention before the softmax.  Split into what the device needs:
+ *   ga_attn_scores_max      : packed[0] = max over ALL scaled scores of the call and its position,
+ *                             (order-preserving bits of the f32 value << 32) | flat index into [B*H][N][Kt];
+ *                             the caller zeroes packed[0] first (device memory, 8 bytes);
+ *   ga_attn_capture_fwd_biased / _bwd_biased : as ga_attn_capture_fwd / _bwd with scores + bias[n][k] * coef[0]
+ *                             (bias [N][Kt] T, shared by every batch entry and head; coef a DEVICE scalar so that
+ *                             nothing synchronises); the backward also accumulates d loss / d coef = sum dS * bias into
+ *                             bias_grad[0] (f32 atomics; may be NULL) — the gradient the reference's autograd sends
+ *                             on through `.max()`, which the host adds to dQ at the maximum's position.
+ * Kt <= 80 (the reference applies the mask to the text context only).
+ */
+int ga_attn_scores_max(const void* Q, const void* K, int B, int H, int N, int Kt, int D, float scale, int dtype,
+                       unsigned long long* packed, ga_stream_t stream);
+int ga_attn_capture_fwd_biased(const void* Q, const void* K, const void* V, void* O, void* P, const void* bias,
+                               const float* coef, int B, int H, int N, int Kt, int D, float scale, int dtype,
+                               ga_stream_t stream);
+int ga_attn_capture_bwd_biased(const void* Q, const void* K, const void* V, const void* dO, const void* dP,
+                               int64_t dP_stride_bh, int64_t dP_stride_n, void* dQ, const void* bias, const float* coef,
+                               float* bias_grad, int B, int H, int N, int Kt, int D, float scale, int dtype,
+                               ga_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K2  aggregate_attention (utils/ptp_utils.py:273-289, select = 0): the mean over every head-map of

@@ -2,8 +2,8 @@
 
 Follows (paths relative to the reference checkout):
   utils/ptp_utils.py:59-93    AttendExciteCrossAttnProcessor.__call__
-  utils/ptp_utils.py:97-146   get_attention_scores  (paint-with-words branch :113-138 is off by
-                              default, `paint_with_words_stop` = 0, and is not restated)
+  utils/ptp_utils.py:97-146   get_attention_scores, including the paint-with-words branch :113-138 (off by
+                              default: `paint_with_words_stop` = 0)
   utils/ptp_utils.py:178-270  AttentionControl / AttentionStore
   utils/ptp_utils.py:273-289  aggregate_attention
 """
@@ -23,11 +23,27 @@ def head_merge(t, heads):
     return t.reshape(bh // heads, heads, n, d).permute(0, 2, 1, 3).reshape(bh // heads, n, d * heads)
 
 
-def attention_probs(q, k, scale):
-    """ptp_utils.py:97-146 with the default flags: softmax_j(scale * q k^T), computed in the input dtype."""
+def attention_probs(q, k, scale, pww=None):
+    """ptp_utils.py:97-146 with the default flags: softmax_j(scale * q k^T), computed in the input dtype.
+    pww = (mask (N, 77), log(1 + sigma_t)): the paint-with-words branch, scores + mask * .4 * scores.max() * log(...)
+    with the maximum over the WHOLE tensor and inside the autograd graph (:134)."""
     scores = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype), q, k.transpose(-1, -2),
                            beta=0, alpha=scale)
+    if pww is not None:
+        mask, log1p_sigma = pww
+        scores = scores + mask.to(scores.dtype).unsqueeze(0).repeat((q.shape[0], 1, 1)) * .4 * scores.max() * log1p_sigma
     return scores.softmax(dim=-1).to(q.dtype)
+
+
+def paint_with_words_mask(token_boxes, n_pixels, shrink, weight):
+    """ptp_utils.py:113-131: (N, 77) mask with `weight` inside each BOX token's rectangle (scaled to the layer's
+    hw = int(N ** .5), shrunk by shrink_factor, pixel centres) in that token's column.  token_boxes: {index: (x,y,w,h)}."""
+    from . import loss as oloss
+    hw = int(n_pixels ** .5)
+    mask = torch.zeros((hw, hw, 77))
+    for idx, rect in token_boxes.items():
+        mask[:, :, idx][torch.from_numpy(oloss.inside_mask(tuple(rect), hw, shrink))] = weight
+    return mask.reshape(hw * hw, 77)
 
 
 class OracleStore:
@@ -75,9 +91,11 @@ class OracleAttnProcessor:
     """Plain-PyTorch processor with the reference's protocol
     proc(attn, hidden_states, encoder_hidden_states=None, attention_mask=None) -> hidden_states."""
 
-    def __init__(self, store, place):
+    def __init__(self, store, place, pww=None):
+        """pww: None, or a callable (n_pixels) -> (mask (N, 77), log(1 + sigma_t)) | None for the current step."""
         self.store = store
         self.place = place
+        self.pww = pww
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None):
         is_cross = encoder_hidden_states is not None
@@ -85,7 +103,8 @@ class OracleAttnProcessor:
         q = head_split(attn.to_q(hidden_states), attn.heads)
         k = head_split(attn.to_k(ctx), attn.heads)
         v = head_split(attn.to_v(ctx), attn.heads)
-        probs = attention_probs(q, k, attn.scale)
+        pww = self.pww(q.shape[1]) if (self.pww is not None and k.shape[1] == 77) else None
+        probs = attention_probs(q, k, attn.scale, pww)
         self.store(probs, is_cross, self.place)
         out = head_merge(torch.bmm(probs, v), attn.heads)
         out = attn.to_out[0](out)

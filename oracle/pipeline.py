@@ -36,12 +36,12 @@ def ddim_step(eps, t, x, acp, steps, num_train=1000):
     return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
 
 
-def install_processors(unet, store):
-    """utils/ptp_utils.py:149-175 register_attention_control with the oracle processor."""
+def install_processors(unet, store, pww=None):
+    """utils/ptp_utils.py:149-175 register_attention_control with the oracle processor (pww: see OracleAttnProcessor)."""
     procs = {}
     for name in unet.attn_processors.keys():
         place = "mid" if name.startswith("mid_block") else ("up" if name.startswith("up_blocks") else "down")
-        procs[name] = oattn.OracleAttnProcessor(store, place)
+        procs[name] = oattn.OracleAttnProcessor(store, place, pww)
     unet.set_attn_processor(procs)
     store.num_att_layers = len(procs)
 
@@ -50,7 +50,9 @@ class GuidedSampler:
     def __init__(self, unet, plan, *, thresholds, config_thresholds=None, only_update_on_threshold_steps=True,
                  max_iter_to_alter=25, run_standard_sd=False, guidance_scale=7.5, steps=50, scale_factor=20,
                  scale_range=(1.0, 0.5), smooth=True, sigma=0.5, kernel_size=3, attention_res=16,
-                 normalize_eot=False, n_prompt_tokens=None, max_refinement_steps=10):
+                 normalize_eot=False, n_prompt_tokens=None, max_refinement_steps=10, paint_with_words=None):
+        """paint_with_words: None or dict(stop=, weight=): the additive box mask of utils/ptp_utils.py:113-138 for the
+        BOX tokens of `plan` while the step index is below `stop`."""
         self.unet, self.plan = unet, plan
         self.thresholds = dict(thresholds) if len(thresholds) else {0: float("inf")}
         self.config_thresholds = dict(config_thresholds if config_thresholds is not None else thresholds)
@@ -67,8 +69,19 @@ class GuidedSampler:
         self.recurse_steps = max(plan.hyper.get("recurse_steps", 1), 1)
         self.recurse_until = plan.hyper.get("recurse_until", 20)
         self.store = oattn.OracleStore()
-        install_processors(unet, self.store)
         self.acp = alphas_cumprod()
+        self.cur_i, self.cur_t = 0, 0
+        pww = None
+        if paint_with_words:
+            boxes = {e["index"]: e["geom"] for e in plan.entries if e["kind"] == "BOX"}
+
+            def pww(n_pixels):  # state.cur_time_step_iter < stop; sigma_t = sqrt((1 - a_t) / a_t)  (shared_state.get_sigma)
+                if not self.cur_i < paint_with_words["stop"]:
+                    return None
+                a = float(self.acp[self.cur_t])
+                return (oattn.paint_with_words_mask(boxes, n_pixels, plan.hyper["shrink_factor"], paint_with_words["weight"]),
+                        math.log(1 + ((1 - a) / a) ** 0.5))
+        install_processors(unet, self.store, pww)
         self.calls = {"fwd_b1_grad": 0, "bwd": 0, "fwd_b2": 0, "loss_evals": 0}
         self.trace = []
 
@@ -110,6 +123,7 @@ class GuidedSampler:
         cond = prompt_embeds[1:2]
         latents = latents.clone()
         for i, t in enumerate(ddim_timesteps(self.steps)):
+            self.cur_i, self.cur_t = i, t
             for rstep in range(self.recurse_steps):
                 updated = False
                 with torch.enable_grad():

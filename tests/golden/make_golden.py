@@ -439,11 +439,26 @@ def g6_processor():
         ("cross_big", 16, 2, 1056, 77, 24, 1, "down"),  # N > 32^2: not stored
         ("self_d16", 32, 2, 64, None, 32, 1, "mid"),
         ("self_d40", 80, 2, 256, None, 80, 1, "up"),
+        # paint-with-words (ptp_utils.py:113-138): additive box mask scaled by the global score maximum and log(1+sigma_t)
+        ("cross_pww_d16", 32, 2, 256, 77, 48, 1, "up"),
+        ("cross_pww_d40_b2", 80, 2, 64, 77, 48, 2, "mid"),
     ]
     arrs = {}
     meta = []
+    sys.path.insert(0, str(OUT.parent.parent))
+    from oracle.pipeline import alphas_cumprod, ddim_timesteps
+    acp = alphas_cumprod().numpy().astype(np.float64)
     for si, (name, C, heads, N, ctx_len, ctx_dim, B, place) in enumerate(specs):
         seed = 600 + 10 * si
+        pww = None
+        state.curHyperParams = dict(state.hyperParameterOverrides)
+        if "pww" in name:
+            pww = {"stop": 3, "weight": 0.7, "iter": 1}
+            state.curHyperParams.update(paint_with_words_stop=pww["stop"], paint_with_words_weight=pww["weight"])
+            state.cur_time_step_iter = pww["iter"]
+            state.timesteps = ddim_timesteps(50)
+            state.sigmas = ((1 - acp) / acp) ** 0.5
+            pww["log1p_sigma"] = float(np.log(1 + state.get_sigma()))
         attn = DuckAttention(C, heads, ctx_dim, seed=0)
         with torch.no_grad():  # weights from the integer-hash generator: rebuilt by the tests
             for pi, (pn, p) in enumerate(attn.named_parameters()):
@@ -468,7 +483,7 @@ def g6_processor():
         arrs[f"{name}.out"] = f32(out)
         arrs[f"{name}.dx"] = f32(x.grad)
         arrs[f"{name}.dq"] = f32(attn.captured["q"].grad)
-        meta.append({"name": name, "C": C, "heads": heads, "N": N, "ctx_len": ctx_len, "ctx_dim": ctx_dim,
+        meta.append({"name": name, "C": C, "heads": heads, "N": N, "ctx_len": ctx_len, "ctx_dim": ctx_dim, "pww": pww,
                      "batch": B, "place": place, "scale": attn.scale, "stored": bool(stored), "seed": seed,
                      "param_order": [pn for pn, _ in attn.named_parameters()],
                      "store_keys": {k: len(v) for k, v in store.attention_store.items()},

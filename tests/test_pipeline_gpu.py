@@ -431,3 +431,32 @@ def test_sdxl_layout_one_guidance_step(dt, tol_maps, tol_grad):
     np.testing.assert_allclose(loss.item(), float(r["loss"]), rtol=1e-4 if dt == "f32" else 3e-2)
     err = (g_hip.float().cpu() - g_ref).abs().max().item() / g_ref.abs().max().item()
     assert err < tol_grad, err
+
+
+def test_paint_with_words_pipeline_vs_oracle():
+    """curHyperParams['paint_with_words_stop'] > 0 through the product path (score maximum, biased capture kernels, the
+    gradient through the maximum) for the first step only, fp32, against the CPU oracle loop with the same setting."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    hyper = dict(G9[2]["hyper"], paint_with_words_stop=1, paint_with_words_weight=0.8)
+    meta = dict(G9[2], steps=3, hyper=hyper)
+    thr = {0: 0.5}
+    unet, embeds, lat0, noise, _ = g9_setup(meta)
+    plan = oloss.TokenPlan(BASE_ENTRIES, {k: v for k, v in hyper.items() if not k.startswith("paint")})
+    s = GuidedSampler(unet, plan, thresholds=thr, only_update_on_threshold_steps=meta["only_update_on_threshold_steps"],
+                      max_iter_to_alter=meta["max_iter_to_alter"], steps=meta["steps"], scale_factor=meta["scale_factor"],
+                      paint_with_words={"stop": 1, "weight": 0.8})
+    ref = s.sample(lat0, embeds, noise).numpy()
+    s0 = GuidedSampler(unet, plan, thresholds=thr, only_update_on_threshold_steps=meta["only_update_on_threshold_steps"],
+                       max_iter_to_alter=meta["max_iter_to_alter"], steps=meta["steps"], scale_factor=meta["scale_factor"])
+    plain = s0.sample(lat0, embeds, noise).numpy()
+    assert np.abs(ref - plain).max() > 1e-2 * np.abs(plain).max()       # the mask really changes the result
+    import copy
+    pipe = build_product(copy.deepcopy(unet), torch.float32)
+    pipe.use_graphs = True    # must fall back to eager launches by itself while paint-with-words is on
+    out, _ = run_product(pipe, meta, embeds, lat0, noise, thr)
+    pipe.use_graphs = False
+    assert s.calls["bwd"] >= 1
+    assert (out.unet_calls["fwd_b1_grad"], out.unet_calls["bwd"]) == (s.calls["fwd_b1_grad"], s.calls["bwd"])
+    err = np.abs(out.latents.float().cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < 5e-3, err
