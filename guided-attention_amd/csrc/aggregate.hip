@@ -23,18 +23,34 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a, int n_elem, f
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n_elem) return;
   float acc = 0.f;
-  for (int m = 0; m < a.n_maps; ++m) {
-    const T* src = static_cast<const T*>(a.maps[m]) + e;
-    const int nh = a.heads[m];
-    int h = 0;
-    for (; h + 8 <= nh; h += 8) {  // 8 loads in flight, then the adds in list order (same sum as the scalar loop)
-      T v[8];
+  // Four tensors x eight head-maps = 32 loads in flight per lane (the 5 x 8 maps of the SD-1.x case take two round
+  // trips instead of five); the adds then run in list order within the batch: tensor-major, head-minor.  Tensors whose
+  // head count is not a multiple of 8 finish in the scalar tail below, still in order.
+  for (int m0 = 0; m0 < a.n_maps; m0 += 4) {
+    int hmax = 0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(h + j) * n_elem];
+    for (int i = 0; i < 4; ++i)
+      if (m0 + i < a.n_maps) hmax = max(hmax, a.heads[m0 + i] & ~7);
+    for (int h0 = 0; h0 < hmax; h0 += 8) {
+      T v[4][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc += Traits<T>::to_f32(v[j]);
+      for (int i = 0; i < 4; ++i) {
+        const bool live = m0 + i < a.n_maps && h0 + 8 <= (a.heads[m0 + i < a.n_maps ? m0 + i : 0] & ~7);
+        const T* src = static_cast<const T*>(a.maps[live ? m0 + i : m0]) + e;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = live ? src[(size_t)(h0 + j) * n_elem] : Traits<T>::zero();
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += Traits<T>::to_f32(v[i][j]);
     }
-    for (; h < nh; ++h) acc += Traits<T>::to_f32(src[(size_t)h * n_elem]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (m0 + i >= a.n_maps) continue;
+      const T* src = static_cast<const T*>(a.maps[m0 + i]) + e;
+      for (int h = a.heads[m0 + i] & ~7; h < a.heads[m0 + i]; ++h) acc += Traits<T>::to_f32(src[(size_t)h * n_elem]);
+    }
   }
   A[e] = acc / (float)a.total_heads;
 }

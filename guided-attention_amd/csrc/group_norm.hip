@@ -6,8 +6,10 @@
 // around every following convolution.  This pair of kernels keeps NHWC end to end:
 //   stats : one workgroup per (image, pixel block): coalesced row reads (4 B = 2 channels per lane; every
 //           channel pair lies in one group because C/G is even), per-thread sums, fixed-order LDS reduction
-//           to per-group partial (sum, sum of squares)                       -> workspace [B][NB][G][2]
-//   apply : folds the <= 32 partials (fixed order), y = silu((x - mean) * rstd * gamma + beta)
+//           to per-group partial (sum, sum of squares)                       -> workspace [B][NB][G][2], NB <= 64
+//   apply : every workgroup first folds the NB partials of all G groups itself (8 lanes per group, fixed order: the
+//           same (mean, rstd) bits in every workgroup) — there is no separate finalize launch — then
+//           y = silu((x - mean) * rstd * gamma + beta); workgroup 0 also leaves (mean, rstd) for the backward
 // Backward recomputes the normalised value and the SiLU derivative, reduces (sum dyhat, sum dyhat*yhat) the same
 // way and writes dx; gamma/beta gradients are not produced (the UNet weights are frozen on this path).
 // HBM-bound: forward moves 2 reads + 1 write of the tensor (the second read hits L2/MALL at these sizes).
@@ -18,7 +20,6 @@ using namespace ga;
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxNB = 256;
 constexpr int kMaxNPT = 5;  // channel pairs per thread: C <= 2560
 constexpr int kU = 8;       // pixels per lane whose loads are issued together (16 in the apply kernels)
 
@@ -104,53 +105,68 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict_
   fold_to_groups<NPT>(s0, s1, CP, cpg, G, lds, partial + ((size_t)b * gridDim.x + nb) * G * 2);
 }
 
-// One wave per (image, group) folds that group's NB per-block partials in a fixed order (lane = partial index mod 64,
-// then the butterfly) and turns them into what the apply kernels need — a single round of loads per lane:
-//   FWD : out[b][g] = (mean, rstd)            BWD : out[b][g] = (mean of dyhat, mean of dyhat*yhat)
-// grid (B, ceil(G / 4)), 4 waves = 4 groups per workgroup.
+// Fold the NB per-block partials of image b into per-group results in LDS (`res`, float2 per group), fixed order:
+// 8 lanes per group (lane part sums partials part, part + 8, ...), then a 3-step butterfly inside the 8 lanes.
+//   FWD : (mean, rstd)            BWD : (mean of dyhat, mean of dyhat * yhat)
+// Needs G <= kThreads / 8 = 32 groups per pass (more: several passes).  Ends with a barrier.  keep != nullptr: this
+// workgroup also stores the results (the forward's (mean, rstd) that the backward reads).
+constexpr int kMaxStatsNB = 128;
+
 template <bool FWD>
-__global__ __launch_bounds__(kThreads) void gn_finalize_kernel(const float* __restrict__ partial, int NB, int G,
-                                                               float inv_n, float eps, float* __restrict__ out) {
-  const int b = blockIdx.x, g = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (g >= G) return;
-  const float2* pp = reinterpret_cast<const float2*>(partial) + (size_t)b * NB * G + g;
-  float2 v[kMaxNB / 64];
+__device__ __forceinline__ void fold_partials(const float* __restrict__ partial, int b, int NB, int G, float inv_n,
+                                              float eps, float2* res, float* keep) {
+  const float2* pp = reinterpret_cast<const float2*>(partial) + (size_t)b * NB * G;
+  for (int g0 = 0; g0 < G; g0 += kThreads / 8) {
+    const int g = g0 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+    float2 v[kMaxStatsNB / 8];
 #pragma unroll
-  for (int i = 0; i < kMaxNB / 64; ++i) {
-    const int nb = lane + 64 * i;
-    v[i] = nb < NB ? pp[(size_t)nb * G] : float2{0.f, 0.f};
-  }
-  float sa = 0.f, sc = 0.f;
-#pragma unroll
-  for (int i = 0; i < kMaxNB / 64; ++i) {
-    sa += v[i].x;
-    sc += v[i].y;
-  }
-  const float v0 = wave_reduce_sum(sa), v1 = wave_reduce_sum(sc);
-  if (lane == 0) {
-    float o0, o1;
-    if (FWD) {
-      const double mean = (double)v0 * inv_n;
-      const double var = fmax((double)v1 * inv_n - mean * mean, 0.0);
-      o0 = (float)mean;
-      o1 = rsqrtf((float)var + eps);
-    } else {
-      o0 = v0 * inv_n;
-      o1 = v1 * inv_n;
+    for (int i = 0; i < kMaxStatsNB / 8; ++i) {
+      const int nb = part + 8 * i;
+      v[i] = (g < G && nb < NB) ? pp[(size_t)nb * G + g] : float2{0.f, 0.f};
     }
-    out[((size_t)b * G + g) * 2] = o0;
-    out[((size_t)b * G + g) * 2 + 1] = o1;
+    float sa = 0.f, sc = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxStatsNB / 8; ++i) {
+      sa += v[i].x;
+      sc += v[i].y;
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      sa += __shfl_xor(sa, o, 64);
+      sc += __shfl_xor(sc, o, 64);
+    }
+    if (part == 0 && g < G) {
+      float o0, o1;
+      if (FWD) {
+        const double mean = (double)sa * inv_n;
+        const double var = fmax((double)sc * inv_n - mean * mean, 0.0);
+        o0 = (float)mean;
+        o1 = rsqrtf((float)var + eps);
+      } else {
+        o0 = sa * inv_n;
+        o1 = sc * inv_n;
+      }
+      res[g] = float2{o0, o1};
+      if (keep != nullptr) {
+        keep[((size_t)b * G + g) * 2] = o0;
+        keep[((size_t)b * G + g) * 2 + 1] = o1;
+      }
+    }
   }
+  __syncthreads();
 }
 
 template <typename T, bool ACT, int NPT, int W>
 __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
                                                             const T* __restrict__ gamma,
                                                             const T* __restrict__ beta, T* __restrict__ y,
-                                                            const float* __restrict__ stats, int HW, int C, int G,
+                                                            const float* __restrict__ partial, int NB, float inv_n,
+                                                            float eps, float* __restrict__ stats, int HW, int C, int G,
                                                             int PB) {
+  __shared__ float2 res[64];
   const int b = blockIdx.y, CP = C / W, cpg = (C / G) / W;
-  const float* mu_rs = stats + (size_t)b * G * 2;
+  fold_partials<true>(partial, b, NB, G, inv_n, eps, res, blockIdx.x == 0 ? stats : nullptr);
+  const float* mu_rs = reinterpret_cast<const float*>(res);
   float sc[NPT][W], sh[NPT][W];
 #pragma unroll
   for (int k = 0; k < NPT; ++k) {
@@ -274,9 +290,11 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
                                                                 const T* __restrict__ gamma,
                                                                 const T* __restrict__ beta,
                                                                 const float* __restrict__ stats,
-                                                                const float* __restrict__ fin, T* __restrict__ dx,
-                                                                int HW, int C, int G, int PB) {
+                                                                const float* __restrict__ partial, int NB, float inv_n,
+                                                                T* __restrict__ dx, int HW, int C, int G, int PB) {
+  __shared__ float2 res[64];
   const int b = blockIdx.y, CP = C / W, cpg = (C / G) / W;
+  fold_partials<false>(partial, b, NB, G, inv_n, 0.f, res, nullptr);
   float mu[NPT], rs[NPT], a1[NPT], a2[NPT], g0[NPT][W], b0[NPT][W], cbk[NPT][W];
 #pragma unroll
   for (int k = 0; k < NPT; ++k) {
@@ -285,8 +303,8 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
       const int g = cp / cpg;
       mu[k] = stats[((size_t)b * G + g) * 2];
       rs[k] = stats[((size_t)b * G + g) * 2 + 1];
-      a1[k] = fin[((size_t)b * G + g) * 2];
-      a2[k] = fin[((size_t)b * G + g) * 2 + 1];
+      a1[k] = res[g].x;
+      a2[k] = res[g].y;
       const Item<T, W> ga_ = reinterpret_cast<const Item<T, W>*>(gamma)[cp];
       const Item<T, W> be = reinterpret_cast<const Item<T, W>*>(beta)[cp];
       load_chan_bias<T, W>(cbias, b, CP, cp, cbk[k]);
@@ -388,6 +406,8 @@ __device__ __forceinline__ void wide_fold(const WideMap& m, const float (&c0)[8]
   }
 }
 
+constexpr int kUS = 16;  // stats kernels: loads in flight per lane (a workgroup's whole pixel block in one round trip)
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void gn_wide_stats_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
                                                                  float* __restrict__ partial, int HW, int C, int G,
@@ -405,13 +425,13 @@ __global__ __launch_bounds__(kThreads) void gn_wide_stats_kernel(const T* __rest
       for (int j = 0; j < 8; ++j) cb[j] = Traits<T>::to_f32(bv.v[j]);
     }
     const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
-    for (int p = p0 + m.pr; p < p1; p += kU * m.RP) {
-      Vec8<T> v[kU];
+    for (int p = p0 + m.pr; p < p1; p += kUS * m.RP) {
+      Vec8<T> v[kUS];
 #pragma unroll
-      for (int u = 0; u < kU; ++u)
+      for (int u = 0; u < kUS; ++u)
         if (p + u * m.RP < p1) v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
 #pragma unroll
-      for (int u = 0; u < kU; ++u)
+      for (int u = 0; u < kUS; ++u)
         if (p + u * m.RP < p1) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -429,12 +449,15 @@ template <typename T, bool ACT>
 __global__ __launch_bounds__(kThreads) void gn_wide_apply_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
                                                                  const T* __restrict__ gamma,
                                                                  const T* __restrict__ beta, T* __restrict__ y,
-                                                                 const float* __restrict__ stats, int HW, int C, int G,
-                                                                 int PB) {
+                                                                 const float* __restrict__ partial, int NB, float inv_n,
+                                                                 float eps, float* __restrict__ stats, int HW, int C,
+                                                                 int G, int PB) {
+  __shared__ float2 res[64];
   const WideMap m(C, G);
-  if (!m.active) return;
   const int b = blockIdx.y, p0 = blockIdx.x * PB, p1 = min(HW, p0 + PB);
-  const float* mr = stats + (size_t)b * G * 2;
+  fold_partials<true>(partial, b, NB, G, inv_n, eps, res, blockIdx.x == 0 ? stats : nullptr);
+  if (!m.active) return;
+  const float* mr = reinterpret_cast<const float*>(res);
   float sc[8], sh[8];
   {
     const Vec8<T> gm = reinterpret_cast<const Vec8<T>*>(gamma)[m.vec], bt = reinterpret_cast<const Vec8<T>*>(beta)[m.vec];
@@ -540,19 +563,22 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
                                                                      const T* __restrict__ gamma,
                                                                      const T* __restrict__ beta,
                                                                      const float* __restrict__ stats,
-                                                                     const float* __restrict__ fin, T* __restrict__ dx,
-                                                                     int HW, int C, int G, int PB) {
+                                                                     const float* __restrict__ partial, int NB,
+                                                                     float inv_n, T* __restrict__ dx, int HW, int C,
+                                                                     int G, int PB) {
+  __shared__ float2 res[64];
   const WideMap m(C, G);
-  if (!m.active) return;
   const int b = blockIdx.y, p0 = blockIdx.x * PB, p1 = min(HW, p0 + PB);
+  fold_partials<false>(partial, b, NB, G, inv_n, 0.f, res, nullptr);
+  if (!m.active) return;
   WideBwdConst<T> k;
   k.load(m, cbias, gamma, beta, stats, b, C, G);
   float a1[8], a2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int g = j < m.split ? m.gA : m.gA + 1;
-    a1[j] = fin[((size_t)b * G + g) * 2];
-    a2[j] = fin[((size_t)b * G + g) * 2 + 1];
+    a1[j] = res[g < G ? g : G - 1].x;
+    a2[j] = res[g < G ? g : G - 1].y;
   }
   const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
   const Vec8<T>* db = reinterpret_cast<const Vec8<T>*>(dy + (size_t)b * HW * C) + m.vec;
@@ -789,7 +815,7 @@ int geometry(int B, int HW, int C, int G, Geom& g) {
   const int CP = C / g.W;
   g.NPT = (CP + kThreads - 1) / kThreads;
   if (g.NPT > kMaxNPT) return GA_ERR_SHAPE;
-  g.PBs = (HW + kMaxNB - 1) / kMaxNB < 8 ? 8 : (HW + kMaxNB - 1) / kMaxNB;  // stats: <= 256 blocks of >= 8 pixels
+  g.PBs = (HW + kMaxStatsNB - 1) / kMaxStatsNB < 8 ? 8 : (HW + kMaxStatsNB - 1) / kMaxStatsNB;  // stats: <= 64 blocks
   g.NB = (HW + g.PBs - 1) / g.PBs;
   g.PBa = HW >= 4096 ? 16 : (HW >= 1024 ? 8 : 4);                            // apply: small blocks
   g.NBa = (HW + g.PBa - 1) / g.PBa;
@@ -803,9 +829,9 @@ int launch_fwd_t(const void* x, const void* cbias, const void* gamma, const void
   const float inv_n = 1.0f / ((float)HW * (float)(C / G));
   hipLaunchKernelGGL((gn_stats_kernel<T, NPT, W>), dim3(g.NB, B), dim3(kThreads), g.lds, s, (const T*)x,
                      (const T*)cbias, ws, HW, C, G, g.PBs);
-  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(B, (G + 3) / 4), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, eps, stats);
   hipLaunchKernelGGL((gn_apply_kernel<T, ACT, NPT, W>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
-                     (const T*)cbias, (const T*)gamma, (const T*)beta, (T*)y, stats, HW, C, G, g.PBa);
+                     (const T*)cbias, (const T*)gamma, (const T*)beta, (T*)y, (const float*)ws, g.NB, inv_n, eps, stats,
+                     HW, C, G, g.PBa);
   return check_launch();
 }
 
@@ -813,12 +839,11 @@ template <typename T, bool ACT, int NPT, int W>
 int launch_bwd_t(const void* x, const void* cbias, const void* dy, const void* gamma, const void* beta,
                  const float* stats, void* dx, float* ws, int B, int HW, int C, int G, const Geom& g, hipStream_t s) {
   const float inv_n = 1.0f / ((float)HW * (float)(C / G));
-  float* fin = ws + (size_t)B * kMaxNB * G * 2;  // [B][G][2] behind the partials
   hipLaunchKernelGGL((gn_bwd_stats_kernel<T, ACT, NPT, W>), dim3(g.NB, B), dim3(kThreads), g.lds, s, (const T*)x,
                      (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, HW, C, G, g.PBs);
-  hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(B, (G + 3) / 4), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, 0.0f, fin);
   hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT, NPT, W>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
-                     (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, fin, (T*)dx, HW, C, G, g.PBa);
+                     (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, (const float*)ws, g.NB, inv_n,
+                     (T*)dx, HW, C, G, g.PBa);
   return check_launch();
 }
 
@@ -852,8 +877,8 @@ struct WideGeom {
   int PBs, NB, PBa, NBa;
   WideGeom(int HW, int C) {
     const int RP = kThreads / (C / 8);
-    const int fill = (HW + kMaxNB - 1) / kMaxNB;     // stats: at most kMaxNB partial blocks
-    PBs = fill > 4 * RP ? fill : 4 * RP;             // >= 4 pixels per thread
+    const int fill = (HW + kMaxStatsNB - 1) / kMaxStatsNB;     // stats: at most kMaxStatsNB partial blocks
+    PBs = fill > 8 * RP ? fill : 8 * RP;             // >= 8 pixels per thread, all loaded in one batch where they fit
     NB = (HW + PBs - 1) / PBs;
     PBa = 4 * RP;                                    // apply: one 4-deep batch of loads per thread
     NBa = (HW + PBa - 1) / PBa;
@@ -867,13 +892,14 @@ int wide_fwd(const void* x, const void* cbias, const void* gamma, const void* be
   const float inv_n = 1.0f / ((float)HW * (float)(C / G));
   hipLaunchKernelGGL(gn_wide_stats_kernel<T>, dim3(g.NB, B), dim3(kThreads), 0, s, (const T*)x, (const T*)cbias, ws, HW,
                      C, G, g.PBs);
-  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(B, (G + 3) / 4), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, eps, stats);
   if (act)
     hipLaunchKernelGGL((gn_wide_apply_kernel<T, true>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
-                       (const T*)cbias, (const T*)gamma, (const T*)beta, (T*)y, stats, HW, C, G, g.PBa);
+                       (const T*)cbias, (const T*)gamma, (const T*)beta, (T*)y, (const float*)ws, g.NB, inv_n, eps, stats,
+                       HW, C, G, g.PBa);
   else
     hipLaunchKernelGGL((gn_wide_apply_kernel<T, false>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
-                       (const T*)cbias, (const T*)gamma, (const T*)beta, (T*)y, stats, HW, C, G, g.PBa);
+                       (const T*)cbias, (const T*)gamma, (const T*)beta, (T*)y, (const float*)ws, g.NB, inv_n, eps, stats,
+                       HW, C, G, g.PBa);
   return check_launch();
 }
 
@@ -882,20 +908,20 @@ int wide_bwd(const void* x, const void* cbias, const void* dy, const void* gamma
              void* dx, float* ws, int B, int HW, int C, int G, int act, hipStream_t s) {
   const WideGeom g(HW, C);
   const float inv_n = 1.0f / ((float)HW * (float)(C / G));
-  float* fin = ws + (size_t)B * kMaxNB * G * 2;  // [B][G][2] behind the partials
   if (act)
     hipLaunchKernelGGL((gn_wide_bwd_stats_kernel<T, true>), dim3(g.NB, B), dim3(kThreads), 0, s, (const T*)x,
                        (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, HW, C, G, g.PBs);
   else
     hipLaunchKernelGGL((gn_wide_bwd_stats_kernel<T, false>), dim3(g.NB, B), dim3(kThreads), 0, s, (const T*)x,
                        (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, HW, C, G, g.PBs);
-  hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(B, (G + 3) / 4), dim3(kThreads), 0, s, ws, g.NB, G, inv_n, 0.0f, fin);
   if (act)
     hipLaunchKernelGGL((gn_wide_bwd_apply_kernel<T, true>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
-                       (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, fin, (T*)dx, HW, C, G, g.PBa);
+                       (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, (const float*)ws, g.NB,
+                       inv_n, (T*)dx, HW, C, G, g.PBa);
   else
     hipLaunchKernelGGL((gn_wide_bwd_apply_kernel<T, false>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
-                       (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, fin, (T*)dx, HW, C, G, g.PBa);
+                       (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, (const float*)ws, g.NB,
+                       inv_n, (T*)dx, HW, C, G, g.PBa);
   return check_launch();
 }
 

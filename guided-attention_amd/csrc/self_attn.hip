@@ -392,6 +392,22 @@ __device__ __forceinline__ void store_colsT(T* __restrict__ base, size_t row_str
   }
 }
 
+// Workgroup -> (batch, head, tile).  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its
+// own L2; every tile of one (batch, head) pair sweeps that pair's whole K / V (or Q / dO), so a pair's tiles should
+// share an XCD.  The launch index is therefore re-read as "XCD-major": XCD x takes the contiguous range
+// [x * W/8, (x+1) * W/8) of the pair-major work list (the W % 8 leftovers keep their place at the end).  With 8 heads
+// at batch 1 this is the old head-fastest order (one head per XCD); with 5 / 10 / 20 heads (SD-2.x, SDXL) it replaces
+// an order that smeared every head over all eight L2s (PMC: 9x the algorithmic bytes fetched past L2).  Placement is a
+// speed matter only: nothing depends on which XCD a workgroup really lands on.
+__device__ __forceinline__ void decode_block(int H, int ntile, int& b, int& head, int& tile) {
+  const unsigned W = gridDim.x, bid = blockIdx.x, cpx = W >> 3;
+  const unsigned j = bid < (cpx << 3) ? (bid & 7u) * cpx + (bid >> 3) : bid;
+  const unsigned pair = j / (unsigned)ntile;
+  tile = (int)(j - pair * (unsigned)ntile);
+  head = (int)(pair % (unsigned)H);
+  b = (int)(pair / (unsigned)H);
+}
+
 // raw v_exp_f32: arguments here are <= 0 (or the result is multiplied by something that dominates), so the
 // denormal-range fix-up sequence of exp2f (compare / select / ldexp per element) is dead weight
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -454,7 +470,8 @@ __global__ __launch_bounds__(64 * NW) void self_attn_fwd_kernel(const T* __restr
   constexpr int kVoff = row_img<T, NK, KT>();
   T* const lds = reinterpret_cast<T*>(smem);
 
-  const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
+  int b, head, qt;
+  decode_block(H, nqt, b, head, qt);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq;     // row stride of Q / K / V (H*D, or 3*H*D when they are slices of a fused QKV)
   const size_t rso = (size_t)H * D;  // row stride of O
@@ -648,7 +665,8 @@ __global__ __launch_bounds__(64 * NW) void self_attn_fwd_pipe_kernel(const T* __
   T* const kring = reinterpret_cast<T*>(smem);   // [2][kKimg]
   T* const vring = kring + 2 * kKimg;            // [2][kVimg]
 
-  const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
+  int b, head, qt;
+  decode_block(H, nqt, b, head, qt);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq, rso = (size_t)H * D;
   const T* Qb = Q + (size_t)b * N * rs + (size_t)head * D;
@@ -879,7 +897,8 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
   T* const lds = reinterpret_cast<T*>(smem);
   constexpr int kVoff = row_img<T, NK, KT>(), kToff = 2 * row_img<T, NK, KT>();
   constexpr int kBuf = NBUF == 2 ? 2 * row_img<T, NK, KT>() + col_img<T, NK, KT>() : 0;
-  const int head = blockIdx.x % H, rest = blockIdx.x / H, qt = rest % nqt, b = rest / nqt;
+  int b, head, qt;
+  decode_block(H, nqt, b, head, qt);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq, rso = (size_t)H * D;
   const size_t off = (size_t)b * N * rs + (size_t)head * D;    // into Q / K / V / dQ
@@ -1064,7 +1083,8 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
   constexpr int kBuf = NBUF == 2 ? kOne : 0;
   float* const stats = reinterpret_cast<float*>(lds + NBUF * kOne);  // [2][2][KT]: (LSE, delta) per buffer
   constexpr int kSbuf = 2 * KT;
-  const int head = blockIdx.x % H, rest = blockIdx.x / H, ktile = rest % nkt, b = rest / nkt;
+  int b, head, ktile;
+  decode_block(H, nkt, b, head, ktile);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq, rso = (size_t)H * D;
   const size_t off = (size_t)b * N * rs + (size_t)head * D;    // into Q / K / V / dK / dV

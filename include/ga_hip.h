@@ -193,7 +193,7 @@ int ga_self_attn_bwd(const void* Q, const void* K, const void* V, const void* O,
 
 /* ---------------------------------------------------------------------------------------------
  * UNet host helper: GroupNorm (+ fused SiLU) on channels-last activations, forward and backward to the
- * input (3 launches each: per-block partial sums, per-image finalize, apply).  Stands in for the GroupNorm -> SiLU pairs of the diffusers UNet blocks the reference runs in
+ * input (large levels: 2 launches each way — per-block partial sums, then an apply pass whose workgroups fold the partials themselves; <= 256 pixels: 1 launch).  Stands in for the GroupNorm -> SiLU pairs of the diffusers UNet blocks the reference runs in
  * pipeline_guided_attention.py:583-743 (diffusers 0.12.1 ResnetBlock2D / Transformer2DModel).
  *   x, y, dy, dx [B][HW][C] T (NHWC); gamma, beta [C] T; stats [B][G][2] f32 (mean, rstd), written by the
  *   forward and read by the backward; workspace GA_GN_WORKSPACE_FLOATS(B, G) f32 scratch.  C/G must be even, G <= 64,

@@ -23,8 +23,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", f"-I{
 VARIANTS = {
     "r1": ("1a2888f", []),                       # round-1 kernels
     "cur": (None, []),
-    "qb1": (None, ["-DGA_FWD_QB=1", "-DGA_BWD_CB=1"]),
-    "qb2": (None, ["-DGA_FWD_QB=2", "-DGA_BWD_CB=2"]),
+    "nw2": (None, ["-DGA_FWD_NW=2"]),
+    "nw1": (None, ["-DGA_FWD_NW=1"]),
 }
 
 
@@ -55,7 +55,8 @@ def run(which="fwd", rounds=5, iters=50):
         lib.ga_self_attn_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
         lib.ga_self_attn_bwd.argtypes = [vp] * 10 + [i32, i32, i32, i32, i32, f32, i32, vp]
         libs[name] = lib
-    shapes = [(1, 8, 4096, 40), (3, 8, 4096, 40)]
+    import os
+    shapes = [tuple(int(v) for v in t.split('x')) for t in os.environ.get('SA_SHAPES', '1x8x4096x40,3x8x4096x40').split(',')]
     results = {}
     for (B, H, N, D) in shapes:
         dev = torch.device("cuda")
