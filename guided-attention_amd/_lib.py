@@ -61,6 +61,10 @@ PROTOTYPES = {
     "ga_geglu_fwd": [_vp, _vp, _i64, _i, _i, _vp],
     "ga_geglu_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "ga_bias_residual_add": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "ga_conv3x3_pack_weights": [_vp, _vp, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp],
+    "ga_conv3x3_plan": [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i),
+                        ctypes.POINTER(ctypes.c_longlong)],
+    "ga_conv3x3_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ga_add_layer_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp],
     "ga_add_layer_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
 }

@@ -1,0 +1,400 @@
+// 3x3 convolution (pad 1, stride 1 or 2) on channels-last activations as an implicit GEMM on gfx950 MFMA — the
+// ResnetBlock / up- / down-sampling convolutions of the UNet the guidance pass runs forward and backward
+// (diffusers 0.12.1 blocks called from pipeline_guided_attention.py:583-743; the reference leaves them to cuDNN).
+//
+//   Y[m][n] = sum over tap t = (ky, kx), channel c of  X[pixel(m) + tap offset][c] * Wp[t][n][c]      (+ bias[n] + R[m][n])
+//   m = (batch, oy, ox) output pixel, n = output channel, GEMM depth K = 9 * Cin
+//
+// Why not the library kernel: at guidance batch 1 the UNet's convolutions are small-M GEMMs (M = 4096 / 1024 / 256 / 64
+// pixels against N = 320 ... 1280 channels); a 128 x 128 macro-tile leaves 20 ... 96 workgroups for 256 CUs.  This
+// kernel takes the tile from {128x128, 128x64, 64x64} and splits the GEMM depth across workgroups (split-K, f32 partial
+// slabs summed by a small epilogue kernel) so that every shape fills the chip.
+//
+// Mapping: 256 threads = 4 waves in a 2 x 2 grid over the macro-tile, each wave (BM/2) x (BN/2) as 32 x 32 MFMA blocks
+// (v_mfma_f32_32x32x16: 16 accumulator registers per block).  Per k-step of 32 channels of one tap the workgroup stages
+// an A tile [BM pixels][32] (rows gathered from the shifted input pixels, zeros outside the image) and a B tile
+// [BN][32] of the pre-packed weights Wp[tap][n][c] in LDS — both "row = m or n, depth contiguous", 80-byte rows:
+// the 16-byte fragment reads of the 32x32x16 operands are conflict-free — double-buffered, next step prefetched to
+// registers under the MFMAs, one barrier per step.  The weight fragment is the MFMA's A operand and the pixel fragment
+// its B operand, so a lane ends up with 4 consecutive output channels of ONE pixel per register quad: the tile goes
+// through LDS once more and leaves as whole 16-byte row pieces with bias and residual added on the way.
+// The backward-to-input of a stride-1 convolution is the same kernel on the upstream gradient with the weights
+// flipped and transposed (pre-packed once per weight version by the host).
+#include "attn_common.h"
+
+using namespace ga;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef GA_CONV_PRIO
+#define GA_CONV_PRIO 0
+#endif
+#ifndef GA_CONV_KC
+#define GA_CONV_KC 64
+#endif
+constexpr int kKC = GA_CONV_KC;    // depth of one k-step (channels of one tap)
+constexpr int kLD = kKC + 8;       // LDS row stride in elements (80 bytes): conflict-free 16-byte fragment reads
+constexpr int kThreads = 256;
+
+template <typename T>
+struct Mma32;
+template <>
+struct Mma32<_Float16> {
+  __device__ static __forceinline__ f32x16 run(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma32<bf16_t> {
+  __device__ static __forceinline__ f32x16 run(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+struct ConvArgs {
+  int B, H, W, Cin, Ho, Wo, Cout, stride;
+  int M;            // B * Ho * Wo
+  int steps;        // k-steps in all: 9 * Cin / 32
+  int steps_per;    // k-steps per split
+};
+
+// OUT_F32 = true: this workgroup's split writes its raw f32 partial tile to part[split][m][n] (no bias / residual).
+template <typename T, int BM, int BN, bool OUT_F32>
+__global__ __launch_bounds__(kThreads) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Wp,
+                                                           T* __restrict__ Y, float* __restrict__ part,
+                                                           const T* __restrict__ bias, const T* __restrict__ residual,
+                                                           ConvArgs a) {
+  constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
+  constexpr int IM = WM / 32, JN = WN / 32;   // 32x32 blocks per wave
+  constexpr int QP = kKC / 8;                 // 16-byte pieces per row of a k-step
+  constexpr int RPP = kThreads / QP;          // rows staged per pass
+  constexpr int PA = BM / RPP, PB = BN / RPP; // staging passes
+  constexpr int kTile = (BM + BN) * kLD;      // elements per LDS buffer
+  constexpr int kCtile = BM * (BN + 8);       // output staging tile (T), row stride BN + 8
+  constexpr int kLds = 2 * kTile > kCtile ? 2 * kTile : kCtile;
+  __shared__ __attribute__((aligned(16))) T lds[kLds];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, split = blockIdx.z;
+  const int it0 = split * a.steps_per, it1 = min(a.steps, it0 + a.steps_per);
+  const int cchunks = a.Cin / kKC;
+
+  // ---- staging assignment: thread -> (row = tid / 4 (+ 64 per pass), 16-byte piece q = tid % 4 of the 64-byte slice)
+  const int srow = tid / QP, sq = tid % QP;
+  int a_iy[PA], a_ix[PA];        // top-left input pixel of the 3x3 window (may be -1)
+  long long a_base[PA];          // element offset of pixel (iy, ix) channel 0 (only used when in bounds)
+  bool a_ok[PA];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int m = m0 + srow + RPP * p;
+    a_ok[p] = m < a.M;
+    const int mm = a_ok[p] ? m : 0;
+    const int b = mm / (a.Ho * a.Wo), rem = mm - b * (a.Ho * a.Wo);
+    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    a_iy[p] = oy * a.stride - 1;
+    a_ix[p] = ox * a.stride - 1;
+    a_base[p] = (((long long)b * a.H + a_iy[p]) * a.W + a_ix[p]) * a.Cin;
+  }
+  uint4 ra[PA], rb[PB];
+  auto load_step = [&](int it) {
+    const int tap = it / cchunks, c0 = (it - tap * cchunks) * kKC;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int iy = a_iy[p] + ky, ix = a_ix[p] + kx;
+      ra[p] = uint4{0, 0, 0, 0};
+      if (a_ok[p] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+        ra[p] = *reinterpret_cast<const uint4*>(X + a_base[p] + ((long long)ky * a.W + kx) * a.Cin + c0 + 8 * sq);
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int n = n0 + srow + RPP * p;
+      rb[p] = uint4{0, 0, 0, 0};
+      if (n < a.Cout) rb[p] = *reinterpret_cast<const uint4*>(Wp + ((long long)tap * a.Cout + n) * a.Cin + c0 + 8 * sq);
+    }
+  };
+  auto store_step = [&](int buf) {
+    T* As = lds + buf * kTile;
+    T* Bs = As + BM * kLD;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) *reinterpret_cast<uint4*>(As + (srow + RPP * p) * kLD + 8 * sq) = ra[p];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) *reinterpret_cast<uint4*>(Bs + (srow + RPP * p) * kLD + 8 * sq) = rb[p];
+  };
+
+  f32x16 acc[JN][IM];   // [n block][m block]: D = Wfrag (rows n) x Xfrag (cols m)
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;   // fragment row inside a 32-block, k half
+  if (it0 < it1) {
+    load_step(it0);
+    store_step(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int it = it0; it < it1; ++it) {
+    if (it + 1 < it1) load_step(it + 1);   // global loads in flight under this step's MFMAs
+    const T* As = lds + buf * kTile;
+    const T* Bs = As + BM * kLD;
+#pragma unroll
+    for (int kk = 0; kk < kKC / 16; ++kk) {
+      uint4 fa[IM], fb[JN];
+#pragma unroll
+      for (int i = 0; i < IM; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + (wm * WM + i * 32 + fr) * kLD + kk * 16 + fh * 8);
+#pragma unroll
+      for (int j = 0; j < JN; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + (wn * WN + j * 32 + fr) * kLD + kk * 16 + fh * 8);
+#if GA_CONV_PRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int i = 0; i < IM; ++i) acc[j][i] = Mma32<T>::run(fb[j], fa[i], acc[j][i]);
+#if GA_CONV_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+    if (it + 1 < it1) store_step(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue.  acc[j][i][r]: output channel n = n0 + wn*WN + j*32 + (r & 3) + 8 * (r >> 2) + 4 * fh,
+  //                               pixel          m = m0 + wm*WM + i*32 + fr
+  if constexpr (OUT_F32) {
+    float* dst = part + (size_t)split * a.M * a.Cout;
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+      const int m = m0 + wm * WM + i * 32 + fr;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int n = n0 + wn * WN + j * 32 + 8 * qd + 4 * fh;
+          if (n < a.Cout)
+            *reinterpret_cast<f32x4*>(dst + (size_t)m * a.Cout + n) =
+                f32x4{acc[j][i][4 * qd], acc[j][i][4 * qd + 1], acc[j][i][4 * qd + 2], acc[j][i][4 * qd + 3]};
+        }
+    }
+  } else {
+    constexpr int LDC = BN + 8;
+    T* Cs = lds;   // every wave passed the last barrier of the loop: the A / B buffers are free
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          typename Traits<T>::frag f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) f[r] = Traits<T>::from_f32(acc[j][i][4 * qd + r]);
+          store_frag<T>(Cs + (wm * WM + i * 32 + fr) * LDC + wn * WN + j * 32 + 8 * qd + 4 * fh, f);
+        }
+    __syncthreads();
+    constexpr int VPR = BN / 8;                    // 16-byte vectors per tile row
+    for (int v = tid; v < BM * VPR; v += kThreads) {
+      const int r = v / VPR, cv = (v - r * VPR) * 8;
+      const int m = m0 + r, n = n0 + cv;
+      if (m >= a.M || n >= a.Cout) continue;
+      uint4 val = *reinterpret_cast<const uint4*>(Cs + r * LDC + cv);
+      if (bias != nullptr || residual != nullptr) {
+        T* e = reinterpret_cast<T*>(&val);
+        uint4 bv = uint4{0, 0, 0, 0}, rv = uint4{0, 0, 0, 0};
+        if (bias != nullptr) bv = *reinterpret_cast<const uint4*>(bias + n);
+        if (residual != nullptr) rv = *reinterpret_cast<const uint4*>(residual + (size_t)m * a.Cout + n);
+        const T* be = reinterpret_cast<const T*>(&bv);
+        const T* re = reinterpret_cast<const T*>(&rv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          e[k] = Traits<T>::from_f32(Traits<T>::to_f32(e[k]) + Traits<T>::to_f32(be[k]) + Traits<T>::to_f32(re[k]));
+      }
+      *reinterpret_cast<uint4*>(Y + (size_t)m * a.Cout + n) = val;
+    }
+  }
+}
+
+// split-K epilogue: Y[m][n] = sum_s part[s][m][n] (+ bias[n] + R[m][n]), fixed summation order; 8 channels per thread
+template <typename T>
+__global__ __launch_bounds__(kThreads) void conv_splitk_sum_kernel(const float* __restrict__ part, int splits, T* __restrict__ Y,
+                                                                   const T* __restrict__ bias,
+                                                                   const T* __restrict__ residual, long long MN, int Cout) {
+  const long long v = ((long long)blockIdx.x * kThreads + threadIdx.x) * 8;
+  if (v >= MN) return;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < splits; ++sp) {
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(part + (size_t)sp * MN + v);
+    const f32x4 p1 = *reinterpret_cast<const f32x4*>(part + (size_t)sp * MN + v + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s[k] += p0[k];
+      s[4 + k] += p1[k];
+    }
+  }
+  const int n = (int)(v % Cout);
+  uint4 bv = uint4{0, 0, 0, 0}, rv = uint4{0, 0, 0, 0}, out;
+  if (bias != nullptr) bv = *reinterpret_cast<const uint4*>(bias + n);
+  if (residual != nullptr) rv = *reinterpret_cast<const uint4*>(residual + v);
+  const T* be = reinterpret_cast<const T*>(&bv);
+  const T* re = reinterpret_cast<const T*>(&rv);
+  T* oe = reinterpret_cast<T*>(&out);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) oe[k] = Traits<T>::from_f32(s[k] + Traits<T>::to_f32(be[k]) + Traits<T>::to_f32(re[k]));
+  *reinterpret_cast<uint4*>(Y + v) = out;
+}
+
+// pre-pack: W [Cout][Cin][3][3] in whatever strides the framework holds (element strides given) ->
+//   forward : Wp[t = ky*3+kx][n = cout][c = cin]          = W[cout][cin][ky][kx]
+//   backward: Wp[t = ky*3+kx][n = cin ][c = cout]         = W[cout][cin][2-ky][2-kx]   (dX = conv(dY, flipped, transposed))
+template <typename T>
+__global__ __launch_bounds__(kThreads) void conv_pack_kernel(const T* __restrict__ W, T* __restrict__ Wp, int Cout, int Cin,
+                                                             long long s_o, long long s_i, long long s_y, long long s_x,
+                                                             int transpose) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const long long total = 9LL * Cout * Cin;
+  if (idx >= total) return;
+  const int N = transpose ? Cin : Cout, C = transpose ? Cout : Cin;
+  const int c = (int)(idx % C);
+  const int n = (int)((idx / C) % N);
+  const int t = (int)(idx / ((long long)C * N));
+  const int ky = t / 3, kx = t - 3 * ky;
+  const int co = transpose ? c : n, ci = transpose ? n : c;
+  const int sy = transpose ? 2 - ky : ky, sx = transpose ? 2 - kx : kx;
+  Wp[idx] = W[co * s_o + ci * s_i + sy * s_y + sx * s_x];
+}
+
+struct Plan {
+  int bm, bn, splits;
+};
+
+// Tile and split choice.  What the sweep over every UNet shape showed (tools/conv_tune.py, profiles/): the best plan
+// puts about 480 workgroups on the chip (just under two per CU) with the largest tile that gets there, splitting the
+// GEMM depth as needed (at most 16 ways, at least 3 k-steps per slice), and avoids tiles that pad the channel count
+// (320 outputs: 64-wide tiles).  Measured plans for the UNet's own shapes live in conv_plans.json on the host side;
+// this is the rule for everything else.
+Plan choose_plan(int M, int N, int steps) {
+  const int cands[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+  const double tile_cost[3] = {1.0, 1.08, 1.22};   // relative time per flop of the tile shapes (operand reuse)
+  Plan best{64, 64, 1};
+  double best_cost = 1e30;
+  for (int ci = 0; ci < 3; ++ci) {
+    const int bm = cands[ci][0], bn = cands[ci][1];
+    const long long tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn, tiles = tm * tn;
+    const double waste = (double)(tm * bm) * (double)(tn * bn) / ((double)M * (double)N);
+    const int max_s = steps / 3 < 16 ? (steps / 3 < 1 ? 1 : steps / 3) : 16;
+    for (int s = 1; s <= max_s; ++s) {
+      const double wgs = (double)tiles * s;
+      // fill: below ~480 workgroups CUs idle; above, whole extra rounds of ~512 resident workgroups
+      const double fill = wgs <= 512.0 ? 480.0 / (wgs < 480.0 ? wgs : 480.0) : ((double)((long long)((wgs + 511) / 512)) * 512.0) / wgs;
+      const double split_cost = 1.0 + 0.015 * (s - 1);   // f32 partial slabs written and summed
+      const double cost = waste * tile_cost[ci] * fill * split_cost;
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = Plan{bm, bn, s};
+      }
+    }
+  }
+  return best;
+}
+
+template <typename T, int BM, int BN>
+int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T* residual, const ConvArgs& a, int splits,
+                hipStream_t s) {
+  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, splits);
+  if (splits == 1) {
+    hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, false>), grid, dim3(kThreads), 0, s, X, Wp, Y, (float*)nullptr, bias,
+                       residual, a);
+  } else {
+    hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, true>), grid, dim3(kThreads), 0, s, X, Wp, (T*)nullptr, ws, (const T*)nullptr,
+                       (const T*)nullptr, a);
+    const long long MN = (long long)a.M * a.Cout;
+    hipLaunchKernelGGL(conv_splitk_sum_kernel<T>, dim3((unsigned)((MN / 8 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       (const float*)ws, splits, Y, bias, residual, MN, a.Cout);
+  }
+  return check_launch();
+}
+
+template <typename T>
+int conv_t(const void* X, const void* Wp, void* Y, float* ws, const void* bias, const void* residual, ConvArgs a, int bm,
+           int bn, int splits, hipStream_t s) {
+  a.steps = 9 * a.Cin / kKC;
+  a.steps_per = (a.steps + splits - 1) / splits;
+  const T* x = (const T*)X;
+  const T* w = (const T*)Wp;
+  const T* b = (const T*)bias;
+  const T* r = (const T*)residual;
+  if (bm == 128 && bn == 128) return launch_tile<T, 128, 128>(x, w, (T*)Y, ws, b, r, a, splits, s);
+  if (bm == 128 && bn == 64) return launch_tile<T, 128, 64>(x, w, (T*)Y, ws, b, r, a, splits, s);
+  if (bm == 64 && bn == 64) return launch_tile<T, 64, 64>(x, w, (T*)Y, ws, b, r, a, splits, s);
+  return GA_ERR_SHAPE;
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int ga_conv3x3_plan(int B, int H, int W, int Cin, int Cout, int stride, int* bm, int* bn, int* splits,
+                               long long* workspace_floats) {
+  if (!bm || !bn || !splits || !workspace_floats) return GA_ERR_NULL;
+  if (B < 1 || H < 1 || W < 1 || Cin < kKC || Cin % kKC != 0 || Cout < 8 || Cout % 8 != 0 || (stride != 1 && stride != 2))
+    return GA_ERR_SHAPE;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const Plan p = choose_plan(B * Ho * Wo, Cout, 9 * Cin / kKC);
+  *bm = p.bm;
+  *bn = p.bn;
+  *splits = p.splits;
+  *workspace_floats = p.splits > 1 ? (long long)p.splits * B * Ho * Wo * Cout : 0;
+  return GA_OK;
+}
+
+extern "C" int ga_conv3x3_pack_weights(const void* W, void* Wp, int Cout, int Cin, int64_t stride_o, int64_t stride_i,
+                                       int64_t stride_y, int64_t stride_x, int transpose_flip, int dtype,
+                                       ga_stream_t stream) {
+  if (!W || !Wp) return GA_ERR_NULL;
+  if (Cout < 1 || Cin < 1) return GA_ERR_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long long total = 9LL * Cout * Cin;
+  dim3 grid((unsigned)((total + kThreads - 1) / kThreads));
+  switch (dtype) {
+    case GA_F16:
+      hipLaunchKernelGGL(conv_pack_kernel<_Float16>, grid, dim3(kThreads), 0, s, (const _Float16*)W, (_Float16*)Wp, Cout, Cin,
+                         (long long)stride_o, (long long)stride_i, (long long)stride_y, (long long)stride_x, transpose_flip);
+      break;
+    case GA_BF16:
+      hipLaunchKernelGGL(conv_pack_kernel<bf16_t>, grid, dim3(kThreads), 0, s, (const bf16_t*)W, (bf16_t*)Wp, Cout, Cin,
+                         (long long)stride_o, (long long)stride_i, (long long)stride_y, (long long)stride_x, transpose_flip);
+      break;
+    default:
+      return GA_ERR_DTYPE;
+  }
+  return check_launch();
+}
+
+extern "C" int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* workspace, const void* bias,
+                               const void* residual, int B, int H, int W, int Cin, int Cout, int stride, int bm, int bn,
+                               int splits, int dtype, ga_stream_t stream) {
+  if (!X || !Wp || !Y) return GA_ERR_NULL;
+  if (B < 1 || H < 1 || W < 1 || Cin < kKC || Cin % kKC != 0 || Cout < 8 || Cout % 8 != 0 || (stride != 1 && stride != 2))
+    return GA_ERR_SHAPE;
+  if (splits < 1 || splits > 64 || (splits > 1 && !workspace)) return GA_ERR_SHAPE;
+  if (!al16(X) || !al16(Wp) || !al16(Y) || (bias && !al16(bias)) || (residual && !al16(residual))) return GA_ERR_ALIGN;
+  ConvArgs a;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stride = stride;
+  a.Ho = (H - 1) / stride + 1;
+  a.Wo = (W - 1) / stride + 1;
+  a.M = B * a.Ho * a.Wo;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case GA_F16: return conv_t<_Float16>(X, Wp, Y, workspace, bias, residual, a, bm, bn, splits, s);
+    case GA_BF16: return conv_t<bf16_t>(X, Wp, Y, workspace, bias, residual, a, bm, bn, splits, s);
+    default: return GA_ERR_DTYPE;
+  }
+}

@@ -711,6 +711,120 @@ def add_layer_norm(a, x, weight, bias, eps):
     return AddLayerNorm.apply(a, x, weight, bias, eps)
 
 
+# --------------------------------------------------------------------------------------- 3x3 convolution (implicit GEMM)
+_conv_plan_cache = {}
+_conv_pack_cache = {}   # (weight data_ptr, version, dtype, transpose) -> packed tensor (weights are frozen on this path)
+
+
+_conv_plan_table = None
+
+
+def _measured_conv_plans():
+    """{(M, Cin, Cout, stride): (bm, bn, splits)} measured on an MI355X for the UNet's own shapes (tools/conv_tune.py);
+    shapes not listed take the rule of ga_conv3x3_plan."""
+    global _conv_plan_table
+    if _conv_plan_table is None:
+        import json
+        from pathlib import Path
+        path = Path(__file__).resolve().parent / "conv_plans.json"
+        _conv_plan_table = {}
+        if path.exists():
+            for k, v in json.loads(path.read_text()).items():
+                _conv_plan_table[tuple(int(x) for x in k.split(","))] = tuple(v)
+    return _conv_plan_table
+
+
+def conv3x3_plan(B, H, W, Cin, Cout, stride):
+    key = (B, H, W, Cin, Cout, stride)
+    plan = _conv_plan_cache.get(key)
+    if plan is None:
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        hit = _measured_conv_plans().get((B * Ho * Wo, Cin, Cout, stride))
+        if hit is not None:
+            bm, bn, sp = hit
+            plan = _conv_plan_cache[key] = (bm, bn, sp, sp * B * Ho * Wo * Cout if sp > 1 else 0)
+            return plan
+        bm, bn, sp, ws = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+        check(load().ga_conv3x3_plan(B, H, W, Cin, Cout, stride, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp),
+                                     ctypes.byref(ws)), "ga_conv3x3_plan")
+        plan = _conv_plan_cache[key] = (bm.value, bn.value, sp.value, ws.value)
+    return plan
+
+
+def conv3x3_packed_weights(weight, transpose_flip):
+    """[9][N][C] pack of a (Cout, Cin, 3, 3) weight (any strides), cached per (storage, version)."""
+    key = (weight.data_ptr(), weight._version, weight.dtype, bool(transpose_flip), tuple(weight.stride()))
+    hit = _conv_pack_cache.get(key)
+    if hit is None:
+        require_cuda(weight)
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        N, C = (Cin, Cout) if transpose_flip else (Cout, Cin)
+        hit = torch.empty((9, N, C), dtype=weight.dtype, device=weight.device)
+        so, si, sy, sx = weight.stride()
+        check(load().ga_conv3x3_pack_weights(_ptr(weight), _ptr(hit), Cout, Cin, so, si, sy, sx, int(bool(transpose_flip)),
+                                             dtype_code(weight), stream_ptr()), "ga_conv3x3_pack_weights")
+        if len(_conv_pack_cache) > 512:
+            _conv_pack_cache.clear()
+        _conv_pack_cache[key] = hit
+    return hit
+
+
+def conv3x3_supported(x, weight, stride=1):
+    return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and weight.shape[2:] == (3, 3) and
+            weight.shape[1] % 32 == 0 and weight.shape[0] % 32 == 0 and stride in (1, 2))   # both ways round: backward
+
+
+def conv3x3_nhwc(x, wp, cout, stride=1, bias=None, residual=None, plan=None):
+    """x (B, Cin, H, W) channels-last, wp the [9][Cout][Cin] pack -> y (B, Cout, Ho, Wo) channels-last."""
+    require_cuda(x, wp, bias, residual)
+    x = _nhwc(x)
+    B, Cin, H, W = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    bm, bn, splits, ws_floats = plan or conv3x3_plan(B, H, W, Cin, cout, stride)
+    y = torch.empty((B, cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    ws = torch.empty(ws_floats, dtype=torch.float32, device=x.device) if splits > 1 else None
+    if residual is not None:
+        residual = _nhwc(residual)
+    _count(("conv3x3", B, Cin, H * W, stride, cout, bias is not None or residual is not None, str(x.dtype)))
+    check(load().ga_conv3x3_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(bias), _ptr(residual), B, H, W, Cin, cout,
+                                 stride, bm, bn, splits, dtype_code(x), stream_ptr()), "ga_conv3x3_nhwc")
+    return y
+
+
+class Conv3x3(torch.autograd.Function):
+    """y = conv2d(x, weight, bias=None, padding=1, stride) (+ bias + residual) on channels-last 16-bit activations.
+    Differentiable w.r.t. x (stride 1: the same kernel on the flipped / transposed pack) and the residual; the weights
+    are frozen on this path."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, stride):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise GaError("convolution weight gradients are not part of the guided-attention path (frozen UNet)")
+        wp = conv3x3_packed_weights(weight, False)
+        y = conv3x3_nhwc(x, wp, weight.shape[0], stride, bias, residual)
+        ctx.weight, ctx.stride, ctx.in_shape = weight, stride, tuple(x.shape)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        weight, stride = ctx.weight, ctx.stride
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if stride == 1:
+                gx = conv3x3_nhwc(gy, conv3x3_packed_weights(weight, True), weight.shape[1], 1)
+            else:   # the three down-sampling convolutions: library transposed convolution
+                gx = torch.nn.grad.conv2d_input(ctx.in_shape, weight, gy, stride=stride, padding=1)
+        return gx, None, None, (gy if ctx.has_res else None), None
+
+
+def conv3x3(x, weight, bias=None, residual=None, stride=1):
+    return Conv3x3.apply(x, weight, bias, residual, stride)
+
+
+conv3x3.supported = conv3x3_supported
+
+
 # --------------------------------------------------------------------------------------- tiled self-attention
 def _sub_ptr(t, elem_offset):
     return ctypes.c_void_p(t.data_ptr() + elem_offset * t.element_size())

@@ -129,7 +129,9 @@ class GuidedAttention:
             # transposes) and the fused NHWC GroupNorm(+SiLU) HIP kernels in every norm layer
             self.unet.to(memory_format=torch.channels_last)
             self.unet.set_norm_impl(ops.group_norm_act)
-            self.unet.set_fused_impl(ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm))
+            import os
+            conv = ops.conv3x3 if os.environ.get("GA_LIBRARY_CONV", "0") != "1" else None   # GA_LIBRARY_CONV=1: MIOpen
+            self.unet.set_fused_impl(ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm), conv)
             # MIOpen: time the candidate conv kernels once per shape — for the 16-bit production dtypes only.  In
             # fp32 (parity runs) the library's default choice is kept: the exhaustive search executes every
             # candidate solver, and the fp32 96x96 backward-data search was seen to abort the process once.

@@ -138,6 +138,17 @@ class GroupNormAct(nn.GroupNorm):
         return F.silu(y) if self.act else y
 
 
+def conv3x3(x, conv, impl, residual=None, with_bias=True):
+    """A 3x3 Conv2d (padding 1) of the UNet, optionally with its bias and a residual added in the same pass.  `impl` is
+    the implicit-GEMM HIP kernel (ops.conv3x3, installed by the GPU pipeline for the 16-bit dtypes) or None = the library
+    convolution (what the CPU oracle and the fp32 parity runs use)."""
+    bias = conv.bias if with_bias else None
+    if impl is not None and impl.supported(x, conv.weight, conv.stride[0]):
+        return impl(x, conv.weight, bias, residual, conv.stride[0])
+    y = F.conv2d(x, conv.weight, bias, stride=conv.stride, padding=1)
+    return y if residual is None else y + residual
+
+
 def pointwise_conv_tokens(x_tokens, conv):
     """A 1x1 Conv2d applied to a (B, HW, C) token view as ONE GEMM with the bias in its epilogue: on channels-last
     activations the token view is free, and the library GEMM beats the implicit-GEMM conv path at these sizes."""
@@ -241,14 +252,15 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
-    add_impl = None  # fused conv2-bias + residual add (ops.bias_residual_add)
+    add_impl = None   # fused conv2-bias + residual add (ops.bias_residual_add)
+    conv_impl = None  # implicit-GEMM 3x3 convolution with bias / residual epilogue (ops.conv3x3)
 
     def forward(self, x, temb_act):
         """temb_act = SiLU(time embedding), computed once per UNet forward; or the dict the UNet prepared with this
         block's time_emb_proj(temb_act) already evaluated (all blocks in one GEMM)."""
         # norm1 / norm2 carry the SiLU.  conv1's bias rides on the time projection (one add instead of two): the
         # UNet's batched projection already contains it; the stand-alone path adds it here
-        h = F.conv2d(self.norm1(x), self.conv1.weight, None, padding=1)
+        h = conv3x3(self.norm1(x), self.conv1, self.conv_impl, with_bias=False)
         if isinstance(temb_act, dict):
             tproj = temb_act[id(self)]
         else:
@@ -257,6 +269,8 @@ class ResnetBlock2D(nn.Module):
         if self.conv_shortcut is not None:
             _, _, hh, ww = x.shape
             x = tokens_to_nchw(pointwise_conv_tokens(nchw_to_tokens(x), self.conv_shortcut), hh, ww)
+        if self.conv_impl is not None and self.conv_impl.supported(h, self.conv2.weight, 1):
+            return self.conv_impl(h, self.conv2.weight, self.conv2.bias, x, 1)   # bias + skip connection in the epilogue
         if self.add_impl is not None and self.conv2.out_channels % 8 == 0:
             # conv2's bias and the skip connection in one pass (the library conv adds its bias as a separate kernel)
             return self.add_impl(F.conv2d(h, self.conv2.weight, None, padding=1), self.conv2.bias, x)
@@ -264,15 +278,19 @@ class ResnetBlock2D(nn.Module):
 
 
 class Downsample2D(nn.Module):
+    conv_impl = None
+
     def __init__(self, channels):
         super().__init__()
         self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=1)
 
     def forward(self, x):
-        return self.conv(x)
+        return conv3x3(x, self.conv, self.conv_impl)
 
 
 class Upsample2D(nn.Module):
+    conv_impl = None
+
     def __init__(self, channels):
         super().__init__()
         self.conv = nn.Conv2d(channels, channels, 3, padding=1)
@@ -282,7 +300,7 @@ class Upsample2D(nn.Module):
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         else:
             x = F.interpolate(x, size=output_size, mode="nearest")
-        return self.conv(x)
+        return conv3x3(x, self.conv, self.conv_impl)
 
 
 class DownBlock(nn.Module):
@@ -535,14 +553,17 @@ class UNet2DConditionModel(nn.Module):
             if isinstance(m, GroupNormAct):
                 m.impl = impl
 
-    def set_fused_impl(self, geglu=None, bias_residual_add=None, layer_norms=None):
+    def set_fused_impl(self, geglu=None, bias_residual_add=None, layer_norms=None, conv=None):
         """Install (or with None remove) the fused element-wise epilogues: GEGLU, conv-bias + residual, and
-        (layer_norm, add_layer_norm) for the transformer blocks."""
+        (layer_norm, add_layer_norm) for the transformer blocks; `conv` = the implicit-GEMM 3x3 convolution."""
         for m in self.modules():
+            if isinstance(m, (Downsample2D, Upsample2D)):
+                m.conv_impl = conv
             if isinstance(m, GEGLU):
                 m.impl = geglu
             elif isinstance(m, ResnetBlock2D):
                 m.add_impl = bias_residual_add
+                m.conv_impl = conv
             elif isinstance(m, BasicTransformerBlock):
                 m.ln_impl = layer_norms
 

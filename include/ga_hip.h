@@ -224,6 +224,28 @@ int ga_geglu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int F, i
 int ga_bias_residual_add(const void* y, const void* bias, const void* residual, void* out, int64_t rows, int C,
                          int dtype, ga_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * UNet host helper: 3x3 convolution, pad 1, stride 1 or 2, on channels-last activations as an implicit GEMM on MFMA
+ * (diffusers 0.12.1 ResnetBlock2D / Upsample2D / Downsample2D convolutions, run by the reference inside
+ * pipeline_guided_attention.py:583-743 through cuDNN).  16-bit types; Cin % 32 == 0, Cout % 8 == 0.
+ *   ga_conv3x3_pack_weights : W [Cout][Cin][3][3] with the given ELEMENT strides -> Wp [9][N][C] (tap-major, depth
+ *                             contiguous).  transpose_flip = 0: N = Cout, C = Cin (forward).  transpose_flip = 1:
+ *                             N = Cin, C = Cout, taps mirrored — with it the same kernel computes the backward to the
+ *                             input of a stride-1 convolution from the upstream gradient.  Once per weight version.
+ *   ga_conv3x3_plan         : tile (bm x bn) and split-K factor for a shape, and the f32 workspace it needs
+ *                             (splits * B * Ho * Wo * Cout floats, 0 when splits == 1).  Pure host function.
+ *   ga_conv3x3_nhwc         : Y [B][Ho][Wo][Cout] = conv(X [B][H][W][Cin], Wp) (+ bias[Cout]) (+ residual like Y);
+ *                             bias / residual may be NULL; Ho = (H - 1) / stride + 1.  splits > 1 runs the GEMM depth
+ *                             in `splits` slices into `workspace` and a second small launch sums them in fixed order.
+ */
+int ga_conv3x3_pack_weights(const void* W, void* Wp, int Cout, int Cin, int64_t stride_o, int64_t stride_i,
+                            int64_t stride_y, int64_t stride_x, int transpose_flip, int dtype, ga_stream_t stream);
+int ga_conv3x3_plan(int B, int H, int W, int Cin, int Cout, int stride, int* bm, int* bn, int* splits,
+                    long long* workspace_floats);
+int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* workspace, const void* bias, const void* residual,
+                    int B, int H, int W, int Cin, int Cout, int stride, int bm, int bn, int splits, int dtype,
+                    ga_stream_t stream);
+
 /* Residual add + LayerNorm (diffusers 0.12.1 BasicTransformerBlock.forward: x = attn(norm(x)) + x; norm_next(x)):
  *   fwd: x_new = a + x (rounded to T), y = LayerNorm(x_new) * gamma + beta, stats [rows][2] f32 = (mean, rstd).
  *        a == NULL: plain LayerNorm of x (x_new is not written and may be NULL).  stats may be NULL (inference).

@@ -701,3 +701,49 @@ def test_self_attention_fused_qkv_matches_separate(ops):
     (o2 * w).sum().backward()
     assert torch.equal(o, o2)
     assert torch.equal(qkv.grad, torch.cat([q.grad, k.grad, v.grad], dim=-1))
+
+
+# ------------------------------------------------------------------------------------- 3x3 convolution (implicit GEMM)
+CONV_SHAPES = [  # B, Cin, Cout, H, W, stride
+    (1, 64, 64, 16, 16, 1), (2, 96, 96, 9, 7, 1), (1, 320, 320, 32, 32, 1), (1, 640, 320, 16, 16, 1), (3, 64, 128, 20, 12, 1),
+    (1, 64, 64, 16, 16, 2), (2, 96, 64, 9, 7, 2), (1, 1280, 1280, 8, 8, 1), (1, 32, 32, 5, 5, 1),
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", CONV_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_conv3x3_implicit_gemm(ops, shape, dt):
+    """ga_conv3x3_nhwc (every tile / split-K plan) and its autograd wrapper against torch's conv2d in fp64 on the CPU:
+    forward with bias + residual, backward to the input (stride 1: the same kernel on the flipped, transposed pack)."""
+    B, Cin, Cout, H, W, stride = shape
+    x = dev(hashrand.normalish((B, Cin, H, W), 61 + Cin), DT[dt]).contiguous(memory_format=torch.channels_last)
+    w = dev(hashrand.normalish((Cout, Cin, 3, 3), 62 + Cout) * (1.0 / math.sqrt(9 * Cin)), DT[dt])
+    bias = dev(hashrand.normalish((Cout,), 63) * 0.3, DT[dt])
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = dev(hashrand.normalish((B, Cout, Ho, Wo), 64), DT[dt]).contiguous(memory_format=torch.channels_last)
+    gy = dev(hashrand.normalish((B, Cout, Ho, Wo), 65), DT[dt]).contiguous(memory_format=torch.channels_last)
+    xr = x.double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, w.double().cpu(), bias.double().cpu(), stride=stride, padding=1) + res.double().cpu()
+    yr.backward(gy.double().cpu())
+    y_plain = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None, stride=stride, padding=1)
+    tol = TOL[dt] * 2
+    wp = ops.conv3x3_packed_weights(w, False)
+    steps = 9 * Cin // 32
+    for bm, bn in ((128, 128), (128, 64), (64, 64)):
+        for splits in (1, 2, 4, 16):
+            if splits > steps:
+                continue
+            ws = splits * B * Ho * Wo * Cout if splits > 1 else 0
+            y = ops.conv3x3_nhwc(x, wp, Cout, stride, bias, res, plan=(bm, bn, splits, ws))
+            assert y.shape == (B, Cout, Ho, Wo) and y.is_contiguous(memory_format=torch.channels_last)
+            close(y, yr.detach().numpy(), tol, f"y tile {bm}x{bn} splits {splits}")
+            y0 = ops.conv3x3_nhwc(x, wp, Cout, stride, None, None, plan=(bm, bn, splits, ws))
+            close(y0, y_plain.numpy(), tol, f"plain y tile {bm}x{bn} splits {splits}")
+    # autograd wrapper with the planner's own choice; weights in channels-last strides too (what the UNet holds)
+    xa, ra = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    ya = ops.conv3x3(xa, w.contiguous(memory_format=torch.channels_last), bias, ra, stride)
+    close(ya, yr.detach().numpy(), tol, "autograd forward")
+    ya.backward(gy)
+    close(xa.grad, xr.grad.numpy(), tol * 2, "dx")
+    assert torch.equal(ra.grad, gy)
+    assert not ops.conv3x3_supported(x.float(), w.float(), stride)      # fp32 stays on the library path

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Per-shape time of the UNet's 3x3 convolutions: the library (MIOpen, benchmark mode, channels-last fp16) against
+ga_conv3x3_nhwc for every (tile, split-K) plan — forward; the stride-1 backward-to-input is the same kernel with
+Cin / Cout swapped, listed as its own shape.  hipGraph replay timing.  Prints a table and a JSON line."""
+import json
+import sys
+from pathlib import Path
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from guided_attention_amd import ops  # noqa: E402
+
+torch.backends.cudnn.benchmark = True
+BASE = [  # (Cin, Cout, H, stride)
+    (320, 320, 64, 1), (640, 320, 64, 1), (960, 320, 64, 1), (320, 640, 64, 1), (320, 960, 64, 1), (320, 320, 64, 2), (640, 640, 64, 1),
+    (320, 640, 32, 1), (640, 640, 32, 1), (1280, 640, 32, 1), (1920, 640, 32, 1), (960, 640, 32, 1), (640, 1280, 32, 1),
+    (640, 1920, 32, 1), (640, 960, 32, 1), (640, 640, 32, 2), (1280, 1280, 32, 1),
+    (640, 1280, 16, 1), (1280, 1280, 16, 1), (2560, 1280, 16, 1), (1920, 1280, 16, 1), (1280, 2560, 16, 1), (1280, 1920, 16, 1),
+    (1280, 1280, 16, 2), (1280, 1280, 8, 1), (2560, 1280, 8, 1), (1280, 2560, 8, 1),
+]
+
+
+def replay_us(fn, iters=20):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn()
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        s.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(3):
+            g.replay()
+        e1.record(s)
+        e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (3 * iters)
+
+
+def bind(path):
+    import ctypes
+    lib = ctypes.CDLL(str(path))
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    lib.ga_conv3x3_pack_weights.argtypes = [vp, vp, i32, i32, i64, i64, i64, i64, i32, i32, vp]
+    lib.ga_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 10 + [vp]
+    return lib
+
+
+def variant_times(lib, x, w, co, st, plans):
+    """{plan: us} for one extra build of conv3x3.hip (tools/micro/sa_variants/libconv_*.so), same inputs."""
+    import ctypes
+    B, ci, h, _ = x.shape
+    ho = (h - 1) // st + 1
+    wp = torch.empty(9, co, ci, device="cuda", dtype=x.dtype)
+    sp_ = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    so, si, sy, sx = w.stride()
+    assert lib.ga_conv3x3_pack_weights(P(w), P(wp), co, ci, so, si, sy, sx, 0, 0, sp_()) == 0
+    y = torch.empty(B, co, ho, ho, device="cuda", dtype=x.dtype).contiguous(memory_format=torch.channels_last)
+    out = {}
+    for (bm, bn, sp) in plans:
+        ws = torch.empty(sp * B * ho * ho * co, device="cuda", dtype=torch.float32) if sp > 1 else None
+
+        def call():
+            rc = lib.ga_conv3x3_nhwc(P(x), P(wp), P(y), P(ws), None, None, B, h, h, ci, co, st, bm, bn, sp, 0, sp_())
+            assert rc == 0, rc
+        out[(bm, bn, sp)] = replay_us(call, iters=10)
+    return out
+
+
+def main():
+    batches = [int(b) for b in (sys.argv[1] if len(sys.argv) > 1 else "1,3").split(",")]
+    vdir = Path(__file__).resolve().parent / "micro" / "sa_variants"
+    variants = {p.stem[3:]: bind(p) for p in sorted(vdir.glob("libconv_*.so"))} if "variants" in sys.argv else {}
+    table = {}
+    print(f"{'B':>2} {'Cin':>5} {'Cout':>5} {'HW':>3} {'s':>1} {'lib us':>8} {'TF/s':>6} | {'best plan':>14} {'us':>8} {'TF/s':>6} {'x':>5} | heuristic")
+    for B in batches:
+        for ci, co, h, st in BASE:
+            x = torch.randn(B, ci, h, h, device="cuda", dtype=torch.half).contiguous(memory_format=torch.channels_last)
+            w = (torch.randn(co, ci, 3, 3, device="cuda", dtype=torch.half) * 0.02).contiguous(memory_format=torch.channels_last)
+            ho = (h - 1) // st + 1
+            flop = 2.0 * B * ho * ho * co * ci * 9
+            t_lib = replay_us(lambda: F.conv2d(x, w, None, stride=st, padding=1))
+            wp = ops.conv3x3_packed_weights(w, False)
+            steps = 9 * ci // 64
+            res = {}
+            for bm, bn in ((128, 128), (128, 64), (64, 64)):
+                for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+                    if steps // sp < 3:
+                        continue
+                    tiles = -(-B * ho * ho // bm) * -(-co // bn)
+                    if tiles * sp > 4096 or (tiles * sp < 96 and sp < 16):
+                        continue
+                    ws = sp * B * ho * ho * co if sp > 1 else 0
+                    plan = (bm, bn, sp, ws)
+                    res[(bm, bn, sp)] = replay_us(lambda: ops.conv3x3_nhwc(x, wp, co, st, None, None, plan=plan), iters=10)
+            best = min(res, key=res.get)
+            extra = ""
+            for vname, vlib in variants.items():
+                vt = variant_times(vlib, x, w, co, st, [k for k in res if (9 * ci // 64) // k[2] >= 3])
+                vb = min(vt, key=vt.get)
+                extra += f" | {vname} {vb} {vt[vb]:.1f}"
+            heur = ops.conv3x3_plan(B, h, h, ci, co, st)[:3]
+            t_h = res.get(tuple(heur))
+            print(f"{B:>2} {ci:>5} {co:>5} {h:>3} {st:>1} {t_lib:8.1f} {flop / t_lib / 1e6:6.0f} | {str(best):>14} {res[best]:8.1f} "
+                  f"{flop / res[best] / 1e6:6.0f} {t_lib / res[best]:5.2f} | {heur} {t_h if t_h is None else round(t_h, 1)}{extra}", flush=True)
+            table[f"{B},{ci},{co},{h},{st}"] = {"lib_us": round(t_lib, 1), "best": list(best), "best_us": round(res[best], 1),
+                                                "all": {f"{k[0]}x{k[1]}x{k[2]}": round(v, 1) for k, v in res.items()}}
+    print(json.dumps(table))
+
+
+if __name__ == "__main__":
+    main()
