@@ -232,6 +232,8 @@ def kernel_work(key):
         return "hbm", esz * B * D * (4 if flag else 2)
     if kind == "add_layer_norm_bwd":                 # row, dy (, g_res) in; dx out
         return "hbm", esz * B * D * (4 if flag else 3)
+    if kind == "conv3x3":                            # B, H = Cin, N = H*W, Kt = stride, D = Cout: 2 * M * 9 Cin * Cout
+        return "mfma", 2.0 * B * (N // (Kt * Kt)) * 9 * H * D
     if kind.startswith("group_norm"):
         elems = B * N * D  # here H = groups, N = pixels, D = channels
         return "hbm", esz * elems * (2 if kind == "group_norm_fwd" else 3)

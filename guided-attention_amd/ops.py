@@ -66,7 +66,24 @@ def replay_launch_us(key, iters=100):
     dtype = {"torch.float16": torch.float16, "torch.bfloat16": torch.bfloat16, "torch.float32": torch.float32}[dt]
     dev = torch.device("cuda", torch.cuda.current_device())
     lib = load()
-    if kind in ("geglu_fwd", "geglu_bwd", "bias_residual_add", "add_layer_norm_fwd", "add_layer_norm_bwd"):
+    if kind == "conv3x3":          # key = (kind, B, Cin, H*W, stride, Cout, epilogue?, dtype); the UNet's maps are square
+        cin, hw, stride, cout = H, N, Kt, D
+        side_len = int(round(hw ** 0.5))
+        x = torch.randn(B, cin, side_len, hw // side_len, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
+        wp = torch.randn(9, cout, cin, device=dev, dtype=dtype) * (9 * cin) ** -0.5
+        ho, wo = (side_len - 1) // stride + 1, (hw // side_len - 1) // stride + 1
+        bias = torch.randn(cout, device=dev, dtype=dtype) if flag else None
+        res = (torch.randn(B, cout, ho, wo, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
+               if flag else None)
+        bm, bn, splits, ws_floats = conv3x3_plan(B, side_len, hw // side_len, cin, cout, stride)
+        y = torch.empty(B, cout, ho, wo, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
+        ws = torch.empty(max(1, ws_floats), device=dev, dtype=torch.float32)
+        code = dtype_code(x)
+
+        def fn():
+            check(lib.ga_conv3x3_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(bias), _ptr(res), B, side_len,
+                                      hw // side_len, cin, cout, stride, bm, bn, splits, code, stream_ptr()), "replay conv")
+    elif kind in ("geglu_fwd", "geglu_bwd", "bias_residual_add", "add_layer_norm_fwd", "add_layer_norm_bwd"):
         rows, C = B, D
         code = dtype_code(torch.empty(0, dtype=dtype))
         t = lambda *shape: torch.randn(*shape, device=dev, dtype=dtype)  # noqa: E731
@@ -769,9 +786,12 @@ def conv3x3_packed_weights(weight, transpose_flip):
     return hit
 
 
+CONV_KC = 64   # channels per k-step of ga_conv3x3_nhwc (kKC in csrc/conv3x3.hip): Cin must be a multiple
+
+
 def conv3x3_supported(x, weight, stride=1):
     return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and weight.shape[2:] == (3, 3) and
-            weight.shape[1] % 32 == 0 and weight.shape[0] % 32 == 0 and stride in (1, 2))   # both ways round: backward
+            weight.shape[1] % CONV_KC == 0 and weight.shape[0] % CONV_KC == 0 and stride in (1, 2))   # both ways round: backward
 
 
 def conv3x3_nhwc(x, wp, cout, stride=1, bias=None, residual=None, plan=None):

@@ -227,7 +227,8 @@ int ga_bias_residual_add(const void* y, const void* bias, const void* residual, 
 /* ---------------------------------------------------------------------------------------------
  * UNet host helper: 3x3 convolution, pad 1, stride 1 or 2, on channels-last activations as an implicit GEMM on MFMA
  * (diffusers 0.12.1 ResnetBlock2D / Upsample2D / Downsample2D convolutions, run by the reference inside
- * pipeline_guided_attention.py:583-743 through cuDNN).  16-bit types; Cin % 32 == 0, Cout % 8 == 0.
+ * pipeline_guided_attention.py:583-743 through cuDNN).  16-bit types; Cin % 64 == 0 (one k-step = 64 channels of one
+ * tap), Cout % 8 == 0; anything else returns GA_ERR_SHAPE.
  *   ga_conv3x3_pack_weights : W [Cout][Cin][3][3] with the given ELEMENT strides -> Wp [9][N][C] (tap-major, depth
  *                             contiguous).  transpose_flip = 0: N = Cout, C = Cin (forward).  transpose_flip = 1:
  *                             N = Cin, C = Cout, taps mirrored — with it the same kernel computes the backward to the

@@ -705,8 +705,8 @@ def test_self_attention_fused_qkv_matches_separate(ops):
 
 # ------------------------------------------------------------------------------------- 3x3 convolution (implicit GEMM)
 CONV_SHAPES = [  # B, Cin, Cout, H, W, stride
-    (1, 64, 64, 16, 16, 1), (2, 96, 96, 9, 7, 1), (1, 320, 320, 32, 32, 1), (1, 640, 320, 16, 16, 1), (3, 64, 128, 20, 12, 1),
-    (1, 64, 64, 16, 16, 2), (2, 96, 64, 9, 7, 2), (1, 1280, 1280, 8, 8, 1), (1, 32, 32, 5, 5, 1),
+    (1, 64, 64, 16, 16, 1), (2, 192, 192, 9, 7, 1), (1, 320, 320, 32, 32, 1), (1, 640, 320, 16, 16, 1), (3, 64, 128, 20, 12, 1),
+    (1, 64, 64, 16, 16, 2), (2, 192, 64, 9, 7, 2), (1, 1280, 1280, 8, 8, 1), (1, 128, 64, 5, 5, 1),
 ]
 
 
@@ -728,7 +728,7 @@ def test_conv3x3_implicit_gemm(ops, shape, dt):
     y_plain = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None, stride=stride, padding=1)
     tol = TOL[dt] * 2
     wp = ops.conv3x3_packed_weights(w, False)
-    steps = 9 * Cin // 32
+    steps = 9 * Cin // ops.CONV_KC
     for bm, bn in ((128, 128), (128, 64), (64, 64)):
         for splits in (1, 2, 4, 16):
             if splits > steps:

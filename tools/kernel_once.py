@@ -3,6 +3,7 @@
   kernel_once.py sa_fwd|sa_bwd B H N D [dtype]        self-attention forward / backward (needs a forward first)
   kernel_once.py cap_fwd|cap_bwd B H N D [dtype]      cross-attention capture (Kt = 77; fwd stores P)
   kernel_once.py gn_fwd|gn_bwd B C HW [dtype]         GroupNorm(+SiLU), 32 groups, channels-last
+  kernel_once.py conv B Cin HW stride Cout [dtype]    3x3 implicit-GEMM convolution with bias + residual, the planner's tile
 Inputs are resident in HBM before the launches; 5 launches each."""
 import sys
 from pathlib import Path
@@ -48,6 +49,18 @@ elif kind.startswith("gn_"):
         y = ops.group_norm_act(x, w, b_, 32, 1e-5, True)
         if kind == "gn_bwd":
             y.backward(g)
+elif kind == "conv":
+    B, cin, HW, stride, cout = nums
+    side = int(round(HW ** 0.5))
+    x = torch.randn(B, cin, side, HW // side, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, device=dev, dtype=dt) * (9 * cin) ** -0.5).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(cout, device=dev, dtype=dt)
+    ho = (side - 1) // stride + 1
+    res = torch.randn(B, cout, ho, (HW // side - 1) // stride + 1, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
+    wp = ops.conv3x3_packed_weights(w, False)
+    torch.cuda.synchronize()
+    for _ in range(reps):
+        ops.conv3x3_nhwc(x, wp, cout, stride, bias, res)
 else:
     raise SystemExit(f"unknown kernel kind {kind}")
 torch.cuda.synchronize()
