@@ -58,11 +58,14 @@ struct ConvArgs {
   int M;            // B * Ho * Wo
   int steps;        // k-steps in all: 9 * Cin / 32
   int steps_per;    // k-steps per split
+  int tm, tn;       // m tiles, n tiles of the launch (grid = tm * tn * splits workgroups, one dimension)
+  int n_fastest;    // workgroup order inside an XCD's run: n tiles fastest (1) or m tiles fastest (0)
+  unsigned x_bytes, w_bytes;   // sizes of X and Wp (buffer descriptors: loads beyond them return zeros); < 2 GiB
 };
 
 // OUT_F32 = true: this workgroup's split writes its raw f32 partial tile to part[split][m][n] (no bias / residual).
 template <typename T, int BM, int BN, bool OUT_F32>
-__global__ __launch_bounds__(kThreads) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Wp,
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Wp,
                                                            T* __restrict__ Y, float* __restrict__ part,
                                                            const T* __restrict__ bias, const T* __restrict__ residual,
                                                            ConvArgs a) {
@@ -78,45 +81,82 @@ __global__ __launch_bounds__(kThreads) void conv3x3_kernel(const T* __restrict__
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, split = blockIdx.z;
+  // Workgroup -> (m tile, n tile, k split), XCD-aware.  The hardware deals consecutive workgroup ids round-robin over the
+  // 8 XCDs (ids b and b + 8 share an L2).  The workgroups that read the same weight slice Wp[taps of split][n tile] are
+  // its tm m-tiles: give each XCD one contiguous run of the m-fastest order, so a weight slice is fetched into ONE L2
+  // instead of up to 8 (the 1280-channel layers otherwise re-read their 29.5 MB of weights once per m tile: 7x the
+  // algorithmic bytes at the fabric counters).  Bijective for any grid size; placement is a speed matter only.
+  int m0, n0, split;
+  {
+    const int total = gridDim.x, q = total >> 3, r = total & 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    if (a.n_fastest) {   // activations outweigh the weights (64x64 level): an XCD keeps an m tile's pixels, sweeps the n tiles
+      const int nt = logical % a.tn, rest = logical / a.tn;
+      n0 = nt * BN;
+      m0 = (rest % a.tm) * BM;
+      split = rest / a.tm;
+    } else {
+      const int mt = logical % a.tm, rest = logical / a.tm;
+      m0 = mt * BM;
+      n0 = (rest % a.tn) * BN;
+      split = rest / a.tn;
+    }
+  }
   const int it0 = split * a.steps_per, it1 = min(a.steps, it0 + a.steps_per);
   const int cchunks = a.Cin / kKC;
 
-  // ---- staging assignment: thread -> (row = tid / 4 (+ 64 per pass), 16-byte piece q = tid % 4 of the 64-byte slice)
+  // ---- staging assignment: thread -> (row = tid / QP (+ RPP per pass), 16-byte piece sq of the row's 128-byte slice).
+  // Loads are raw buffer loads with a 32-bit byte offset per lane: a lane whose pixel falls outside the image (or whose
+  // row is beyond M / Cout) carries an offset of 2 GiB, past the descriptor's size, and the hardware returns zeros —
+  // no branch around a load, no zero-initialised destination (either one makes the compiler drain every load in
+  // flight before the next group is issued, which would undo the look-ahead below).
+  constexpr unsigned kOob = 0x80000000u;
   const int srow = tid / QP, sq = tid % QP;
-  int a_iy[PA], a_ix[PA];        // top-left input pixel of the 3x3 window (may be -1)
-  long long a_base[PA];          // element offset of pixel (iy, ix) channel 0 (only used when in bounds)
-  bool a_ok[PA];
+  int a_iy[PA], a_ix[PA];        // top-left input pixel of the 3x3 window (may be -1); iy = -4 marks a row beyond M
+  int a_off[PA];                 // byte offset of (pixel (iy, ix), channel 8 * sq) — may be negative, only used in bounds
 #pragma unroll
   for (int p = 0; p < PA; ++p) {
     const int m = m0 + srow + RPP * p;
-    a_ok[p] = m < a.M;
-    const int mm = a_ok[p] ? m : 0;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
     const int b = mm / (a.Ho * a.Wo), rem = mm - b * (a.Ho * a.Wo);
     const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-    a_iy[p] = oy * a.stride - 1;
+    a_iy[p] = ok ? oy * a.stride - 1 : -4;
     a_ix[p] = ox * a.stride - 1;
-    a_base[p] = (((long long)b * a.H + a_iy[p]) * a.W + a_ix[p]) * a.Cin;
+    a_off[p] = (((b * a.H + a_iy[p]) * a.W + a_ix[p]) * a.Cin + 8 * sq) * (int)sizeof(T);
   }
-  uint4 ra[PA], rb[PB];
-  auto load_step = [&](int it) {
+  unsigned b_off[PB];            // byte offset of (row n, channel 8 * sq) inside one tap's [Cout][Cin] slab, or kOob
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int n = n0 + srow + RPP * p;
+    b_off[p] = n < a.Cout ? (unsigned)((n * a.Cin + 8 * sq) * (int)sizeof(T)) : kOob;
+  }
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wp), 0, a.w_bytes, 0x00020000);
+  // Two register sets: the loads of k-step it + 2 are issued before the MFMAs of step it and only waited for one
+  // whole step later (the compiler's counted vmcnt leaves the younger set in flight).  One step of look-ahead left
+  // every step waiting out a full memory round trip (1.1 - 1.6 us per step against 0.1 - 0.2 us of MFMAs).
+  uint4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+  auto load_step = [&](int it, uint4 (&ra)[PA], uint4 (&rb)[PB]) {
     const int tap = it / cchunks, c0 = (it - tap * cchunks) * kKC;
     const int ky = tap / 3, kx = tap - 3 * ky;
+    const int a_step = ((ky * a.W + kx) * a.Cin + c0) * (int)sizeof(T);              // wave-uniform
+    const unsigned b_step = (unsigned)((tap * a.Cout * a.Cin + c0) * (int)sizeof(T));  // wave-uniform; kOob + it stays >= 2 GiB
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      const int iy = a_iy[p] + ky, ix = a_ix[p] + kx;
-      ra[p] = uint4{0, 0, 0, 0};
-      if (a_ok[p] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-        ra[p] = *reinterpret_cast<const uint4*>(X + a_base[p] + ((long long)ky * a.W + kx) * a.Cin + c0 + 8 * sq);
+      const bool in = (unsigned)(a_iy[p] + ky) < (unsigned)a.H && (unsigned)(a_ix[p] + kx) < (unsigned)a.W;
+      const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, in ? (unsigned)(a_off[p] + a_step) : kOob, 0, 0);
+      ra[p] = uint4{x[0], x[1], x[2], x[3]};
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-      const int n = n0 + srow + RPP * p;
-      rb[p] = uint4{0, 0, 0, 0};
-      if (n < a.Cout) rb[p] = *reinterpret_cast<const uint4*>(Wp + ((long long)tap * a.Cout + n) * a.Cin + c0 + 8 * sq);
+      const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[p] + b_step, 0, 0);
+      rb[p] = uint4{x[0], x[1], x[2], x[3]};
     }
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, const uint4 (&ra)[PA], const uint4 (&rb)[PB]) {
     T* As = lds + buf * kTile;
     T* Bs = As + BM * kLD;
 #pragma unroll
@@ -134,14 +174,7 @@ __global__ __launch_bounds__(kThreads) void conv3x3_kernel(const T* __restrict__
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5;   // fragment row inside a 32-block, k half
-  if (it0 < it1) {
-    load_step(it0);
-    store_step(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int it = it0; it < it1; ++it) {
-    if (it + 1 < it1) load_step(it + 1);   // global loads in flight under this step's MFMAs
+  auto mma_step = [&](int buf) {
     const T* As = lds + buf * kTile;
     const T* Bs = As + BM * kLD;
 #pragma unroll
@@ -162,9 +195,29 @@ __global__ __launch_bounds__(kThreads) void conv3x3_kernel(const T* __restrict__
       __builtin_amdgcn_s_setprio(0);
 #endif
     }
-    if (it + 1 < it1) store_step(buf ^ 1);
+  };
+  // Straight-line loop body: every load group is issued unconditionally (beyond the last step the index is clamped:
+  // the set is loaded again and never used) — a branch around a load group makes the compiler assume at the merge that
+  // nothing younger is in flight and wait for vmcnt(0) where a counted wait would leave the next set's loads running.
+  const int last = it1 - 1;
+  if (it0 < it1) {
+    load_step(it0, ra0, rb0);
+    load_step(min(it0 + 1, last), ra1, rb1);
+    store_step(0, ra0, rb0);
+  }
+  __syncthreads();
+  for (int it = it0; it < it1; it += 2) {
+    // even step: LDS buffer 0 holds step it, set 1 holds step it + 1 (in flight), set 0 is free
+    load_step(min(it + 2, last), ra0, rb0);
+    mma_step(0);
+    store_step(1, ra1, rb1);
     __syncthreads();
-    buf ^= 1;
+    if (it + 1 >= it1) break;
+    // odd step: buffer 1 holds step it + 1, set 0 holds step it + 2 (in flight), set 1 is free
+    load_step(min(it + 3, last), ra1, rb1);
+    mma_step(1);
+    store_step(0, ra0, rb0);
+    __syncthreads();
   }
 
   // ---- epilogue.  acc[j][i][r]: output channel n = n0 + wn*WN + j*32 + (r & 3) + 8 * (r >> 2) + 4 * fh,
@@ -306,9 +359,17 @@ Plan choose_plan(int M, int N, int steps) {
 }
 
 template <typename T, int BM, int BN>
-int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T* residual, const ConvArgs& a, int splits,
+int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T* residual, const ConvArgs& a_in, int splits,
                 hipStream_t s) {
-  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, splits);
+  ConvArgs a = a_in;
+  a.tm = (a.M + BM - 1) / BM;
+  a.tn = (a.Cout + BN - 1) / BN;
+  {  // bytes that reach the fabric if each XCD fetches what its run of workgroups shares once
+    const double xb = (double)a.B * a.H * a.W * a.Cin, wb = 9.0 * a.Cin * a.Cout;
+    const double m_first = wb + xb * (a.tn * splits < 8 ? a.tn * splits : 8), n_first = xb + wb * (a.tm < 8 ? a.tm : 8);
+    a.n_fastest = n_first < m_first ? 1 : 0;
+  }
+  dim3 grid((unsigned)(a.tm * a.tn * splits));
   if (splits == 1) {
     hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, false>), grid, dim3(kThreads), 0, s, X, Wp, Y, (float*)nullptr, bias,
                        residual, a);
@@ -391,6 +452,10 @@ extern "C" int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* wo
   a.Ho = (H - 1) / stride + 1;
   a.Wo = (W - 1) / stride + 1;
   a.M = B * a.Ho * a.Wo;
+  const long long xb = (long long)B * H * W * Cin * 2, wb = 9LL * Cin * Cout * 2;
+  if (xb >= (1LL << 31) || wb >= (1LL << 31) || (long long)a.M * Cout >= (1LL << 31)) return GA_ERR_SHAPE;   // 32-bit byte offsets
+  a.x_bytes = (unsigned)xb;
+  a.w_bytes = (unsigned)wb;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case GA_F16: return conv_t<_Float16>(X, Wp, Y, workspace, bias, residual, a, bm, bn, splits, s);

@@ -3,6 +3,7 @@
 the pipeline differentiates (reference: pipeline_guided_attention.py:466 autograd.grad(loss, latents)).
 """
 import ctypes
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -770,8 +771,11 @@ def conv3x3_plan(B, H, W, Cin, Cout, stride):
 
 def conv3x3_packed_weights(weight, transpose_flip):
     """[9][N][C] pack of a (Cout, Cin, 3, 3) weight (any strides), cached per (storage, version)."""
-    key = (weight.data_ptr(), weight._version, weight.dtype, bool(transpose_flip), tuple(weight.stride()))
-    hit = _conv_pack_cache.get(key)
+    key = (weight.data_ptr(), weight._version, weight.dtype, bool(transpose_flip), tuple(weight.stride()), tuple(weight.shape))
+    entry = _conv_pack_cache.get(key)
+    # the entry is only good for the tensor object it was made from: a freed weight's address can be handed to another
+    # tensor of the same shape with other contents (tests do that; the UNet's frozen parameters never move)
+    hit = entry[1] if entry is not None and entry[0]() is weight else None
     if hit is None:
         require_cuda(weight)
         Cout, Cin = weight.shape[0], weight.shape[1]
@@ -782,7 +786,7 @@ def conv3x3_packed_weights(weight, transpose_flip):
                                              dtype_code(weight), stream_ptr()), "ga_conv3x3_pack_weights")
         if len(_conv_pack_cache) > 512:
             _conv_pack_cache.clear()
-        _conv_pack_cache[key] = hit
+        _conv_pack_cache[key] = (weakref.ref(weight), hit)
     return hit
 
 
