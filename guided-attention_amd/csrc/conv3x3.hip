@@ -60,6 +60,7 @@ struct ConvArgs {
   int steps_per;    // k-steps per split
   int tm, tn;       // m tiles, n tiles of the launch (grid = tm * tn * splits workgroups, one dimension)
   int n_fastest;    // workgroup order inside an XCD's run: n tiles fastest (1) or m tiles fastest (0)
+  int pad;          // 1: 3x3 taps around the pixel; 0: a single tap (plain GEMM  Y[m][n] = sum_c X[m][c] W[n][c])
   unsigned x_bytes, w_bytes;   // sizes of X and Wp (buffer descriptors: loads beyond them return zeros); < 2 GiB
 };
 
@@ -122,8 +123,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
     const int mm = ok ? m : 0;
     const int b = mm / (a.Ho * a.Wo), rem = mm - b * (a.Ho * a.Wo);
     const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-    a_iy[p] = ok ? oy * a.stride - 1 : -4;
-    a_ix[p] = ox * a.stride - 1;
+    a_iy[p] = ok ? oy * a.stride - a.pad : -4;
+    a_ix[p] = ox * a.stride - a.pad;
     a_off[p] = (((b * a.H + a_iy[p]) * a.W + a_ix[p]) * a.Cin + 8 * sq) * (int)sizeof(T);
   }
   unsigned b_off[PB];            // byte offset of (row n, channel 8 * sq) inside one tap's [Cout][Cin] slab, or kOob
@@ -275,33 +276,39 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
   }
 }
 
-// split-K epilogue: Y[m][n] = sum_s part[s][m][n] (+ bias[n] + R[m][n]), fixed summation order; 8 channels per thread
-template <typename T>
+// split-K epilogue: Y[m][n] = sum_s part[s][m][n] (+ bias[n] + R[m][n]), fixed summation order s = 0, 1, ...; 4 channels
+// per thread.  S > 0: the split count is a compile-time constant and every slab's load is issued before the first add
+// (the runtime-count loop waited out one memory round trip per slab); S = 0: generic loop.
+template <typename T, int S>
 __global__ __launch_bounds__(kThreads) void conv_splitk_sum_kernel(const float* __restrict__ part, int splits, T* __restrict__ Y,
                                                                    const T* __restrict__ bias,
                                                                    const T* __restrict__ residual, long long MN, int Cout) {
-  const long long v = ((long long)blockIdx.x * kThreads + threadIdx.x) * 8;
+  const long long v = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4;
   if (v >= MN) return;
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int sp = 0; sp < splits; ++sp) {
-    const f32x4 p0 = *reinterpret_cast<const f32x4*>(part + (size_t)sp * MN + v);
-    const f32x4 p1 = *reinterpret_cast<const f32x4*>(part + (size_t)sp * MN + v + 4);
+  f32x4 acc;
+  if constexpr (S > 0) {
+    f32x4 p[S];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      s[k] += p0[k];
-      s[4 + k] += p1[k];
-    }
+    for (int sp = 0; sp < S; ++sp) p[sp] = *reinterpret_cast<const f32x4*>(part + (size_t)sp * MN + v);
+    acc = p[0];
+#pragma unroll
+    for (int sp = 1; sp < S; ++sp) acc += p[sp];
+  } else {
+    acc = *reinterpret_cast<const f32x4*>(part + v);
+    for (int sp = 1; sp < splits; ++sp) acc += *reinterpret_cast<const f32x4*>(part + (size_t)sp * MN + v);
   }
   const int n = (int)(v % Cout);
-  uint4 bv = uint4{0, 0, 0, 0}, rv = uint4{0, 0, 0, 0}, out;
-  if (bias != nullptr) bv = *reinterpret_cast<const uint4*>(bias + n);
-  if (residual != nullptr) rv = *reinterpret_cast<const uint4*>(residual + v);
-  const T* be = reinterpret_cast<const T*>(&bv);
-  const T* re = reinterpret_cast<const T*>(&rv);
-  T* oe = reinterpret_cast<T*>(&out);
+  typename Traits<T>::frag bv, rv, out;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) oe[k] = Traits<T>::from_f32(s[k] + Traits<T>::to_f32(be[k]) + Traits<T>::to_f32(re[k]));
-  *reinterpret_cast<uint4*>(Y + v) = out;
+  for (int k = 0; k < 4; ++k) {
+    bv[k] = Traits<T>::from_f32(0.f);
+    rv[k] = Traits<T>::from_f32(0.f);
+  }
+  if (bias != nullptr) bv = load_frag<T>(bias + n);
+  if (residual != nullptr) rv = load_frag<T>(residual + v);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[k] = Traits<T>::from_f32(acc[k] + Traits<T>::to_f32(bv[k]) + Traits<T>::to_f32(rv[k]));
+  store_frag<T>(Y + v, out);
 }
 
 // pre-pack: W [Cout][Cin][3][3] in whatever strides the framework holds (element strides given) ->
@@ -365,7 +372,7 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T
   a.tm = (a.M + BM - 1) / BM;
   a.tn = (a.Cout + BN - 1) / BN;
   {  // bytes that reach the fabric if each XCD fetches what its run of workgroups shares once
-    const double xb = (double)a.B * a.H * a.W * a.Cin, wb = 9.0 * a.Cin * a.Cout;
+    const double xb = (double)a.B * a.H * a.W * a.Cin, wb = (a.pad ? 9.0 : 1.0) * a.Cin * a.Cout;
     const double m_first = wb + xb * (a.tn * splits < 8 ? a.tn * splits : 8), n_first = xb + wb * (a.tm < 8 ? a.tm : 8);
     a.n_fastest = n_first < m_first ? 1 : 0;
   }
@@ -377,8 +384,19 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T
     hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, true>), grid, dim3(kThreads), 0, s, X, Wp, (T*)nullptr, ws, (const T*)nullptr,
                        (const T*)nullptr, a);
     const long long MN = (long long)a.M * a.Cout;
-    hipLaunchKernelGGL(conv_splitk_sum_kernel<T>, dim3((unsigned)((MN / 8 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                       (const float*)ws, splits, Y, bias, residual, MN, a.Cout);
+    const dim3 sgrid((unsigned)((MN / 4 + kThreads - 1) / kThreads));
+#define GA_SUM_CASE(S)                                                                                                 \
+  case S:                                                                                                              \
+    hipLaunchKernelGGL((conv_splitk_sum_kernel<T, S>), sgrid, dim3(kThreads), 0, s, (const float*)ws, splits, Y, bias,   \
+                       residual, MN, a.Cout);                                                                          \
+    break;
+    switch (splits) {
+      GA_SUM_CASE(2) GA_SUM_CASE(3) GA_SUM_CASE(4) GA_SUM_CASE(6) GA_SUM_CASE(8) GA_SUM_CASE(12) GA_SUM_CASE(16)
+      default:
+        hipLaunchKernelGGL((conv_splitk_sum_kernel<T, 0>), sgrid, dim3(kThreads), 0, s, (const float*)ws, splits, Y, bias,
+                           residual, MN, a.Cout);
+    }
+#undef GA_SUM_CASE
   }
   return check_launch();
 }
@@ -386,7 +404,7 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T
 template <typename T>
 int conv_t(const void* X, const void* Wp, void* Y, float* ws, const void* bias, const void* residual, ConvArgs a, int bm,
            int bn, int splits, hipStream_t s) {
-  a.steps = 9 * a.Cin / kKC;
+  a.steps = (a.pad ? 9 : 1) * a.Cin / kKC;
   a.steps_per = (a.steps + splits - 1) / splits;
   const T* x = (const T*)X;
   const T* w = (const T*)Wp;
@@ -452,6 +470,7 @@ extern "C" int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* wo
   a.Ho = (H - 1) / stride + 1;
   a.Wo = (W - 1) / stride + 1;
   a.M = B * a.Ho * a.Wo;
+  a.pad = 1;
   const long long xb = (long long)B * H * W * Cin * 2, wb = 9LL * Cin * Cout * 2;
   if (xb >= (1LL << 31) || wb >= (1LL << 31) || (long long)a.M * Cout >= (1LL << 31)) return GA_ERR_SHAPE;   // 32-bit byte offsets
   a.x_bytes = (unsigned)xb;
@@ -460,6 +479,30 @@ extern "C" int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* wo
   switch (dtype) {
     case GA_F16: return conv_t<_Float16>(X, Wp, Y, workspace, bias, residual, a, bm, bn, splits, s);
     case GA_BF16: return conv_t<bf16_t>(X, Wp, Y, workspace, bias, residual, a, bm, bn, splits, s);
+    default: return GA_ERR_DTYPE;
+  }
+}
+
+/* Y[M][N] = X[M][K] * W[N][K]^T (+ bias[N]) (+ residual[M][N]): the Linear layers and 1x1 convolutions of the UNet (weights
+ * in the framework's own [out][in] layout, no packing) on the same pipelined MFMA kernel, as a one-tap convolution. */
+extern "C" int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspace, const void* bias, const void* residual,
+                          int64_t M, int K, int N, int bm, int bn, int splits, int dtype, ga_stream_t stream) {
+  if (!X || !W || !Y) return GA_ERR_NULL;
+  if (M < 1 || K < kKC || K % kKC != 0 || N < 8 || N % 8 != 0) return GA_ERR_SHAPE;
+  if (splits < 1 || splits > 64 || (splits > 1 && !workspace)) return GA_ERR_SHAPE;
+  if (!al16(X) || !al16(W) || !al16(Y) || (bias && !al16(bias)) || (residual && !al16(residual))) return GA_ERR_ALIGN;
+  const long long xb = (long long)M * K * 2, wb = (long long)N * K * 2;
+  if (xb >= (1LL << 31) || wb >= (1LL << 31) || (long long)M * N >= (1LL << 31)) return GA_ERR_SHAPE;
+  ConvArgs a;
+  a.B = 1; a.H = (int)M; a.W = 1; a.Cin = K; a.Cout = N; a.stride = 1;
+  a.Ho = (int)M; a.Wo = 1; a.M = (int)M;
+  a.pad = 0;
+  a.x_bytes = (unsigned)xb;
+  a.w_bytes = (unsigned)wb;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case GA_F16: return conv_t<_Float16>(X, W, Y, workspace, bias, residual, a, bm, bn, splits, s);
+    case GA_BF16: return conv_t<bf16_t>(X, W, Y, workspace, bias, residual, a, bm, bn, splits, s);
     default: return GA_ERR_DTYPE;
   }
 }

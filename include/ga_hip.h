@@ -247,6 +247,16 @@ int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* workspace, co
                     int B, int H, int W, int Cin, int Cout, int stride, int bm, int bn, int splits, int dtype,
                     ga_stream_t stream);
 
+/* Linear layers / 1x1 convolutions of the UNet (diffusers 0.12.1 CrossAttention.to_q/to_k/to_v/to_out, FeedForward,
+ * Transformer2DModel.proj_in/proj_out, ResnetBlock2D.conv_shortcut — called from pipeline_guided_attention.py:647-738
+ * and utils/ptp_utils.py:70-91 through torch.nn.functional.linear / conv2d) on the convolution's pipelined MFMA kernel
+ * as a one-tap convolution:  Y[M][N] = X[M][K] * W[N][K]^T (+ bias[N]) (+ residual[M][N]).
+ * W is the framework's own [out_features][in_features] layout (no packing).  16-bit types; K % 64 == 0, N % 8 == 0;
+ * bm x bn in {128x128, 128x64, 64x64}; splits > 1 needs workspace of splits * M * N floats.
+ */
+int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspace, const void* bias, const void* residual, int64_t M,
+               int K, int N, int bm, int bn, int splits, int dtype, ga_stream_t stream);
+
 /* Residual add + LayerNorm (diffusers 0.12.1 BasicTransformerBlock.forward: x = attn(norm(x)) + x; norm_next(x)):
  *   fwd: x_new = a + x (rounded to T), y = LayerNorm(x_new) * gamma + beta, stats [rows][2] f32 = (mean, rstd).
  *        a == NULL: plain LayerNorm of x (x_new is not written and may be NULL).  stats may be NULL (inference).

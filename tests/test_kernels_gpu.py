@@ -747,3 +747,32 @@ def test_conv3x3_implicit_gemm(ops, shape, dt):
     close(xa.grad, xr.grad.numpy(), tol * 2, "dx")
     assert torch.equal(ra.grad, gy)
     assert not ops.conv3x3_supported(x.float(), w.float(), stride)      # fp32 stays on the library path
+
+
+GEMM_SHAPES = [(200, 64, 72, 1), (4096, 320, 320, 1), (768, 1280, 640, 4), (130, 192, 264, 3)]   # M, K, N, splits
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", GEMM_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_gemm_nt(ops, shape, dt):
+    """ga_gemm_nt (the convolution kernel as a one-tap convolution) against an fp64 matmul on the CPU: ragged M and N,
+    every tile, with and without split-K, bias + residual epilogue."""
+    import ctypes
+    from guided_attention_amd._lib import load, dtype_code, stream_ptr
+    M, K, N, splits = shape
+    x = dev(hashrand.normalish((M, K), 71), DT[dt])
+    w = dev(hashrand.normalish((N, K), 72) * (1.0 / math.sqrt(K)), DT[dt])
+    bias = dev(hashrand.normalish((N,), 73) * 0.3, DT[dt])
+    res = dev(hashrand.normalish((M, N), 74), DT[dt])
+    ref = x.double().cpu() @ w.double().cpu().T + bias.double().cpu() + res.double().cpu()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    for bm, bn in ((128, 128), (128, 64), (64, 64)):
+        for sp in (1, splits):
+            if sp > K // ops.CONV_KC:
+                continue
+            y = torch.empty(M, N, device="cuda", dtype=DT[dt])
+            ws = torch.empty(sp * M * N, device="cuda", dtype=torch.float32) if sp > 1 else None
+            rc = load().ga_gemm_nt(P(x), P(w), P(y), P(ws), P(bias), P(res), M, K, N, bm, bn, sp, dtype_code(x), stream_ptr())
+            assert rc == 0
+            close(y, ref.numpy(), TOL[dt] * 2, f"gemm tile {bm}x{bn} splits {sp}")
+    assert load().ga_gemm_nt(P(x), P(w), P(y), None, None, None, M, K + 8, N, 64, 64, 1, dtype_code(x), stream_ptr()) < 0
