@@ -140,14 +140,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
   // whole step later (the compiler's counted vmcnt leaves the younger set in flight).  One step of look-ahead left
   // every step waiting out a full memory round trip (1.1 - 1.6 us per step against 0.1 - 0.2 us of MFMAs).
   uint4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
-  auto load_step = [&](int it, uint4 (&ra)[PA], uint4 (&rb)[PB]) {
-    const int tap = it / cchunks, c0 = (it - tap * cchunks) * kKC;
-    const int ky = tap / 3, kx = tap - 3 * ky;
-    const int a_step = ((ky * a.W + kx) * a.Cin + c0) * (int)sizeof(T);              // wave-uniform
-    const unsigned b_step = (unsigned)((tap * a.Cout * a.Cin + c0) * (int)sizeof(T));  // wave-uniform; kOob + it stays >= 2 GiB
+  // (tap, channel chunk) of the next k-step to load, advanced incrementally (no division per step); past the last step
+  // of this split it stays put: that step is loaded again and never used (see the loop below)
+  int ld_it = it0, ld_tap = it0 / cchunks, ld_c = it0 - ld_tap * cchunks;
+  int ld_ky = ld_tap / 3, ld_kx = ld_tap - 3 * ld_ky;
+  auto load_step = [&](uint4 (&ra)[PA], uint4 (&rb)[PB]) {
+    const int a_step = ((ld_ky * a.W + ld_kx) * a.Cin + ld_c * kKC) * (int)sizeof(T);                  // wave-uniform
+    const unsigned b_step = (unsigned)((ld_tap * a.Cout * a.Cin + ld_c * kKC) * (int)sizeof(T));        // kOob + it stays >= 2 GiB
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      const bool in = (unsigned)(a_iy[p] + ky) < (unsigned)a.H && (unsigned)(a_ix[p] + kx) < (unsigned)a.W;
+      const bool in = (unsigned)(a_iy[p] + ld_ky) < (unsigned)a.H && (unsigned)(a_ix[p] + ld_kx) < (unsigned)a.W;
       const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, in ? (unsigned)(a_off[p] + a_step) : kOob, 0, 0);
       ra[p] = uint4{x[0], x[1], x[2], x[3]};
     }
@@ -155,6 +157,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
     for (int p = 0; p < PB; ++p) {
       const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[p] + b_step, 0, 0);
       rb[p] = uint4{x[0], x[1], x[2], x[3]};
+    }
+    if (ld_it + 1 < it1) {
+      ++ld_it;
+      if (++ld_c == cchunks) {
+        ld_c = 0;
+        ++ld_tap;
+        if (++ld_kx == 3) {
+          ld_kx = 0;
+          ++ld_ky;
+        }
+      }
     }
   };
   auto store_step = [&](int buf, const uint4 (&ra)[PA], const uint4 (&rb)[PB]) {
@@ -197,28 +210,33 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
 #endif
     }
   };
-  // Straight-line loop body: every load group is issued unconditionally (beyond the last step the index is clamped:
-  // the set is loaded again and never used) — a branch around a load group makes the compiler assume at the merge that
+  // Straight-line loop body: every load group is issued unconditionally (beyond the last step the same step is
+  // loaded again and never used) — a branch around a load group makes the compiler assume at the merge that
   // nothing younger is in flight and wait for vmcnt(0) where a counted wait would leave the next set's loads running.
-  const int last = it1 - 1;
   if (it0 < it1) {
-    load_step(it0, ra0, rb0);
-    load_step(min(it0 + 1, last), ra1, rb1);
+    load_step(ra0, rb0);
+    load_step(ra1, rb1);
     store_step(0, ra0, rb0);
   }
   __syncthreads();
-  for (int it = it0; it < it1; it += 2) {
+  // Two steps per trip, no exit in the middle: a mid-loop break made the accumulators live in different registers on
+  // the two paths and the compiler copied all of them (16 v_mov_b64 behind the last MFMA of every step).
+  int it = it0;
+  for (; it + 1 < it1; it += 2) {
     // even step: LDS buffer 0 holds step it, set 1 holds step it + 1 (in flight), set 0 is free
-    load_step(min(it + 2, last), ra0, rb0);
+    load_step(ra0, rb0);         // step it + 2
     mma_step(0);
     store_step(1, ra1, rb1);
     __syncthreads();
-    if (it + 1 >= it1) break;
     // odd step: buffer 1 holds step it + 1, set 0 holds step it + 2 (in flight), set 1 is free
-    load_step(min(it + 3, last), ra1, rb1);
+    load_step(ra1, rb1);         // step it + 3
     mma_step(1);
     store_step(0, ra0, rb0);
     __syncthreads();
+  }
+  if (it < it1) {                // odd number of steps: the last one sits in buffer 0
+    mma_step(0);
+    __syncthreads();             // the epilogue reuses the buffers: every wave's fragment reads must be done
   }
 
   // ---- epilogue.  acc[j][i][r]: output channel n = n0 + wn*WN + j*32 + (r & 3) + 8 * (r >> 2) + 4 * fh,
