@@ -20,6 +20,8 @@
 // through LDS once more and leaves as whole 16-byte row pieces with bias and residual added on the way.
 // The backward-to-input of a stride-1 convolution is the same kernel on the upstream gradient with the weights
 // flipped and transposed (pre-packed once per weight version by the host).
+#include <cstdlib>
+
 #include "attn_common.h"
 
 using namespace ga;
@@ -33,6 +35,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 #ifndef GA_CONV_KC
 #define GA_CONV_KC 64
+#endif
+// Ablation switches for tools/conv_tune.py variants (micro-benchmark builds only; results are wrong by construction,
+// only the time is read): bit 0 no global loads inside the loop, bit 1 no LDS stores inside the loop, bit 2 no MFMAs,
+// bit 3 no barriers inside the loop.
+#ifndef GA_CONV_ABL
+#define GA_CONV_ABL 0
 #endif
 constexpr int kKC = GA_CONV_KC;    // depth of one k-step (channels of one tap)
 constexpr int kLD = kKC + 8;       // LDS row stride in elements (80 bytes): conflict-free 16-byte fragment reads
@@ -64,6 +72,94 @@ struct ConvArgs {
   unsigned x_bytes, w_bytes;   // sizes of X and Wp (buffer descriptors: loads beyond them return zeros); < 2 GiB
 };
 
+// Workgroup -> (m tile, n tile, k split), XCD-aware.  The hardware deals consecutive workgroup ids round-robin over the
+// 8 XCDs (ids b and b + 8 share an L2).  The workgroups that read the same weight slice Wp[taps of split][n tile] are
+// its tm m-tiles: give each XCD one contiguous run of the m-fastest order, so a weight slice is fetched into ONE L2
+// instead of up to 8 (the 1280-channel layers otherwise re-read their 29.5 MB of weights once per m tile: 7x the
+// algorithmic bytes at the fabric counters).  Bijective for any grid size; placement is a speed matter only.
+template <int BM, int BN>
+__device__ __forceinline__ void tile_of_workgroup(const ConvArgs& a, int& m0, int& n0, int& split) {
+  const int total = gridDim.x, q = total >> 3, r = total & 7;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  if (a.n_fastest) {   // activations outweigh the weights (64x64 level): an XCD keeps an m tile's pixels, sweeps the n tiles
+    const int nt = logical % a.tn, rest = logical / a.tn;
+    n0 = nt * BN;
+    m0 = (rest % a.tm) * BM;
+    split = rest / a.tm;
+  } else {
+    const int mt = logical % a.tm, rest = logical / a.tm;
+    m0 = mt * BM;
+    n0 = (rest % a.tn) * BN;
+    split = rest / a.tn;
+  }
+}
+
+// Epilogue of both kernels.  acc[j][i][r]: output channel n = n0 + wn*WN + j*32 + (r & 3) + 8 * (r >> 2) + 4 * fh,
+//                                          pixel          m = m0 + wm*WM + i*32 + fr
+// OUT_F32: raw f32 partial tile to part[split][m][n]; else through LDS (every wave has passed the loop's last barrier:
+// the staging buffers are free) and out as whole 16-byte row pieces with bias and residual added.
+template <typename T, int BM, int BN, bool OUT_F32>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T* lds, T* __restrict__ Y,
+                                              float* __restrict__ part, const T* __restrict__ bias,
+                                              const T* __restrict__ residual, const ConvArgs& a, int m0, int n0,
+                                              int split) {
+  constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, JN = WN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+  if constexpr (OUT_F32) {
+    float* dst = part + (size_t)split * a.M * a.Cout;
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+      const int m = m0 + wm * WM + i * 32 + fr;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int n = n0 + wn * WN + j * 32 + 8 * qd + 4 * fh;
+          if (n < a.Cout)
+            *reinterpret_cast<f32x4*>(dst + (size_t)m * a.Cout + n) =
+                f32x4{acc[j][i][4 * qd], acc[j][i][4 * qd + 1], acc[j][i][4 * qd + 2], acc[j][i][4 * qd + 3]};
+        }
+    }
+  } else {
+    constexpr int LDC = BN + 8;
+    T* Cs = lds;
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          typename Traits<T>::frag f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) f[r] = Traits<T>::from_f32(acc[j][i][4 * qd + r]);
+          store_frag<T>(Cs + (wm * WM + i * 32 + fr) * LDC + wn * WN + j * 32 + 8 * qd + 4 * fh, f);
+        }
+    __syncthreads();
+    constexpr int VPR = BN / 8;                    // 16-byte vectors per tile row
+    for (int v = tid; v < BM * VPR; v += kThreads) {
+      const int r = v / VPR, cv = (v - r * VPR) * 8;
+      const int m = m0 + r, n = n0 + cv;
+      if (m >= a.M || n >= a.Cout) continue;
+      uint4 val = *reinterpret_cast<const uint4*>(Cs + r * LDC + cv);
+      if (bias != nullptr || residual != nullptr) {
+        T* e = reinterpret_cast<T*>(&val);
+        uint4 bv = uint4{0, 0, 0, 0}, rv = uint4{0, 0, 0, 0};
+        if (bias != nullptr) bv = *reinterpret_cast<const uint4*>(bias + n);
+        if (residual != nullptr) rv = *reinterpret_cast<const uint4*>(residual + (size_t)m * a.Cout + n);
+        const T* be = reinterpret_cast<const T*>(&bv);
+        const T* re = reinterpret_cast<const T*>(&rv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          e[k] = Traits<T>::from_f32(Traits<T>::to_f32(e[k]) + Traits<T>::to_f32(be[k]) + Traits<T>::to_f32(re[k]));
+      }
+      *reinterpret_cast<uint4*>(Y + (size_t)m * a.Cout + n) = val;
+    }
+  }
+}
+
 // OUT_F32 = true: this workgroup's split writes its raw f32 partial tile to part[split][m][n] (no bias / residual).
 template <typename T, int BM, int BN, bool OUT_F32>
 __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Wp,
@@ -82,28 +178,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // Workgroup -> (m tile, n tile, k split), XCD-aware.  The hardware deals consecutive workgroup ids round-robin over the
-  // 8 XCDs (ids b and b + 8 share an L2).  The workgroups that read the same weight slice Wp[taps of split][n tile] are
-  // its tm m-tiles: give each XCD one contiguous run of the m-fastest order, so a weight slice is fetched into ONE L2
-  // instead of up to 8 (the 1280-channel layers otherwise re-read their 29.5 MB of weights once per m tile: 7x the
-  // algorithmic bytes at the fabric counters).  Bijective for any grid size; placement is a speed matter only.
   int m0, n0, split;
-  {
-    const int total = gridDim.x, q = total >> 3, r = total & 7;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    if (a.n_fastest) {   // activations outweigh the weights (64x64 level): an XCD keeps an m tile's pixels, sweeps the n tiles
-      const int nt = logical % a.tn, rest = logical / a.tn;
-      n0 = nt * BN;
-      m0 = (rest % a.tm) * BM;
-      split = rest / a.tm;
-    } else {
-      const int mt = logical % a.tm, rest = logical / a.tm;
-      m0 = mt * BM;
-      n0 = (rest % a.tn) * BN;
-      split = rest / a.tn;
-    }
-  }
+  tile_of_workgroup<BM, BN>(a, m0, n0, split);
   const int it0 = split * a.steps_per, it1 = min(a.steps, it0 + a.steps_per);
   const int cchunks = a.Cin / kKC;
 
@@ -144,7 +220,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
   // of this split it stays put: that step is loaded again and never used (see the loop below)
   int ld_it = it0, ld_tap = it0 / cchunks, ld_c = it0 - ld_tap * cchunks;
   int ld_ky = ld_tap / 3, ld_kx = ld_tap - 3 * ld_ky;
+  bool in_loop = false;
   auto load_step = [&](uint4 (&ra)[PA], uint4 (&rb)[PB]) {
+    if ((GA_CONV_ABL & 1) && in_loop) return;
     const int a_step = ((ld_ky * a.W + ld_kx) * a.Cin + ld_c * kKC) * (int)sizeof(T);                  // wave-uniform
     const unsigned b_step = (unsigned)((ld_tap * a.Cout * a.Cin + ld_c * kKC) * (int)sizeof(T));        // kOob + it stays >= 2 GiB
 #pragma unroll
@@ -171,6 +249,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
     }
   };
   auto store_step = [&](int buf, const uint4 (&ra)[PA], const uint4 (&rb)[PB]) {
+    if ((GA_CONV_ABL & 2) && in_loop) return;
     T* As = lds + buf * kTile;
     T* Bs = As + BM * kLD;
 #pragma unroll
@@ -204,7 +283,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
 #pragma unroll
       for (int j = 0; j < JN; ++j)
 #pragma unroll
-        for (int i = 0; i < IM; ++i) acc[j][i] = Mma32<T>::run(fb[j], fa[i], acc[j][i]);
+        for (int i = 0; i < IM; ++i) {
+#if GA_CONV_ABL & 4
+          asm volatile("" ::"v"(fb[j].x), "v"(fb[j].w), "v"(fa[i].x), "v"(fa[i].w));   // keep the fragment reads alive
+#else
+          acc[j][i] = Mma32<T>::run(fb[j], fa[i], acc[j][i]);
+#endif
+        }
 #if GA_CONV_PRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
@@ -222,76 +307,213 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
   // Two steps per trip, no exit in the middle: a mid-loop break made the accumulators live in different registers on
   // the two paths and the compiler copied all of them (16 v_mov_b64 behind the last MFMA of every step).
   int it = it0;
+  in_loop = true;
+#define GA_CONV_SYNC() do { if (!(GA_CONV_ABL & 8)) __syncthreads(); } while (0)
   for (; it + 1 < it1; it += 2) {
     // even step: LDS buffer 0 holds step it, set 1 holds step it + 1 (in flight), set 0 is free
     load_step(ra0, rb0);         // step it + 2
     mma_step(0);
     store_step(1, ra1, rb1);
-    __syncthreads();
+    GA_CONV_SYNC();
     // odd step: buffer 1 holds step it + 1, set 0 holds step it + 2 (in flight), set 1 is free
     load_step(ra1, rb1);         // step it + 3
     mma_step(1);
     store_step(0, ra0, rb0);
-    __syncthreads();
+    GA_CONV_SYNC();
   }
   if (it < it1) {                // odd number of steps: the last one sits in buffer 0
     mma_step(0);
     __syncthreads();             // the epilogue reuses the buffers: every wave's fragment reads must be done
   }
 
-  // ---- epilogue.  acc[j][i][r]: output channel n = n0 + wn*WN + j*32 + (r & 3) + 8 * (r >> 2) + 4 * fh,
-  //                               pixel          m = m0 + wm*WM + i*32 + fr
-  if constexpr (OUT_F32) {
-    float* dst = part + (size_t)split * a.M * a.Cout;
-#pragma unroll
-    for (int i = 0; i < IM; ++i) {
-      const int m = m0 + wm * WM + i * 32 + fr;
-      if (m >= a.M) continue;
-#pragma unroll
-      for (int j = 0; j < JN; ++j)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int n = n0 + wn * WN + j * 32 + 8 * qd + 4 * fh;
-          if (n < a.Cout)
-            *reinterpret_cast<f32x4*>(dst + (size_t)m * a.Cout + n) =
-                f32x4{acc[j][i][4 * qd], acc[j][i][4 * qd + 1], acc[j][i][4 * qd + 2], acc[j][i][4 * qd + 3]};
-        }
-    }
+  conv_epilogue<T, BM, BN, OUT_F32>(acc, lds, Y, part, bias, residual, a, m0, n0, split);
+}
+
+// ---- variant with the input patch kept in LDS (stride 1, tiles made of whole image rows) ---------------------------
+// The kernel above stages a [BM pixels][64 channels] tile per tap: the nine taps of one channel chunk re-load and
+// re-store (nearly) the same pixels nine times, and the ablation builds showed staging — global loads plus LDS stores,
+// the stores alone a quarter of the time — costing as much as the MFMAs and not hiding behind them (a 128 x 64 step
+// needs 96 B/clk of LDS stores to keep the matrix pipe fed; ds_write_b128 tops out near 79 B/clk/CU).  Here a tile is
+// whole rows of one image (or whole small images); per 64-channel chunk the workgroup stages the rows it needs ONCE —
+// (rows + 2) x (W + 2) pixels, zeros around the image — and all nine taps read their pixel fragments from that patch
+// at shifted addresses.  A-side staging falls from 9 x BM rows to (rows + 2)(W + 2) rows per chunk (128 pixels of a
+// 64-wide image: 1152 -> 264); the weight tile [BN][64] per (chunk, tap) is staged as before.
+//   k order: chunk outer, tap inner.  Patch of chunk c + 1: nine 16-byte pieces per thread, all issued at tap 0 of
+//   chunk c, stored after tap 8 between two barriers (single patch buffer: LDS stays small enough for two workgroups
+//   per CU).  Weights: three register sets in rotation (9 taps = 3 x 3, so every index is static in the unrolled
+//   chunk body), two sets in flight as above; LDS weight buffer = global step parity (runtime).
+// 16-byte pieces per thread per chunk: patches of up to 288 pixels for 128-pixel tiles (a 64-wide image: 4 x 66 = 264),
+// 224 for 64-pixel tiles (3 x 66 = 198)
+constexpr int patch_pieces(int BM) { return BM >= 128 ? 9 : 7; }
+
+struct PatchGeom {
+  int nseg, srows;   // the tile = nseg segments of srows full rows each (nseg > 1: whole images, srows = H)
+};
+
+__host__ __device__ inline bool patch_geometry(int BM, int H, int W, PatchGeom& g) {
+  if (BM % W == 0 && (H * W) % BM == 0) {
+    g.nseg = 1;
+    g.srows = BM / W;
+  } else if (BM % (H * W) == 0) {
+    g.nseg = BM / (H * W);
+    g.srows = H;
   } else {
-    constexpr int LDC = BN + 8;
-    T* Cs = lds;   // every wave passed the last barrier of the loop: the A / B buffers are free
+    return false;
+  }
+  return g.nseg * (g.srows + 2) * (W + 2) * (kKC / 8) <= patch_pieces(BM) * kThreads;
+}
+
+template <typename T, int BM, int BN, bool OUT_F32>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_kernel(const T* __restrict__ X, const T* __restrict__ Wp,
+                                                                    T* __restrict__ Y, float* __restrict__ part,
+                                                                    const T* __restrict__ bias,
+                                                                    const T* __restrict__ residual, ConvArgs a) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int IM = WM / 32, JN = WN / 32;
+  constexpr int QP = kKC / 8;                 // 16-byte pieces per row
+  constexpr int RPP = kThreads / QP;          // rows staged per pass
+  constexpr int PB = BN / RPP;                // weight staging passes
+  constexpr int kPatchPieces = patch_pieces(BM);
+  constexpr int kPatchRows = kPatchPieces * RPP;          // 288 / 224
+  constexpr int kPatch = kPatchRows * kLD;                 // elements of the patch buffer
+  constexpr int kBt = BN * kLD;                            // one weight buffer
+  constexpr int kCtile = BM * (BN + 8);
+  constexpr int kLds = kPatch + 2 * kBt > kCtile ? kPatch + 2 * kBt : kCtile;
+  __shared__ __attribute__((aligned(16))) T lds[kLds];
+  T* patch = lds;
+  T* wbuf = lds + kPatch;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int m0, n0, split;
+  tile_of_workgroup<BM, BN>(a, m0, n0, split);
+  const int cchunks = a.Cin / kKC;
+  const int c_begin = split * a.steps_per, c_end = min(cchunks, c_begin + a.steps_per);   // chunks of this split
+
+  PatchGeom g;
+  patch_geometry(BM, a.H, a.W, g);
+  const int PW = a.W + 2, seg_px = g.srows * a.W, seg_rows = g.srows + 2;
+  const int npatch = g.nseg * seg_rows * PW;
+
+  constexpr unsigned kOob = 0x80000000u;
+  const int srow = tid / QP, sq = tid % QP;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wp), 0, a.w_bytes, 0x00020000);
+
+  // ---- patch staging: piece p of this thread = patch pixel q = srow + RPP * p, channels 8 sq .. 8 sq + 7 of the chunk
+  unsigned pa_off[kPatchPieces];   // byte offset of that pixel's channel 8 sq in X, or kOob (halo / beyond the batch)
+#pragma unroll
+  for (int p = 0; p < kPatchPieces; ++p) {
+    const int q = srow + RPP * p;
+    const int seg = q / (seg_rows * PW), rem = q - seg * (seg_rows * PW);
+    const int pr = rem / PW, pc = rem - pr * PW;
+    const int mseg = m0 + seg * seg_px;                  // first output pixel of the segment
+    const int b = mseg / (a.H * a.W), y0 = (mseg - b * (a.H * a.W)) / a.W;
+    const int iy = y0 + pr - 1, ix = pc - 1;
+    const bool ok = q < npatch && mseg < a.M && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    pa_off[p] = ok ? (unsigned)((((b * a.H + iy) * a.W + ix) * a.Cin + 8 * sq) * (int)sizeof(T)) : kOob;
+  }
+  uint4 rp[kPatchPieces];
+  auto load_patch = [&](int chunk) {
+    const unsigned step = (unsigned)(chunk * kKC * (int)sizeof(T));
+#pragma unroll
+    for (int p = 0; p < kPatchPieces; ++p) {
+      const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, pa_off[p] + step, 0, 0);
+      rp[p] = uint4{x[0], x[1], x[2], x[3]};
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int p = 0; p < kPatchPieces; ++p)
+      *reinterpret_cast<uint4*>(patch + (srow + RPP * p) * kLD + 8 * sq) = rp[p];
+  };
+
+  // ---- weight staging (as in the kernel above)
+  unsigned b_off[PB];
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int n = n0 + srow + RPP * p;
+    b_off[p] = n < a.Cout ? (unsigned)((n * a.Cin + 8 * sq) * (int)sizeof(T)) : kOob;
+  }
+  uint4 rb[3][PB];
+  auto load_w = [&](int chunk, int tap, uint4 (&r)[PB]) {
+    const unsigned step = (unsigned)((tap * a.Cout * a.Cin + chunk * kKC) * (int)sizeof(T));
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[p] + step, 0, 0);
+      r[p] = uint4{x[0], x[1], x[2], x[3]};
+    }
+  };
+  auto store_w = [&](int buf, const uint4 (&r)[PB]) {
+    T* Bs = wbuf + buf * kBt;
+#pragma unroll
+    for (int p = 0; p < PB; ++p) *reinterpret_cast<uint4*>(Bs + (srow + RPP * p) * kLD + 8 * sq) = r[p];
+  };
+
+  f32x16 acc[JN][IM];
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
 #pragma unroll
     for (int i = 0; i < IM; ++i)
 #pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  // ---- fragment addresses: this lane's pixel of each 32-block -> top-left pixel of its 3x3 window in the patch
+  const int fr = lane & 31, fh = lane >> 5;
+  int pix_base[IM];   // element offset into the patch
+#pragma unroll
+  for (int i = 0; i < IM; ++i) {
+    const int pm = wm * WM + i * 32 + fr;
+    const int seg = pm / seg_px, rem = pm - seg * seg_px;
+    const int r = rem / a.W, c = rem - r * a.W;
+    pix_base[i] = ((seg * seg_rows + r) * PW + c) * kLD + fh * 8;
+  }
+  auto mma_tap = [&](int buf, int ky, int kx) {
+    const T* Bs = wbuf + buf * kBt;
+    const int tap_off = (ky * PW + kx) * kLD;   // wave-uniform
+#pragma unroll
+    for (int kk = 0; kk < kKC / 16; ++kk) {
+      uint4 fa[IM], fb[JN];
+#pragma unroll
+      for (int i = 0; i < IM; ++i) fa[i] = *reinterpret_cast<const uint4*>(patch + pix_base[i] + tap_off + kk * 16);
+#pragma unroll
+      for (int j = 0; j < JN; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + (wn * WN + j * 32 + fr) * kLD + kk * 16 + fh * 8);
+#pragma unroll
       for (int j = 0; j < JN; ++j)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          typename Traits<T>::frag f;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) f[r] = Traits<T>::from_f32(acc[j][i][4 * qd + r]);
-          store_frag<T>(Cs + (wm * WM + i * 32 + fr) * LDC + wn * WN + j * 32 + 8 * qd + 4 * fh, f);
-        }
+        for (int i = 0; i < IM; ++i) acc[j][i] = Mma32<T>::run(fb[j], fa[i], acc[j][i]);
+    }
+  };
+
+  if (c_begin < c_end) {
+    // prologue: patch of the first chunk, weights of its taps 0 and 1
+    load_patch(c_begin);
+    load_w(c_begin, 0, rb[0]);
+    load_w(c_begin, 1, rb[1]);
+    store_patch();
+    store_w(0, rb[0]);
     __syncthreads();
-    constexpr int VPR = BN / 8;                    // 16-byte vectors per tile row
-    for (int v = tid; v < BM * VPR; v += kThreads) {
-      const int r = v / VPR, cv = (v - r * VPR) * 8;
-      const int m = m0 + r, n = n0 + cv;
-      if (m >= a.M || n >= a.Cout) continue;
-      uint4 val = *reinterpret_cast<const uint4*>(Cs + r * LDC + cv);
-      if (bias != nullptr || residual != nullptr) {
-        T* e = reinterpret_cast<T*>(&val);
-        uint4 bv = uint4{0, 0, 0, 0}, rv = uint4{0, 0, 0, 0};
-        if (bias != nullptr) bv = *reinterpret_cast<const uint4*>(bias + n);
-        if (residual != nullptr) rv = *reinterpret_cast<const uint4*>(residual + (size_t)m * a.Cout + n);
-        const T* be = reinterpret_cast<const T*>(&bv);
-        const T* re = reinterpret_cast<const T*>(&rv);
+    int s = 0;   // global step counter of this workgroup: weight buffer = s & 1
+    for (int c = c_begin; c < c_end; ++c) {
+      const int cn = min(c + 1, c_end - 1);   // next chunk (clamped: loaded again and never used after the last one)
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          e[k] = Traits<T>::from_f32(Traits<T>::to_f32(e[k]) + Traits<T>::to_f32(be[k]) + Traits<T>::to_f32(re[k]));
+      for (int t = 0; t < 9; ++t) {
+        // loads for step s + 2 (tap t + 2, wrapping into the next chunk) into the set freed at the previous step
+        if (t + 2 < 9) load_w(c, t + 2, rb[(t + 2) % 3]);
+        else load_w(cn, t + 2 - 9, rb[(t + 2) % 3]);
+        if (t == 0) load_patch(cn);
+        mma_tap(s & 1, t / 3, t % 3);
+        store_w((s + 1) & 1, rb[(t + 1) % 3]);     // step s + 1's weights (loaded one step ago)
+        __syncthreads();
+        ++s;
       }
-      *reinterpret_cast<uint4*>(Y + (size_t)m * a.Cout + n) = val;
+      // every wave is past tap 8: the patch may be replaced
+      store_patch();
+      __syncthreads();
     }
   }
+  conv_epilogue<T, BM, BN, OUT_F32>(acc, lds, Y, part, bias, residual, a, m0, n0, split);
 }
 
 // split-K epilogue: Y[m][n] = sum_s part[s][m][n] (+ bias[n] + R[m][n]), fixed summation order s = 0, 1, ...; 4 channels
@@ -383,6 +605,15 @@ Plan choose_plan(int M, int N, int steps) {
   return best;
 }
 
+// GA_CONV_V1=1 in the environment keeps every shape on the per-tap staging kernel (A/B runs of tools/conv_tune.py)
+inline bool force_v1() {
+  static const bool v = [] {
+    const char* e = getenv("GA_CONV_V1");
+    return e != nullptr && e[0] == '1';
+  }();
+  return v;
+}
+
 template <typename T, int BM, int BN>
 int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T* residual, const ConvArgs& a_in, int splits,
                 hipStream_t s) {
@@ -395,12 +626,24 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T
     a.n_fastest = n_first < m_first ? 1 : 0;
   }
   dim3 grid((unsigned)(a.tm * a.tn * splits));
+  PatchGeom pg;
+  // 8x8 maps stay on the per-tap kernel: the halo makes the patch 100 pixels for 64 and the depth splits only by chunks
+  const bool patch = a.pad == 1 && a.stride == 1 && a.W >= 16 && patch_geometry(BM, a.H, a.W, pg) && !force_v1();
+  if (patch) a.steps_per = (a.Cin / kKC + splits - 1) / splits;   // this variant splits the depth by channel chunks
   if (splits == 1) {
-    hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, false>), grid, dim3(kThreads), 0, s, X, Wp, Y, (float*)nullptr, bias,
-                       residual, a);
+    if (patch)
+      hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, false>), grid, dim3(kThreads), 0, s, X, Wp, Y, (float*)nullptr,
+                         bias, residual, a);
+    else
+      hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, false>), grid, dim3(kThreads), 0, s, X, Wp, Y, (float*)nullptr, bias,
+                         residual, a);
   } else {
-    hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, true>), grid, dim3(kThreads), 0, s, X, Wp, (T*)nullptr, ws, (const T*)nullptr,
-                       (const T*)nullptr, a);
+    if (patch)
+      hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, true>), grid, dim3(kThreads), 0, s, X, Wp, (T*)nullptr, ws,
+                         (const T*)nullptr, (const T*)nullptr, a);
+    else
+      hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, true>), grid, dim3(kThreads), 0, s, X, Wp, (T*)nullptr, ws,
+                         (const T*)nullptr, (const T*)nullptr, a);
     const long long MN = (long long)a.M * a.Cout;
     const dim3 sgrid((unsigned)((MN / 4 + kThreads - 1) / kThreads));
 #define GA_SUM_CASE(S)                                                                                                 \

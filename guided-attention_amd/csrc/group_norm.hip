@@ -455,6 +455,17 @@ __global__ __launch_bounds__(kThreads) void gn_wide_apply_kernel(const T* __rest
   __shared__ float2 res[64];
   const WideMap m(C, G);
   const int b = blockIdx.y, p0 = blockIdx.x * PB, p1 = min(HW, p0 + PB);
+  const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
+  Vec8<T>* yb = reinterpret_cast<Vec8<T>*>(y + (size_t)b * HW * C) + m.vec;
+  // the first batch of activation loads is issued BEFORE the statistics are folded: the fold is its own dependent
+  // round trip to L2 (partials -> shuffle -> LDS -> barrier) and nothing in it needs x
+  Vec8<T> v[kU];
+  int p = p0 + m.pr;
+  if (m.active) {
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (p + u * m.RP < p1) v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
+  }
   fold_partials<true>(partial, b, NB, G, inv_n, eps, res, blockIdx.x == 0 ? stats : nullptr);
   if (!m.active) return;
   const float* mr = reinterpret_cast<const float*>(res);
@@ -471,13 +482,7 @@ __global__ __launch_bounds__(kThreads) void gn_wide_apply_kernel(const T* __rest
       sh[j] = Traits<T>::to_f32(bt.v[j]) - (mr[2 * g] - cbj) * sc[j];  // (x + cb - mean) * scale + beta
     }
   }
-  const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
-  Vec8<T>* yb = reinterpret_cast<Vec8<T>*>(y + (size_t)b * HW * C) + m.vec;
-  for (int p = p0 + m.pr; p < p1; p += kU * m.RP) {
-    Vec8<T> v[kU];
-#pragma unroll
-    for (int u = 0; u < kU; ++u)
-      if (p + u * m.RP < p1) v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
+  for (; p < p1; p += kU * m.RP) {
 #pragma unroll
     for (int u = 0; u < kU; ++u)
       if (p + u * m.RP < p1) {
@@ -490,6 +495,10 @@ __global__ __launch_bounds__(kThreads) void gn_wide_apply_kernel(const T* __rest
         }
         yb[(size_t)(p + u * m.RP) * m.VP] = o;
       }
+    const int pn = p + kU * m.RP;   // next batch (none with the launch geometry of WideGeom: one batch per thread)
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (pn + u * m.RP < p1) v[u] = xb[(size_t)(pn + u * m.RP) * m.VP];
   }
 }
 
@@ -569,6 +578,19 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
   __shared__ float2 res[64];
   const WideMap m(C, G);
   const int b = blockIdx.y, p0 = blockIdx.x * PB, p1 = min(HW, p0 + PB);
+  const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
+  const Vec8<T>* db = reinterpret_cast<const Vec8<T>*>(dy + (size_t)b * HW * C) + m.vec;
+  Vec8<T>* ob = reinterpret_cast<Vec8<T>*>(dx + (size_t)b * HW * C) + m.vec;
+  Vec8<T> v[kU], d[kU];   // first batch in flight under the fold of the partial sums (as in the forward)
+  int p = p0 + m.pr;
+  if (m.active) {
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (p + u * m.RP < p1) {
+        v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
+        d[u] = db[(size_t)(p + u * m.RP) * m.VP];
+      }
+  }
   fold_partials<false>(partial, b, NB, G, inv_n, 0.f, res, nullptr);
   if (!m.active) return;
   WideBwdConst<T> k;
@@ -580,17 +602,7 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
     a1[j] = res[g < G ? g : G - 1].x;
     a2[j] = res[g < G ? g : G - 1].y;
   }
-  const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
-  const Vec8<T>* db = reinterpret_cast<const Vec8<T>*>(dy + (size_t)b * HW * C) + m.vec;
-  Vec8<T>* ob = reinterpret_cast<Vec8<T>*>(dx + (size_t)b * HW * C) + m.vec;
-  for (int p = p0 + m.pr; p < p1; p += kU * m.RP) {
-    Vec8<T> v[kU], d[kU];
-#pragma unroll
-    for (int u = 0; u < kU; ++u)
-      if (p + u * m.RP < p1) {
-        v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
-        d[u] = db[(size_t)(p + u * m.RP) * m.VP];
-      }
+  for (; p < p1; p += kU * m.RP) {
 #pragma unroll
     for (int u = 0; u < kU; ++u)
       if (p + u * m.RP < p1) {
@@ -602,6 +614,13 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
           o.v[j] = Traits<T>::from_f32(k.rs[j] * (dh - a1[j] - yh * a2[j]));
         }
         ob[(size_t)(p + u * m.RP) * m.VP] = o;
+      }
+    const int pn = p + kU * m.RP;
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (pn + u * m.RP < p1) {
+        v[u] = xb[(size_t)(pn + u * m.RP) * m.VP];
+        d[u] = db[(size_t)(pn + u * m.RP) * m.VP];
       }
   }
 }

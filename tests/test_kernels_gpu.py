@@ -707,6 +707,9 @@ def test_self_attention_fused_qkv_matches_separate(ops):
 CONV_SHAPES = [  # B, Cin, Cout, H, W, stride
     (1, 64, 64, 16, 16, 1), (2, 192, 192, 9, 7, 1), (1, 320, 320, 32, 32, 1), (1, 640, 320, 16, 16, 1), (3, 64, 128, 20, 12, 1),
     (1, 64, 64, 16, 16, 2), (2, 192, 64, 9, 7, 2), (1, 1280, 1280, 8, 8, 1), (1, 128, 64, 5, 5, 1),
+    # tiles of whole image rows / whole images (the patch-in-LDS variant): a partial last tile of whole 8x8 images, several
+    # chunks per split, 2 / 4 / 8 rows per tile
+    (3, 128, 64, 8, 8, 1), (2, 128, 64, 64, 64, 1), (1, 192, 128, 32, 32, 1), (3, 128, 192, 16, 16, 1),
 ]
 
 

@@ -13,13 +13,17 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from guided_attention_amd import ops  # noqa: E402
 
 torch.backends.cudnn.benchmark = True
-BASE = [  # (Cin, Cout, H, stride)
+BASE_ALL = [  # (Cin, Cout, H, stride)
     (320, 320, 64, 1), (640, 320, 64, 1), (960, 320, 64, 1), (320, 640, 64, 1), (320, 960, 64, 1), (320, 320, 64, 2), (640, 640, 64, 1),
     (320, 640, 32, 1), (640, 640, 32, 1), (1280, 640, 32, 1), (1920, 640, 32, 1), (960, 640, 32, 1), (640, 1280, 32, 1),
     (640, 1920, 32, 1), (640, 960, 32, 1), (640, 640, 32, 2), (1280, 1280, 32, 1),
     (640, 1280, 16, 1), (1280, 1280, 16, 1), (2560, 1280, 16, 1), (1920, 1280, 16, 1), (1280, 2560, 16, 1), (1280, 1920, 16, 1),
     (1280, 1280, 16, 2), (1280, 1280, 8, 1), (2560, 1280, 8, 1), (1280, 2560, 8, 1),
 ]
+
+
+# "variants" runs compare extra builds on a few representative shapes only
+BASE = BASE_ALL if "variants" not in sys.argv else [(320, 320, 64, 1), (640, 640, 32, 1), (1280, 1280, 16, 1), (1280, 1280, 8, 1)]
 
 
 def replay_us(fn, iters=20):
