@@ -5,7 +5,7 @@ import csv
 import re
 import sys
 
-OURS = ("attn_capture", "smooth_loss", "aggregate_kernel", "axpy", "axpby", "cfg_ddim", "self_attn", "group_norm", "gn_")
+OURS = ("attn_capture", "smooth_loss", "aggregate_kernel", "axpy", "axpby", "cfg_ddim", "self_attn", "group_norm", "gn_", "conv3x3", "conv_splitk", "geglu", "add_ln", "bias_residual")
 
 
 def short(name):
