@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
 //   k order: chunk outer, tap inner.  Patch of chunk c + 1: nine 16-byte pieces per thread, all issued at tap 0 of
 //   chunk c, stored after tap 8 between two barriers (single patch buffer: LDS stays small enough for two workgroups
 //   per CU).  Weights: three register sets in rotation (9 taps = 3 x 3, so every index is static in the unrolled
-//   chunk body), two sets in flight as above; LDS weight buffer = global step parity (runtime).
+//   chunk body), all three in flight; LDS weight buffer = global step parity (runtime).
 // 16-byte pieces per thread per chunk: patches of up to 288 pixels for 128-pixel tiles (a 64-wide image: 4 x 66 = 264),
 // 224 for 64-pixel tiles (3 x 66 = 198)
 constexpr int patch_pieces(int BM) { return BM >= 128 ? 9 : 7; }
@@ -487,10 +487,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_kernel(const T* __r
   };
 
   if (c_begin < c_end) {
-    // prologue: patch of the first chunk, weights of its taps 0 and 1
+    // prologue: patch of the first chunk, weights of its taps 0, 1 and 2
     load_patch(c_begin);
     load_w(c_begin, 0, rb[0]);
     load_w(c_begin, 1, rb[1]);
+    load_w(c_begin, 2, rb[2]);
     store_patch();
     store_w(0, rb[0]);
     __syncthreads();
@@ -499,12 +500,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_kernel(const T* __r
       const int cn = min(c + 1, c_end - 1);   // next chunk (clamped: loaded again and never used after the last one)
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        // loads for step s + 2 (tap t + 2, wrapping into the next chunk) into the set freed at the previous step
-        if (t + 2 < 9) load_w(c, t + 2, rb[(t + 2) % 3]);
-        else load_w(cn, t + 2 - 9, rb[(t + 2) % 3]);
+        // Step s = (chunk c, tap t): its weights sit in LDS buffer s & 1 (stored during step s - 1), so register set
+        // t % 3 is free: it takes the loads of step s + 3 — three steps of weights in flight (s + 1, about to be stored,
+        // s + 2, s + 3) on the same registers two steps needed.  At batch 1 the weights are a cold stream from HBM.
+        if (t + 3 < 9) load_w(c, t + 3, rb[t % 3]);
+        else load_w(cn, t + 3 - 9, rb[t % 3]);
         if (t == 0) load_patch(cn);
         mma_tap(s & 1, t / 3, t % 3);
-        store_w((s + 1) & 1, rb[(t + 1) % 3]);     // step s + 1's weights (loaded one step ago)
+        store_w((s + 1) & 1, rb[(t + 1) % 3]);     // step s + 1's weights (loaded two steps ago)
         __syncthreads();
         ++s;
       }
