@@ -340,8 +340,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
 // 64-wide image: 1152 -> 264); the weight tile [BN][64] per (chunk, tap) is staged as before.
 //   k order: chunk outer, tap inner.  Patch of chunk c + 1: nine 16-byte pieces per thread, all issued at tap 0 of
 //   chunk c, stored after tap 8 between two barriers (single patch buffer: LDS stays small enough for two workgroups
-//   per CU).  Weights: three register sets in rotation (9 taps = 3 x 3, so every index is static in the unrolled
-//   chunk body), all three in flight; LDS weight buffer = global step parity (runtime).
+//   per CU).  Weights: 3 or 9 register sets in rotation (a divisor of the 9 taps, so every index is static in the
+//   unrolled chunk body), 3 or 6 steps in flight; LDS weight buffer = global step parity (runtime).
 // 16-byte pieces per thread per chunk: patches of up to 288 pixels for 128-pixel tiles (a 64-wide image: 4 x 66 = 264),
 // 224 for 64-pixel tiles (3 x 66 = 198)
 constexpr int patch_pieces(int BM) { return BM >= 128 ? 9 : 7; }
@@ -436,7 +436,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_kernel(const T* __r
     const int n = n0 + srow + RPP * p;
     b_off[p] = n < a.Cout ? (unsigned)((n * a.Cin + 8 * sq) * (int)sizeof(T)) : kOob;
   }
-  uint4 rb[3][PB];
+  // Weight register sets: NS sets in rotation, NS | 9 so that every index is static in the unrolled chunk body; PD of
+  // them in flight (prefetch distance in steps).  A 64-wide weight tile is 2 registers-quads per set: nine sets, six
+  // steps ahead; a 128-wide one keeps three sets, three ahead (the accumulators need the registers).
+  constexpr int NS = BN <= 64 ? 9 : 3, PD = BN <= 64 ? 6 : 3;
+  uint4 rb[NS][PB];
   auto load_w = [&](int chunk, int tap, uint4 (&r)[PB]) {
     const unsigned step = (unsigned)((tap * a.Cout * a.Cin + chunk * kKC) * (int)sizeof(T));
 #pragma unroll
@@ -487,11 +491,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_kernel(const T* __r
   };
 
   if (c_begin < c_end) {
-    // prologue: patch of the first chunk, weights of its taps 0, 1 and 2
+    // prologue: patch of the first chunk, weights of its taps 0 .. PD - 1
     load_patch(c_begin);
-    load_w(c_begin, 0, rb[0]);
-    load_w(c_begin, 1, rb[1]);
-    load_w(c_begin, 2, rb[2]);
+#pragma unroll
+    for (int t = 0; t < PD; ++t) load_w(c_begin, t, rb[t % NS]);
     store_patch();
     store_w(0, rb[0]);
     __syncthreads();
@@ -500,14 +503,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_kernel(const T* __r
       const int cn = min(c + 1, c_end - 1);   // next chunk (clamped: loaded again and never used after the last one)
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        // Step s = (chunk c, tap t): its weights sit in LDS buffer s & 1 (stored during step s - 1), so register set
-        // t % 3 is free: it takes the loads of step s + 3 — three steps of weights in flight (s + 1, about to be stored,
-        // s + 2, s + 3) on the same registers two steps needed.  At batch 1 the weights are a cold stream from HBM.
-        if (t + 3 < 9) load_w(c, t + 3, rb[t % 3]);
-        else load_w(cn, t + 3 - 9, rb[t % 3]);
+        // Step s = (chunk c, tap t): its weights sit in LDS buffer s & 1 (stored during step s - 1).  The set that takes
+        // the loads of step s + PD last held step s + PD - NS <= s, stored at least one step ago: free.  At batch 1 the
+        // weights are a cold stream from HBM and every step of look-ahead shows in the pipeline's time.
+        if (t + PD < 9) load_w(c, t + PD, rb[(t + PD) % NS]);
+        else load_w(cn, t + PD - 9, rb[(t + PD) % NS]);
         if (t == 0) load_patch(cn);
         mma_tap(s & 1, t / 3, t % 3);
-        store_w((s + 1) & 1, rb[(t + 1) % 3]);     // step s + 1's weights (loaded two steps ago)
+        store_w((s + 1) & 1, rb[(t + 1) % NS]);     // step s + 1's weights (loaded PD - 1 steps ago)
         __syncthreads();
         ++s;
       }
