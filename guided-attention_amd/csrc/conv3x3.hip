@@ -38,7 +38,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 // Ablation switches for tools/conv_tune.py variants (micro-benchmark builds only; results are wrong by construction,
 // only the time is read): bit 0 no global loads inside the loop, bit 1 no LDS stores inside the loop, bit 2 no MFMAs,
-// bit 3 no barriers inside the loop.
+// bit 3 no barriers inside the loop, bit 4 (patch variant) no patch reload per chunk; bit 5 (patch variant) no fragment
+// reads (one set of fragments is read once).
 #ifndef GA_CONV_ABL
 #define GA_CONV_ABL 0
 #endif
@@ -486,7 +487,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_kernel(const T* __r
 #pragma unroll
       for (int j = 0; j < JN; ++j)
 #pragma unroll
-        for (int i = 0; i < IM; ++i) acc[j][i] = Mma32<T>::run(fb[j], fa[i], acc[j][i]);
+        for (int i = 0; i < IM; ++i) {
+#if GA_CONV_ABL & 4
+          asm volatile("" ::"v"(fb[j].x), "v"(fb[j].w), "v"(fa[i].x), "v"(fa[i].w));   // keep the fragment reads alive
+#else
+          acc[j][i] = Mma32<T>::run(fb[j], fa[i], acc[j][i]);
+#endif
+        }
     }
   };
 
@@ -506,16 +513,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_kernel(const T* __r
         // Step s = (chunk c, tap t): its weights sit in LDS buffer s & 1 (stored during step s - 1).  The set that takes
         // the loads of step s + PD last held step s + PD - NS <= s, stored at least one step ago: free.  At batch 1 the
         // weights are a cold stream from HBM and every step of look-ahead shows in the pipeline's time.
-        if (t + PD < 9) load_w(c, t + PD, rb[(t + PD) % NS]);
-        else load_w(cn, t + PD - 9, rb[(t + PD) % NS]);
-        if (t == 0) load_patch(cn);
+        if (!(GA_CONV_ABL & 1)) {
+          if (t + PD < 9) load_w(c, t + PD, rb[(t + PD) % NS]);
+          else load_w(cn, t + PD - 9, rb[(t + PD) % NS]);
+        }
+        if (t == 0 && !(GA_CONV_ABL & 16)) load_patch(cn);
         mma_tap(s & 1, t / 3, t % 3);
-        store_w((s + 1) & 1, rb[(t + 1) % NS]);     // step s + 1's weights (loaded PD - 1 steps ago)
-        __syncthreads();
+        if (!(GA_CONV_ABL & 2)) store_w((s + 1) & 1, rb[(t + 1) % NS]);     // step s + 1's weights (loaded PD - 1 steps ago)
+        if (!(GA_CONV_ABL & 8)) __syncthreads();
         ++s;
       }
       // every wave is past tap 8: the patch may be replaced
-      store_patch();
+      if (!(GA_CONV_ABL & 16)) store_patch();
       __syncthreads();
     }
   }

@@ -23,7 +23,7 @@ BASE_ALL = [  # (Cin, Cout, H, stride)
 
 
 # "variants" runs compare extra builds on a few representative shapes only
-BASE = BASE_ALL if "variants" not in sys.argv else [(320, 320, 64, 1), (640, 640, 32, 1), (1280, 1280, 16, 1), (1280, 1280, 8, 1)]
+BASE = BASE_ALL if "variants" not in sys.argv or "all" in sys.argv else [(320, 320, 64, 1), (640, 640, 32, 1), (1280, 1280, 16, 1), (1280, 1280, 8, 1)]
 
 
 def replay_us(fn, iters=20):
@@ -109,8 +109,8 @@ def main():
             extra = ""
             for vname, vlib in variants.items():
                 vt = variant_times(vlib, x, w, co, st, [k for k in res if (9 * ci // 64) // k[2] >= 3])
-                vb = min(vt, key=vt.get)
-                extra += f" | {vname} {vb} {vt[vb]:.1f}"
+                vb = best if best in vt else min(vt, key=vt.get)      # the same plan as the product build's best
+                extra += f" | {vname} {vt[vb]:.1f}"
             heur = ops.conv3x3_plan(B, h, h, ci, co, st)[:3]
             t_h = res.get(tuple(heur))
             print(f"{B:>2} {ci:>5} {co:>5} {h:>3} {st:>1} {t_lib:8.1f} {flop / t_lib / 1e6:6.0f} | {str(best):>14} {res[best]:8.1f} "
