@@ -265,7 +265,8 @@ def pmc_traffic(kernel, model, shape):
 def roofline_entry(census, ops, model="sd15"):
     """Dominant hand-written kernel = the ga_* entry point with the largest total time over the timed region.
     achieved = sum of algorithmic work over its calls / sum of their durations; each shape's duration is measured by a
-    back-to-back hipGraph replay between two HIP events on the launch stream (the weighted mean equals what
+    back-to-back hipGraph replay between two HIP events on the launch stream; the convolution replays rotate over enough
+    weight copies to exceed the Infinity Cache, because in the pipeline its weights are cold (the weighted mean equals what
     `rocprofv3 --kernel-trace --stats` reports as the kernel's AverageNs: profiles/)."""
     per_kind = {}
     for key, count in census.items():

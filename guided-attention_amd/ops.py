@@ -71,7 +71,12 @@ def replay_launch_us(key, iters=100):
         cin, hw, stride, cout = H, N, Kt, D
         side_len = int(round(hw ** 0.5))
         x = torch.randn(B, cin, side_len, hw // side_len, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
-        wp = torch.randn(9, cout, cin, device=dev, dtype=dtype) * (9 * cin) ** -0.5
+        # In the pipeline a convolution's weights are cold (1.7 GB of UNet weights cycle through a 256 MB Infinity Cache
+        # between two uses) while its input was just written.  A back-to-back replay on ONE weight tensor would time an
+        # L2-resident weight stream the product never sees: rotate over enough copies to exceed the Infinity Cache.
+        n_copies = max(1, min(24, -(-320 * 2 ** 20 // (9 * cout * cin * 2))))
+        wps = [torch.randn(9, cout, cin, device=dev, dtype=dtype) * (9 * cin) ** -0.5 for _ in range(n_copies)]
+        turn = [0]
         ho, wo = (side_len - 1) // stride + 1, (hw // side_len - 1) // stride + 1
         bias = torch.randn(cout, device=dev, dtype=dtype) if flag else None
         res = (torch.randn(B, cout, ho, wo, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
@@ -82,6 +87,8 @@ def replay_launch_us(key, iters=100):
         code = dtype_code(x)
 
         def fn():
+            wp = wps[turn[0] % n_copies]
+            turn[0] += 1
             check(lib.ga_conv3x3_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(bias), _ptr(res), B, side_len,
                                       hw // side_len, cin, cout, stride, bm, bn, splits, code, stream_ptr()), "replay conv")
     elif kind in ("geglu_fwd", "geglu_bwd", "bias_residual_add", "add_layer_norm_fwd", "add_layer_norm_bwd"):
