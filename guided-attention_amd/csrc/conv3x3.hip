@@ -345,13 +345,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
 //   unrolled chunk body), 3 or 6 steps in flight; LDS weight buffer = global step parity (runtime).
 // 16-byte pieces per thread per chunk: patches of up to 288 pixels for 128-pixel tiles (a 64-wide image: 4 x 66 = 264),
 // 224 for 64-pixel tiles (3 x 66 = 198)
-constexpr int patch_pieces(int BM) { return BM >= 128 ? 9 : 7; }
+// WIDE: one row of a 128-wide map (SDXL's top level: 3 x 130 = 390 pixels) needs 13 pieces = 416 patch rows
+constexpr int patch_pieces(int BM, bool wide = false) { return wide ? 13 : (BM >= 128 ? 9 : 7); }
 
 struct PatchGeom {
   int nseg, srows;   // the tile = nseg segments of srows full rows each (nseg > 1: whole images, srows = H)
 };
 
-__host__ __device__ inline bool patch_geometry(int BM, int H, int W, PatchGeom& g) {
+__host__ __device__ inline bool patch_geometry(int BM, int H, int W, PatchGeom& g, bool wide = false) {
   if (BM % W == 0 && (H * W) % BM == 0) {
     g.nseg = 1;
     g.srows = BM / W;
@@ -361,11 +362,11 @@ __host__ __device__ inline bool patch_geometry(int BM, int H, int W, PatchGeom& 
   } else {
     return false;
   }
-  return g.nseg * (g.srows + 2) * (W + 2) * (kKC / 8) <= patch_pieces(BM) * kThreads;
+  return g.nseg * (g.srows + 2) * (W + 2) * (kKC / 8) <= patch_pieces(BM, wide) * kThreads;
 }
 
-template <typename T, int BM, int BN, bool OUT_F32>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_kernel(const T* __restrict__ X, const T* __restrict__ Wp,
+template <typename T, int BM, int BN, bool OUT_F32, bool WIDE = false>
+__global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_patch_kernel(const T* __restrict__ X, const T* __restrict__ Wp,
                                                                     T* __restrict__ Y, float* __restrict__ part,
                                                                     const T* __restrict__ bias,
                                                                     const T* __restrict__ residual, ConvArgs a) {
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_kernel(const T* __r
   constexpr int QP = kKC / 8;                 // 16-byte pieces per row
   constexpr int RPP = kThreads / QP;          // rows staged per pass
   constexpr int PB = BN / RPP;                // weight staging passes
-  constexpr int kPatchPieces = patch_pieces(BM);
+  constexpr int kPatchPieces = patch_pieces(BM, WIDE);
   constexpr int kPatchRows = kPatchPieces * RPP;          // 288 / 224
   constexpr int kPatch = kPatchRows * kLD;                 // elements of the patch buffer
   constexpr int kBt = BN * kLD;                            // one weight buffer
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_kernel(const T* __r
   const int c_begin = split * a.steps_per, c_end = min(cchunks, c_begin + a.steps_per);   // chunks of this split
 
   PatchGeom g;
-  patch_geometry(BM, a.H, a.W, g);
+  patch_geometry(BM, a.H, a.W, g, WIDE);
   const int PW = a.W + 2, seg_px = g.srows * a.W, seg_rows = g.srows + 2;
   const int npatch = g.nseg * seg_rows * PW;
 
@@ -629,6 +630,25 @@ inline bool force_v1() {
   return v;
 }
 
+template <typename T>
+int launch_split_sum(float* ws, int splits, T* Y, const T* bias, const T* residual, const ConvArgs& a, hipStream_t s) {
+  const long long MN = (long long)a.M * a.Cout;
+  const dim3 sgrid((unsigned)((MN / 4 + kThreads - 1) / kThreads));
+#define GA_SUM_CASE(S)                                                                                                 \
+  case S:                                                                                                              \
+  hipLaunchKernelGGL((conv_splitk_sum_kernel<T, S>), sgrid, dim3(kThreads), 0, s, (const float*)ws, splits, Y, bias,   \
+                     residual, MN, a.Cout);                                                                          \
+  break;
+  switch (splits) {
+    GA_SUM_CASE(2) GA_SUM_CASE(3) GA_SUM_CASE(4) GA_SUM_CASE(6) GA_SUM_CASE(8) GA_SUM_CASE(12) GA_SUM_CASE(16)
+    default:
+      hipLaunchKernelGGL((conv_splitk_sum_kernel<T, 0>), sgrid, dim3(kThreads), 0, s, (const float*)ws, splits, Y, bias,
+                         residual, MN, a.Cout);
+  }
+#undef GA_SUM_CASE
+  return check_launch();
+}
+
 template <typename T, int BM, int BN>
 int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T* residual, const ConvArgs& a_in, int splits,
                 hipStream_t s) {
@@ -643,7 +663,22 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T
   dim3 grid((unsigned)(a.tm * a.tn * splits));
   PatchGeom pg;
   // 8x8 maps stay on the per-tap kernel: the halo makes the patch 100 pixels for 64 and the depth splits only by chunks
-  const bool patch = a.pad == 1 && a.stride == 1 && a.W >= 16 && patch_geometry(BM, a.H, a.W, pg) && !force_v1();
+  const bool geom_ok = a.pad == 1 && a.stride == 1 && a.W >= 16 && !force_v1();
+  const bool patch = geom_ok && patch_geometry(BM, a.H, a.W, pg);
+  const bool patch_wide = geom_ok && !patch && BM == 128 && patch_geometry(BM, a.H, a.W, pg, true);
+  if (patch_wide) {   // a 128-pixel tile of one 128-wide row: the 13-piece instantiation
+    a.steps_per = (a.Cin / kKC + splits - 1) / splits;
+    if constexpr (BM == 128) {
+      if (splits == 1) {
+        hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, false, true>), grid, dim3(kThreads), 0, s, X, Wp, Y,
+                           (float*)nullptr, bias, residual, a);
+        return check_launch();
+      }
+      hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, true, true>), grid, dim3(kThreads), 0, s, X, Wp, (T*)nullptr, ws,
+                         (const T*)nullptr, (const T*)nullptr, a);
+      return launch_split_sum<T>(ws, splits, Y, bias, residual, a, s);
+    }
+  }
   if (patch) a.steps_per = (a.Cin / kKC + splits - 1) / splits;   // this variant splits the depth by channel chunks
   if (splits == 1) {
     if (patch)
@@ -659,20 +694,7 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T
     else
       hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, true>), grid, dim3(kThreads), 0, s, X, Wp, (T*)nullptr, ws,
                          (const T*)nullptr, (const T*)nullptr, a);
-    const long long MN = (long long)a.M * a.Cout;
-    const dim3 sgrid((unsigned)((MN / 4 + kThreads - 1) / kThreads));
-#define GA_SUM_CASE(S)                                                                                                 \
-  case S:                                                                                                              \
-    hipLaunchKernelGGL((conv_splitk_sum_kernel<T, S>), sgrid, dim3(kThreads), 0, s, (const float*)ws, splits, Y, bias,   \
-                       residual, MN, a.Cout);                                                                          \
-    break;
-    switch (splits) {
-      GA_SUM_CASE(2) GA_SUM_CASE(3) GA_SUM_CASE(4) GA_SUM_CASE(6) GA_SUM_CASE(8) GA_SUM_CASE(12) GA_SUM_CASE(16)
-      default:
-        hipLaunchKernelGGL((conv_splitk_sum_kernel<T, 0>), sgrid, dim3(kThreads), 0, s, (const float*)ws, splits, Y, bias,
-                           residual, MN, a.Cout);
-    }
-#undef GA_SUM_CASE
+    return launch_split_sum<T>(ws, splits, Y, bias, residual, a, s);
   }
   return check_launch();
 }

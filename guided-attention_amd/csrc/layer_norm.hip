@@ -27,10 +27,7 @@ struct alignas(16) Vec {
   T v[N];
 };
 
-// R rows per wave (the row loop is unrolled: all R rows' loads are issued before the first use).  One row per wave kept
-// ~1.3 KB in flight per wave, 16 waves per CU: a third of what the memory system needs to stream at rate; the kernel
-// ran latency-bound at 1.8 - 2.4 TB/s.
-template <typename T, int NV, int R>
+template <typename T, int NV>
 __global__ __launch_bounds__(kThreads) void add_ln_fwd_kernel(const T* __restrict__ a, const T* __restrict__ x,
                                                               const T* __restrict__ gamma, const T* __restrict__ beta,
                                                               T* __restrict__ xnew, T* __restrict__ y,
@@ -38,76 +35,60 @@ __global__ __launch_bounds__(kThreads) void add_ln_fwd_kernel(const T* __restric
                                                               float eps) {
   constexpr int N = Vec<T>::N;
   const int lane = threadIdx.x & 63;
-  const long long row0 = ((long long)blockIdx.x * kRowsPerWg + (threadIdx.x >> 6)) * R;
-  if (row0 >= rows) return;
+  const long long row = (long long)blockIdx.x * kRowsPerWg + (threadIdx.x >> 6);
+  if (row >= rows) return;
   const int cv = C / N;
-  Vec<T> vx[R][NV], va[R][NV];
+  const Vec<T>* xr = reinterpret_cast<const Vec<T>*>(x + row * C);
+  const Vec<T>* ar = a ? reinterpret_cast<const Vec<T>*>(a + row * C) : nullptr;
+  float f[NV][N];
+  float sum = 0.f;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const long long row = row0 + r < rows ? row0 + r : rows - 1;   // a clamped duplicate row is loaded and never stored
+  for (int k = 0; k < NV; ++k) {
+    const int j = lane + 64 * k;
+    if (j < cv) {
+      Vec<T> v = xr[j];
+      if (ar != nullptr) {
+        const Vec<T> w = ar[j];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int j = lane + 64 * k;
-      if (j < cv) {
-        vx[r][k] = reinterpret_cast<const Vec<T>*>(x + row * C)[j];
-        if (a != nullptr) va[r][k] = reinterpret_cast<const Vec<T>*>(a + row * C)[j];
+        for (int e = 0; e < N; ++e) v.v[e] = Traits<T>::from_f32(Traits<T>::to_f32(v.v[e]) + Traits<T>::to_f32(w.v[e]));
+        reinterpret_cast<Vec<T>*>(xnew + row * C)[j] = v;
       }
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        f[k][e] = Traits<T>::to_f32(v.v[e]);
+        sum += f[k][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < N; ++e) f[k][e] = 0.f;
     }
   }
+  const float mean = wave_reduce_sum(sum) / (float)C;
+  float sq = 0.f;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const long long row = row0 + r;
-    if (row >= rows) break;
-    float f[NV][N];
-    float sum = 0.f;
+  for (int k = 0; k < NV; ++k)
+    if (lane + 64 * k < cv) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int j = lane + 64 * k;
-      if (j < cv) {
-        Vec<T> v = vx[r][k];
-        if (a != nullptr) {
-#pragma unroll
-          for (int e = 0; e < N; ++e)
-            v.v[e] = Traits<T>::from_f32(Traits<T>::to_f32(v.v[e]) + Traits<T>::to_f32(va[r][k].v[e]));
-          reinterpret_cast<Vec<T>*>(xnew + row * C)[j] = v;
-        }
-#pragma unroll
-        for (int e = 0; e < N; ++e) {
-          f[k][e] = Traits<T>::to_f32(v.v[e]);
-          sum += f[k][e];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < N; ++e) f[k][e] = 0.f;
+      for (int e = 0; e < N; ++e) {
+        const float d = f[k][e] - mean;
+        sq += d * d;
       }
     }
-    const float mean = wave_reduce_sum(sum) / (float)C;
-    float sq = 0.f;
+  const float rstd = rsqrtf(wave_reduce_sum(sq) / (float)C + eps);
+  if (stats != nullptr && lane == 0) {
+    stats[row * 2] = mean;
+    stats[row * 2 + 1] = rstd;
+  }
 #pragma unroll
-    for (int k = 0; k < NV; ++k)
-      if (lane + 64 * k < cv) {
+  for (int k = 0; k < NV; ++k) {
+    const int j = lane + 64 * k;
+    if (j < cv) {
+      const Vec<T> gm = reinterpret_cast<const Vec<T>*>(gamma)[j], bt = reinterpret_cast<const Vec<T>*>(beta)[j];
+      Vec<T> o;
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-          const float d = f[k][e] - mean;
-          sq += d * d;
-        }
-      }
-    const float rstd = rsqrtf(wave_reduce_sum(sq) / (float)C + eps);
-    if (stats != nullptr && lane == 0) {
-      stats[row * 2] = mean;
-      stats[row * 2 + 1] = rstd;
-    }
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int j = lane + 64 * k;
-      if (j < cv) {
-        const Vec<T> gm = reinterpret_cast<const Vec<T>*>(gamma)[j], bt = reinterpret_cast<const Vec<T>*>(beta)[j];
-        Vec<T> o;
-#pragma unroll
-        for (int e = 0; e < N; ++e)
-          o.v[e] = Traits<T>::from_f32((f[k][e] - mean) * rstd * Traits<T>::to_f32(gm.v[e]) + Traits<T>::to_f32(bt.v[e]));
-        reinterpret_cast<Vec<T>*>(y + row * C)[j] = o;
-      }
+      for (int e = 0; e < N; ++e)
+        o.v[e] = Traits<T>::from_f32((f[k][e] - mean) * rstd * Traits<T>::to_f32(gm.v[e]) + Traits<T>::to_f32(bt.v[e]));
+      reinterpret_cast<Vec<T>*>(y + row * C)[j] = o;
     }
   }
 }
@@ -169,16 +150,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <typename T, int NV>
 int fwd_launch(const void* a, const void* x, const void* gamma, const void* beta, void* xnew, void* y, float* stats,
                long long rows, int C, float eps, hipStream_t s) {
-  // two rows per wave while that still leaves >= 4 workgroups per CU; the small levels keep one row per wave
-  if (NV <= 4 && rows >= 8192) {
-    const unsigned grid = (unsigned)((rows + 2 * kRowsPerWg - 1) / (2 * kRowsPerWg));
-    hipLaunchKernelGGL((add_ln_fwd_kernel<T, NV, 2>), dim3(grid), dim3(kThreads), 0, s, (const T*)a, (const T*)x,
-                       (const T*)gamma, (const T*)beta, (T*)xnew, (T*)y, stats, rows, C, eps);
-  } else {
-    const unsigned grid = (unsigned)((rows + kRowsPerWg - 1) / kRowsPerWg);
-    hipLaunchKernelGGL((add_ln_fwd_kernel<T, NV, 1>), dim3(grid), dim3(kThreads), 0, s, (const T*)a, (const T*)x,
-                       (const T*)gamma, (const T*)beta, (T*)xnew, (T*)y, stats, rows, C, eps);
-  }
+  const unsigned grid = (unsigned)((rows + kRowsPerWg - 1) / kRowsPerWg);
+  hipLaunchKernelGGL((add_ln_fwd_kernel<T, NV>), dim3(grid), dim3(kThreads), 0, s, (const T*)a, (const T*)x,
+                     (const T*)gamma, (const T*)beta, (T*)xnew, (T*)y, stats, rows, C, eps);
   return check_launch();
 }
 
