@@ -591,16 +591,20 @@ struct Plan {
   int bm, bn, splits;
 };
 
-// Tile and split choice.  What the sweep over every UNet shape showed (tools/conv_tune.py, profiles/): the best plan
-// puts about 480 workgroups on the chip (just under two per CU) with the largest tile that gets there, splitting the
-// GEMM depth as needed (at most 16 ways, at least 3 k-steps per slice), and avoids tiles that pad the channel count
-// (320 outputs: 64-wide tiles).  Measured plans for the UNet's own shapes live in conv_plans.json on the host side;
-// this is the rule for everything else.
+// Tile and split choice for shapes without a measured plan (conv_plans.json on the host side holds the measured ones
+// for the SD-1.x UNet).  A time estimate in microseconds per candidate:
+//   compute  = flops x padding waste x fill / rate(tile): about 480 workgroups fill the chip (just under two per CU);
+//              fewer leave CUs idle, more run in rounds of 512; the smaller tiles run at a lower rate (operand reuse);
+//   split-K  = the f32 partial slabs written and read back (splits x M x N x 8 bytes at ~4 TB/s) + the sum launch —
+//              what makes a split pay at M = 256 (30 MB of slabs for 12 splits) and hurt at M = 49 152 (500 MB for 4: the
+//              first rule, a flat 1.5 % per split, chose 4 splits for SDXL's 128x128 level and doubled its time).
+// At most 16 splits, at least 3 k-steps per slice; 320 outputs prefer 64-wide tiles (no channel padding).
 Plan choose_plan(int M, int N, int steps) {
   const int cands[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-  const double tile_cost[3] = {1.0, 1.08, 1.22};   // relative time per flop of the tile shapes (operand reuse)
+  const double rate[3] = {700.0, 650.0, 570.0};   // TFLOP/s of a well-filled launch per tile shape (profiles/r2_conv_tune.txt)
+  const double flops = 2.0 * (double)M * (double)N * (double)steps * kKC;
   Plan best{64, 64, 1};
-  double best_cost = 1e30;
+  double best_us = 1e30;
   for (int ci = 0; ci < 3; ++ci) {
     const int bm = cands[ci][0], bn = cands[ci][1];
     const long long tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn, tiles = tm * tn;
@@ -608,12 +612,12 @@ Plan choose_plan(int M, int N, int steps) {
     const int max_s = steps / 3 < 16 ? (steps / 3 < 1 ? 1 : steps / 3) : 16;
     for (int s = 1; s <= max_s; ++s) {
       const double wgs = (double)tiles * s;
-      // fill: below ~480 workgroups CUs idle; above, whole extra rounds of ~512 resident workgroups
       const double fill = wgs <= 512.0 ? 480.0 / (wgs < 480.0 ? wgs : 480.0) : ((double)((long long)((wgs + 511) / 512)) * 512.0) / wgs;
-      const double split_cost = 1.0 + 0.015 * (s - 1);   // f32 partial slabs written and summed
-      const double cost = waste * tile_cost[ci] * fill * split_cost;
-      if (cost < best_cost) {
-        best_cost = cost;
+      const double compute_us = flops * waste * fill / (rate[ci] * 1e6);
+      const double split_us = s > 1 ? (double)s * (double)M * (double)N * 8.0 / 4.0e6 + 6.0 : 0.0;
+      const double us = compute_us + split_us;
+      if (us < best_us) {
+        best_us = us;
         best = Plan{bm, bn, s};
       }
     }

@@ -102,6 +102,28 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.ga_self_attn_fwd(p, p, p, p, None, 1, 8, 64, 44, 0, 0.1, 0, None) == -4            # D % 8 != 0
 
 
+def test_conv_plan_is_a_host_function(lib):
+    """ga_conv3x3_plan needs no device: the split-K choice prices the f32 partial slabs (a large-M shape is never split,
+    a small-M deep one is), the workspace it asks for matches the plan, and argument errors come back as codes."""
+    def plan(B, H, W, ci, co, st):
+        bm, bn, sp, ws = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+        rc = lib.ga_conv3x3_plan(B, H, W, ci, co, st, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp), ctypes.byref(ws))
+        return rc, bm.value, bn.value, sp.value, ws.value
+    rc, bm, bn, sp, ws = plan(3, 128, 128, 320, 320, 1)          # SDXL's top level, M = 49 152
+    assert rc == 0 and sp == 1 and ws == 0 and (bm, bn) in ((128, 64), (64, 64), (128, 128))
+    rc, bm, bn, sp, ws = plan(1, 16, 16, 1280, 1280, 1)          # M = 256, depth 11 520: split to fill the chip
+    assert rc == 0 and sp > 1 and ws == sp * 256 * 1280
+    rc, bm, bn, sp, ws = plan(1, 64, 64, 320, 320, 2)            # stride 2: output 32 x 32
+    assert rc == 0 and ws == (sp * 1024 * 320 if sp > 1 else 0)
+    assert plan(1, 16, 16, 100, 1280, 1)[0] == -2                # Cin not a multiple of 64
+    assert plan(1, 16, 16, 1280, 1280, 3)[0] == -2               # stride 3
+    assert lib.ga_conv3x3_nhwc(None, None, None, None, None, None, 1, 16, 16, 64, 64, 1, 64, 64, 1, 0, None) == -1
+    assert lib.ga_gemm_nt(None, None, None, None, None, None, 16, 64, 64, 64, 64, 1, 0, None) == -1
+    p = ctypes.c_void_p(4096)
+    assert lib.ga_gemm_nt(p, p, p, None, None, None, 16, 72, 64, 64, 64, 1, 0, None) == -2   # K not a multiple of 64
+    assert lib.ga_conv3x3_nhwc(p, p, p, None, None, None, 1, 16, 16, 64, 64, 1, 96, 64, 1, 0, None) == -2   # no 96-pixel tile
+
+
 def test_product_refuses_cpu_tensors():
     import torch
     from guided_attention_amd import ops
