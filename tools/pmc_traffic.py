@@ -57,11 +57,15 @@ CASES = {
         ("ga_group_norm_bwd", ["gn_bwd", 1, 320, 4096], dict(B=1, H=32, N=4096, D=320), gn_bytes(1, 320, 4096, True), "gn_+bwd"),
     ],
     "sd21": [
+        ("ga_conv3x3", ["conv", 3, 1280, 576, 1, 1280], dict(B=3, H=1280, N=576, D=1280), conv_bytes(3, 1280, 576, 1, 1280), "conv"),
+        ("ga_conv3x3", ["conv", 3, 320, 9216, 1, 320], dict(B=3, H=320, N=9216, D=320), conv_bytes(3, 320, 9216, 1, 320), "conv"),
         ("ga_conv3x3", ["conv", 3, 640, 2304, 1, 640], dict(B=3, H=640, N=2304, D=640), conv_bytes(3, 640, 2304, 1, 640), "conv"),
         ("ga_self_attn_fwd", ["sa_fwd", 3, 5, 9216, 64], dict(B=3, H=5, N=9216, D=64), sa_bytes(3, 5, 9216, 64, False), "self_attn_fwd"),
         ("ga_self_attn_fwd", ["sa_fwd", 1, 5, 9216, 64], dict(B=1, H=5, N=9216, D=64), sa_bytes(1, 5, 9216, 64, False), "self_attn_fwd"),
     ],
     "sdxl": [
+        ("ga_conv3x3", ["conv", 3, 1280, 1024, 1, 1280, "bf16"], dict(B=3, H=1280, N=1024, D=1280), conv_bytes(3, 1280, 1024, 1, 1280), "conv"),
+        ("ga_conv3x3", ["conv", 3, 320, 16384, 1, 320, "bf16"], dict(B=3, H=320, N=16384, D=320), conv_bytes(3, 320, 16384, 1, 320), "conv"),
         ("ga_conv3x3", ["conv", 3, 640, 4096, 1, 640, "bf16"], dict(B=3, H=640, N=4096, D=640), conv_bytes(3, 640, 4096, 1, 640), "conv"),
         ("ga_self_attn_fwd", ["sa_fwd", 3, 10, 4096, 64, "bf16"], dict(B=3, H=10, N=4096, D=64), sa_bytes(3, 10, 4096, 64, False), "self_attn_fwd"),
     ],
