@@ -711,6 +711,7 @@ CONV_SHAPES = [  # B, Cin, Cout, H, W, stride
     # chunks per split, 2 / 4 / 8 rows per tile
     (3, 128, 64, 8, 8, 1), (2, 128, 64, 64, 64, 1), (1, 192, 128, 32, 32, 1), (3, 128, 192, 16, 16, 1),
     (2, 128, 64, 3, 128, 1), (1, 64, 128, 4, 128, 1),    # 128-wide maps (SDXL's top level): one row per tile, 13-piece patch
+    (2, 64, 192, 64, 64, 1),   # activations outweigh the weights: the n-tile-fastest workgroup order inside an XCD's run
 ]
 
 
