@@ -625,7 +625,8 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
   }
 }
 
-// ---- small tensors (<= 256 pixels: the 16x16 and 8x8 levels): one launch, one workgroup per (image, group).
+// ---- small slabs (the 16x16 and 8x8 levels, and 32x32 at 640 channels: a group's slab of <= 20 480 elements): one launch,
+// one workgroup per (image, group).
 // The group's slab (HW pixels x C/G channels, <= 20 480 elements) is read once into LDS while the sums are taken,
 // reduced in-block, then normalised from LDS: a single ~4 us latency chain instead of three launches.
 constexpr int kSmallMaxElems = 20480;
@@ -816,7 +817,7 @@ int small_bwd(const void* x, const void* cb, const void* dy, const void* gamma, 
 
 bool small_path(int HW, int C, int G, size_t slab_bytes_per_elem) {
   const int Cg = C / G;
-  return HW <= 256 && (Cg & 1) == 0 && Cg <= 2048 && HW * Cg <= kSmallMaxElems &&
+  return HW <= 1024 && (Cg & 1) == 0 && Cg <= 2048 && HW * Cg <= kSmallMaxElems &&
          kSmallHeader + slab_bytes_per_elem * (size_t)HW * Cg <= kMaxLdsBytes;
 }
 

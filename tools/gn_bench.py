@@ -9,7 +9,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from guided_attention_amd import ops  # noqa: E402
 
 ops.load()
-shapes = [(1, 320, 4096), (3, 320, 4096), (1, 640, 4096), (1, 960, 4096), (1, 640, 1024), (1, 1280, 1024), (1, 1920, 1024),
+shapes = [(1, 320, 4096), (3, 320, 4096), (1, 640, 4096), (1, 960, 4096), (1, 640, 1024), (3, 640, 1024), (1, 1280, 1024), (1, 1920, 1024),
           (1, 1280, 256), (1, 2560, 256), (1, 1280, 64)]
 for B, C, HW in shapes:
     row = []
