@@ -460,3 +460,45 @@ def test_paint_with_words_pipeline_vs_oracle():
     assert (out.unet_calls["fwd_b1_grad"], out.unet_calls["bwd"]) == (s.calls["fwd_b1_grad"], s.calls["bwd"])
     err = np.abs(out.latents.float().cpu().numpy() - ref).max() / np.abs(ref).max()
     assert err < 5e-3, err
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_full_width_unet_own_convolutions_match_the_library(batch):
+    """The SD-1.x UNet at FULL width in fp16: one guidance-style forward + backward to the latents with the 3x3
+    convolutions on ga_conv3x3_nhwc (every real shape: measured plans, XCD-aware order, patch and per-tap variants,
+    split-K, bias + residual epilogue, the flipped pack in the backward) against the same UNet on the library
+    convolution.  Both accumulate in f32 and round once per layer: the results agree to fp16 rounding noise."""
+    from guided_attention_amd import ops
+    from guided_attention_amd.pipeline_guided_attention import GuidedAttention
+    from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        unet = UNet2DConditionModel(UNetConfig.sd15())
+    unet = unet.half().init_weights_(seed=11)
+    pipe = GuidedAttention(unet).to("cuda", torch.float16)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(batch, 4, 64, 64, generator=g).cuda().half()
+    ctx = torch.randn(batch, 77, 768, generator=g).cuda().half()
+    wgt = torch.randn(batch, 4, 64, 64, generator=g).cuda().half()
+
+    def run_once():
+        x = lat.clone().requires_grad_(True)
+        y = pipe.unet(x, 981, encoder_hidden_states=ctx).sample
+        (gx,) = torch.autograd.grad((y.float() * wgt.float()).sum(), [x])
+        return y.detach().float(), gx.float()
+
+    with ops.census_scope() as cs:
+        y_own, g_own = run_once()
+    assert sum(n for k, n in cs.launches.items() if k[0] == "conv3x3") > 80      # the HIP convolution really ran
+    pipe.unet.set_fused_impl(ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm), None)
+    bench_mode, torch.backends.cudnn.benchmark = torch.backends.cudnn.benchmark, False   # no exhaustive library search here
+    try:
+        with ops.census_scope() as cs:
+            y_lib, g_lib = run_once()
+    finally:
+        torch.backends.cudnn.benchmark = bench_mode
+    assert not any(k[0] == "conv3x3" for k in cs.launches)
+    assert torch.isfinite(y_own).all() and torch.isfinite(g_own).all()
+    ey = float((y_own - y_lib).abs().max() / y_lib.abs().max())
+    eg = float((g_own - g_lib).abs().max() / g_lib.abs().max())
+    assert ey < 2e-2 and eg < 5e-2, (ey, eg)
