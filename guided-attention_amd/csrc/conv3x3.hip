@@ -11,13 +11,21 @@
 // slabs summed by a small epilogue kernel) so that every shape fills the chip.
 //
 // Mapping: 256 threads = 4 waves in a 2 x 2 grid over the macro-tile, each wave (BM/2) x (BN/2) as 32 x 32 MFMA blocks
-// (v_mfma_f32_32x32x16: 16 accumulator registers per block).  Per k-step of 32 channels of one tap the workgroup stages
-// an A tile [BM pixels][32] (rows gathered from the shifted input pixels, zeros outside the image) and a B tile
-// [BN][32] of the pre-packed weights Wp[tap][n][c] in LDS — both "row = m or n, depth contiguous", 80-byte rows:
-// the 16-byte fragment reads of the 32x32x16 operands are conflict-free — double-buffered, next step prefetched to
-// registers under the MFMAs, one barrier per step.  The weight fragment is the MFMA's A operand and the pixel fragment
-// its B operand, so a lane ends up with 4 consecutive output channels of ONE pixel per register quad: the tile goes
-// through LDS once more and leaves as whole 16-byte row pieces with bias and residual added on the way.
+// (v_mfma_f32_32x32x16: 16 accumulator registers per block).  The weight fragment is the MFMA's A operand and the
+// pixel fragment its B operand, so a lane ends up with 4 consecutive output channels of ONE pixel per register quad: the
+// tile goes through LDS once more and leaves as whole 16-byte row pieces with bias and residual added on the way.
+// LDS rows hold 64 channels (one k-step) at a 144-byte stride: the 16-byte fragment reads are conflict-free.
+// Two kernels share the tile mapping and the epilogue:
+//   conv3x3_kernel        per k-step (64 channels of one tap) an A tile [BM pixels][64] gathered from the shifted input
+//                         pixels and a B tile [BN][64] of the pre-packed weights Wp[tap][n][c], double-buffered, two
+//                         steps of loads in flight in two register sets, one barrier per step.  Any shape: stride 2,
+//                         8x8 maps, maps whose rows do not tile into whole 128- / 64-pixel tiles, ga_gemm_nt (one tap).
+//   conv3x3_patch_kernel  stride 1, tiles of whole image rows: the (rows + 2) x (W + 2) input patch of the tile is staged
+//                         ONCE per 64-channel chunk and all nine taps read it at shifted addresses; weights per
+//                         (chunk, tap) with 3 - 6 steps in flight.  See the comment above it.
+// Staging loads are raw buffer loads with 32-bit offsets; whatever lies outside the image or the tile carries an offset
+// past the descriptor's size and comes back as zeros (no branch, no zero-fill pass).  Workgroups are mapped XCD-aware
+// (tile_of_workgroup): the tiles that share a weight slice (or a pixel slab) run on one XCD's L2.
 // The backward-to-input of a stride-1 convolution is the same kernel on the upstream gradient with the weights
 // flipped and transposed (pre-packed once per weight version by the host).
 #include <cstdlib>
