@@ -462,7 +462,7 @@ def test_paint_with_words_pipeline_vs_oracle():
     assert err < 5e-3, err
 
 
-@pytest.mark.parametrize("batch", [1, 3])
+@pytest.mark.parametrize("batch", [1, 2, 3])   # 2 = the CFG pass: no measured plans, the rule of ga_conv3x3_plan
 def test_full_width_unet_own_convolutions_match_the_library(batch):
     """The SD-1.x UNet at FULL width in fp16: one guidance-style forward + backward to the latents with the 3x3
     convolutions on ga_conv3x3_nhwc (every real shape: measured plans, XCD-aware order, patch and per-tap variants,
