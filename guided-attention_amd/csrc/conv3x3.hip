@@ -78,8 +78,17 @@ struct ConvArgs {
   int tm, tn;       // m tiles, n tiles of the launch (grid = tm * tn * splits workgroups, one dimension)
   int n_fastest;    // workgroup order inside an XCD's run: n tiles fastest (1) or m tiles fastest (0)
   int pad;          // 1: 3x3 taps around the pixel; 0: a single tap (plain GEMM  Y[m][n] = sum_c X[m][c] W[n][c])
+  int lane_rot;     // patch kernel on 16-wide maps: lanes 16..31 of a 32-pixel block take their row's pixels rotated by 2
+                    // (see lane_pixel); 0 everywhere else
   unsigned x_bytes, w_bytes;   // sizes of X and Wp (buffer descriptors: loads beyond them return zeros); < 2 GiB
 };
+
+// Which pixel of its 32-pixel block an MFMA lane (0..31) owns.  Identity, except in the patch kernel on 16-wide maps: a
+// block is two image rows there, lanes 16..31 read the patch 18 (not 16) rows further, and the bank of a 144-byte row
+// repeats every 16 rows — within the hardware's 16-lane read groups two lanes then meet on one bank (30 % of the LDS
+// cycles were conflict cycles on the 16x16 level).  Letting lane 16 + j own pixel (j - 2) mod 16 of the second row puts
+// every lane of a group on its own bank again; the epilogue follows the same map.
+__device__ __forceinline__ int lane_pixel(int fr, int rot) { return fr < 16 || rot == 0 ? fr : 16 + ((fr - 16 - rot) & 15); }
 
 // Workgroup -> (m tile, n tile, k split), XCD-aware.  The hardware deals consecutive workgroup ids round-robin over the
 // 8 XCDs (ids b and b + 8 share an L2).  The workgroups that read the same weight slice Wp[taps of split][n tile] are
@@ -115,7 +124,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T
                                               int split) {
   constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, JN = WN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1, fr = lane_pixel(lane & 31, a.lane_rot), fh = lane >> 5;
   if constexpr (OUT_F32) {
     float* dst = part + (size_t)split * a.M * a.Cout;
 #pragma unroll
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
   int pix_base[IM];   // element offset into the patch
 #pragma unroll
   for (int i = 0; i < IM; ++i) {
-    const int pm = wm * WM + i * 32 + fr;
+    const int pm = wm * WM + i * 32 + lane_pixel(fr, a.lane_rot);
     const int seg = pm / seg_px, rem = pm - seg * seg_px;
     const int r = rem / a.W, c = rem - r * a.W;
     pix_base[i] = ((seg * seg_rows + r) * PW + c) * kLD + fh * 8;
@@ -665,6 +674,7 @@ template <typename T, int BM, int BN>
 int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T* residual, const ConvArgs& a_in, int splits,
                 hipStream_t s) {
   ConvArgs a = a_in;
+  a.lane_rot = 0;
   a.tm = (a.M + BM - 1) / BM;
   a.tn = (a.Cout + BN - 1) / BN;
   {  // bytes that reach the fabric if each XCD fetches what its run of workgroups shares once
@@ -691,7 +701,10 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T
       return launch_split_sum<T>(ws, splits, Y, bias, residual, a, s);
     }
   }
-  if (patch) a.steps_per = (a.Cin / kKC + splits - 1) / splits;   // this variant splits the depth by channel chunks
+  if (patch) {
+    a.steps_per = (a.Cin / kKC + splits - 1) / splits;   // this variant splits the depth by channel chunks
+    a.lane_rot = a.W == 16 ? 2 : 0;
+  }
   if (splits == 1) {
     if (patch)
       hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, false>), grid, dim3(kThreads), 0, s, X, Wp, Y, (float*)nullptr,
