@@ -461,7 +461,7 @@ class UNet2DConditionModel(nn.Module):
         """Every ResnetBlock2D adds time_emb_proj(SiLU(temb)): 22 GEMMs with one row of input each.  They are
         evaluated as ONE GEMM against the row-concatenated weights (built once; rebuilt if a weight changes) and
         handed to the blocks as views."""
-        blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        blocks = self._resnet_blocks()
         key = tuple((b.time_emb_proj.weight.data_ptr(), b.time_emb_proj.weight._version, b.time_emb_proj.bias._version,
                      b.conv1.bias._version) for b in blocks)
         cache = self.__dict__.get("_tproj_cache")
@@ -510,12 +510,10 @@ class UNet2DConditionModel(nn.Module):
         weights only, so it is computed once per (timestep, batch) and kept (the reference recomputes ~15 small
         kernels per UNet call; with batch > 1 the per-block column slices of a row-major projection also cost one
         copy each).  Inference-time only: the cache is bypassed while any time-embedding weight requires grad."""
-        blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
-        tw = [self.time_embedding.linear_1.weight, self.time_embedding.linear_1.bias, self.time_embedding.linear_2.weight,
-              self.time_embedding.linear_2.bias]
-        wkey = tuple((p.data_ptr(), p._version) for p in tw) + tuple(
-            (b.time_emb_proj.weight.data_ptr(), b.time_emb_proj.weight._version, b.time_emb_proj.bias._version,
-             b.conv1.bias._version) for b in blocks)
+        # this runs on the host before EVERY hipGraph replay: the module walk (662 modules) and the 22-block key used to
+        # cost ~0.5 ms per call — a device-idle gap of that length at the start of each of the ~120 passes of an image
+        blocks = self._resnet_blocks()
+        wkey = tuple((p.data_ptr(), p._version) for p in self._time_params())
         cache = self.__dict__.setdefault("_tp_cache", {"key": None, "items": {}})
         if cache["key"] != wkey:
             cache["key"], cache["items"] = wkey, {}
@@ -535,8 +533,26 @@ class UNet2DConditionModel(nn.Module):
             cache["items"][k] = flat
         return flat
 
+    def _resnet_blocks(self):
+        """The ResnetBlock2D modules in registration order (the module tree is fixed after construction)."""
+        blocks = self.__dict__.get("_resnets")
+        if blocks is None:
+            blocks = self.__dict__["_resnets"] = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        return blocks
+
+    def _time_params(self):
+        """Every parameter the timestep-only part of the UNet reads (their storage and version key its cache)."""
+        ps = self.__dict__.get("_time_ps")
+        if ps is None:
+            ps = [self.time_embedding.linear_1.weight, self.time_embedding.linear_1.bias, self.time_embedding.linear_2.weight,
+                  self.time_embedding.linear_2.bias]
+            for b in self._resnet_blocks():
+                ps += [b.time_emb_proj.weight, b.time_emb_proj.bias, b.conv1.bias]
+            self.__dict__["_time_ps"] = ps
+        return ps
+
     def _split_time_projection(self, flat, batch):
-        blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        blocks = self._resnet_blocks()
         want = batch * sum(b.time_emb_proj.out_features for b in blocks)
         if flat.numel() != want:
             raise ValueError(f"time projection buffer has {flat.numel()} elements, expected {want} for batch {batch}")
