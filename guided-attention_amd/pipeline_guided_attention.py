@@ -672,10 +672,16 @@ class GuidedAttention:
                             noise = torch.randn(latents.shape, generator=renoise_gen, device=device).to(latents.dtype)
                         latents = ops.latent_axpby(latents, noise, math.sqrt(Bt), math.sqrt(1 - Bt))
 
-        for text, dev_scalar in self._deferred_log:  # device scalars are read once, after the loop
-            helpers.log(text + str(dev_scalar.item()))
+        if self._deferred_log:  # device scalars are read once, after the loop, in ONE device->host copy
+            vals = torch.stack([v.detach().reshape(()).float() for _, v in self._deferred_log]).cpu()
+            for (text, _), v in zip(self._deferred_log, vals):
+                helpers.log(text + str(v.item()))
         self._deferred_log = []
         shift = 0
+        if self._deferred_losses:  # likewise the packed loss tables of the log-only steps (same plan: same length)
+            host_rows = torch.stack([parts[4] for _, _, parts in self._deferred_losses]).cpu()
+            self._deferred_losses = [(pos, step, parts[:4] + (host_rows[j],))
+                                     for j, (pos, step, parts) in enumerate(self._deferred_losses)]
         for pos, step, parts in self._deferred_losses:  # loss logs of the log-only steps, inserted where they belong
             state.cur_time_step_iter, state.sub_iteration = step, 0
             mark = len(helpers.lines)
