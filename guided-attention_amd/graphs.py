@@ -175,8 +175,7 @@ class GraphRunner:
 
     def cfg_forward(self, latents, t, store):
         self._set_t(t, 2)
-        self.lat2[0].copy_(latents[0])
-        self.lat2[1].copy_(latents[0])
+        self.lat2.copy_(latents[0:1].expand_as(self.lat2))   # one broadcast copy instead of one launch per sample
         self.g_cfg.replay()
         ops.add_census(self.launches["cfg"])
         self._publish(store, self.store_cfg)
@@ -185,8 +184,7 @@ class GraphRunner:
     def joint_forward(self, latents, t, store):
         """-> (loss parts of the guidance evaluation, CFG noise prediction (2, ...)) from one batch-3 replay."""
         self._set_t(t, 3)
-        for j in range(3):
-            self.lat3[j].copy_(latents[0])
+        self.lat3.copy_(latents[0:1].expand_as(self.lat3))
         self.g_joint.replay()
         ops.add_census(self.launches["joint"])
         self._publish(store, self.store_joint)

@@ -437,9 +437,12 @@ class UNet2DConditionModel(nn.Module):
 
     # ---- attention-processor registry (diffusers protocol used by utils/ptp_utils.py:149-175)
     def _attention_modules(self):
-        for name, mod in self.named_modules():
-            if isinstance(mod, Attention):
-                yield name, mod
+        """(name, module) of every attention layer, in registration order (the module tree is fixed after construction;
+        register_attention_control asks twice per image)."""
+        mods = self.__dict__.get("_attn_mods")
+        if mods is None:
+            mods = self.__dict__["_attn_mods"] = [(n, m) for n, m in self.named_modules() if isinstance(m, Attention)]
+        return mods
 
     @property
     def attn_processors(self):
