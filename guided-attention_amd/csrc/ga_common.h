@@ -52,27 +52,36 @@ struct Traits<_Float16> {
 template <>
 struct Traits<bf16_t> {
   using elem = bf16_t;
+  // Four bf16 bit patterns in ONE vector register pair.  (A struct holding `bf16_t v[4]` is an aggregate the compiler
+  // has to scalarise: in the self-attention kernels with two query blocks per wave the 8-fragment probability array
+  // stayed a 64-byte private-segment array, i.e. scratch memory traffic in the inner loop.)  Elements are reached
+  // through a proxy, so `f[i] = from_f32(x)` / `to_f32(f[i])` read as for the other types.
   struct frag {
-    bf16_t v[4];
-    __device__ __forceinline__ bf16_t& operator[](int i) { return v[i]; }
-    __device__ __forceinline__ const bf16_t& operator[](int i) const { return v[i]; }
+    s16x4 v;
+    struct ref {
+      s16x4& v;
+      int i;
+      __device__ __forceinline__ operator bf16_t() const { return bf16_t{(uint16_t)v[i]}; }
+      __device__ __forceinline__ ref& operator=(bf16_t x) {
+        v[i] = (short)x.bits;
+        return *this;
+      }
+    };
+    __device__ __forceinline__ ref operator[](int i) { return ref{v, i}; }
+    __device__ __forceinline__ bf16_t operator[](int i) const { return bf16_t{(uint16_t)v[i]}; }
   };
   static constexpr int kDtype = GA_BF16;
   __device__ static __forceinline__ float to_f32(elem x) { return bf16_to_f32(x.bits); }
   __device__ static __forceinline__ elem from_f32(float x) { return elem{f32_to_bf16(x)}; }
   __device__ static __forceinline__ elem zero() { return elem{0}; }
   __device__ static __forceinline__ f32x4 mma16(frag a, frag b, f32x4 acc) {
-    s16x4 av = {(short)a.v[0].bits, (short)a.v[1].bits, (short)a.v[2].bits, (short)a.v[3].bits};
-    s16x4 bv = {(short)b.v[0].bits, (short)b.v[1].bits, (short)b.v[2].bits, (short)b.v[3].bits};
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.v, b.v, acc, 0, 0, 0);
   }
   __device__ static __forceinline__ f32x4 mma16x2(frag a0, frag a1, frag b0, frag b1, f32x4 acc) {
-    struct Pair {
-      frag lo, hi;
-    };
-    const bf16x8 a = __builtin_bit_cast(bf16x8, Pair{a0, a1});
-    const bf16x8 b = __builtin_bit_cast(bf16x8, Pair{b0, b1});
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 a = __builtin_shufflevector(a0.v, a1.v, 0, 1, 2, 3, 4, 5, 6, 7);
+    const s16x8 b = __builtin_shufflevector(b0.v, b1.v, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
   }
 };
 

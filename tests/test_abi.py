@@ -38,6 +38,21 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, n), n
 
 
+def test_no_kernel_uses_scratch_memory(lib):
+    """Code-object metadata of every gfx950 kernel in the library: no private segment (a per-lane stack array the
+    compiler failed to keep in registers is scratch-memory traffic in the inner loop — round 2 shipped eight bf16
+    self-attention kernels with 64 bytes of it) and no spilled vector registers."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import code_object_check
+    from guided_attention_amd import _lib
+    ks = code_object_check.kernels(_lib.LIB_PATH)
+    assert len(ks) > 300, len(ks)
+    assert any("self_attn_fwd_kernel" in k["name"] for k in ks) and any("conv3x3" in k["name"] for k in ks)
+    bad = [(k["name"], k.get("private_segment_fixed_size"), k.get("vgpr_spill_count")) for k in code_object_check.offenders(ks)]
+    assert not bad, bad
+
+
 def test_version_and_strerror(lib):
     m = re.search(r"#define GA_VERSION (\d+)", HEADER.read_text())
     assert lib.ga_version() == int(m.group(1))
