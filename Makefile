@@ -9,7 +9,7 @@ LIB     := guided-attention_amd/libga_hip.so
 # v_accvgpr_read/write traffic around every softmax step (108 -> 0 per loop iteration in self_attn_fwd)
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form
 
-all: $(LIB) oracle
+all: $(LIB)
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/ga_common.h $(CSRC)/attn_common.h include/ga_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -17,11 +17,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/ga_common.h $(CSRC)/attn_common.h include/ga_
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
-oracle:
-	$(MAKE) -C oracle
-
 clean:
 	rm -f $(OBJS) $(LIB)
-	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all clean

@@ -56,6 +56,8 @@ def parse(argv=None):
     ap.add_argument("--two-pass-steps", type=int, default=1,
                     help="after the timed region, also time this many images with the two-pass form of the loss-only "
                          "steps and report it beside the headline (0 = skip)")
+    ap.add_argument("--launch-timeout", type=float, default=3300.0,
+                    help="self-launched ranks (--gpus N run directly) are terminated after this many seconds")
     ap.add_argument("--launch-check", action="store_true",
                     help="only exercise the N-rank launch + rendezvous (gloo when no GPU is visible) and print one line")
     return ap.parse_args(argv)
@@ -82,28 +84,44 @@ def rank_envs(n, port, base=None):
     return envs
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, deadline_s=3300.0):
     """Start n copies of this script, one per GPU.  The parent has made no GPU call and execs nothing: children are
     ordinary subprocesses; rank 0 inherits stdout (its JSON line is THE line), the other ranks' stdout is dropped,
-    stderr is shared.  Returns the worst child return code; if one rank dies the others are terminated."""
+    stderr is shared.  Returns the worst child return code; if one rank dies the others are terminated, and so are all
+    of them when the deadline passes or the parent is interrupted (no rank is left holding a GPU or the port)."""
     port = free_port()
     procs = []
-    for r, env in enumerate(rank_envs(n, port)):
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
     worst = 0
-    alive = set(range(n))
-    while alive:
-        for r in sorted(alive):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            alive.discard(r)
-            if rc != 0:
-                worst = worst or rc
-                for o in alive:          # a rank failed: the others would wait in a collective forever
-                    procs[o].terminate()
-        time.sleep(0.2)
+    try:
+        for r, env in enumerate(rank_envs(n, port)):
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+        alive = set(range(n))
+        t_end = time.monotonic() + deadline_s
+        while alive:
+            for r in sorted(alive):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                alive.discard(r)
+                if rc != 0:
+                    worst = worst or rc
+                    for o in alive:          # a rank failed: the others would wait in a collective forever
+                        procs[o].terminate()
+            if alive and time.monotonic() > t_end:
+                print(f"bench.py: ranks {sorted(alive)} still running after {deadline_s:.0f} s: terminating", file=sys.stderr)
+                worst = worst or 124
+                break
+            time.sleep(0.2)
+    finally:
+        stragglers = [p for p in procs if p.poll() is None]
+        for p in stragglers:
+            p.terminate()
+        for p in stragglers:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
     return worst
 
 
@@ -416,7 +434,7 @@ def main(argv=None):
     args = parse(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
         # run directly with --gpus N: start the N ranks ourselves.  Nothing above touched the GPU.
-        raise SystemExit(launch_ranks(args.gpus, argv))
+        raise SystemExit(launch_ranks(args.gpus, argv, args.launch_timeout))
     if args.launch_check:
         return launch_check()
     from guided_attention_amd import ops, parallel

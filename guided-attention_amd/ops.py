@@ -792,7 +792,10 @@ def conv3x3_packed_weights(weight, transpose_flip):
         check(load().ga_conv3x3_pack_weights(_ptr(weight), _ptr(hit), Cout, Cin, so, si, sy, sx, int(bool(transpose_flip)),
                                              dtype_code(weight), stream_ptr()), "ga_conv3x3_pack_weights")
         if len(_conv_pack_cache) > 512:
-            _conv_pack_cache.clear()
+            # captured hipGraphs read the packs by raw pointer: only entries whose weight tensor is gone may be dropped
+            # (a live weight's pack must stay where it is for as long as a graph may replay against it)
+            for dead in [k for k, (ref, _) in _conv_pack_cache.items() if ref() is None]:
+                del _conv_pack_cache[dead]
         _conv_pack_cache[key] = (weakref.ref(weight), hit)
     return hit
 

@@ -46,34 +46,32 @@ def text_under_image(image, text, text_color=(0, 0, 0)):
 
 
 def view_images(images, num_rows=1, offset_ratio=0.02, display_image=True):
-    """Grid of equally sized (h, w, 3) images, white gutters (reference :26-56); returns the PIL image."""
+    """Tile equally sized (h, w, 3) panels into `num_rows` rows separated by white gutters of `offset_ratio` of the
+    panel height and return the PIL image — the notebook helper of the reference (:26-56), including its habit of
+    appending `len(images) % num_rows` blank panels before the column count is taken."""
     import numpy as np
     from PIL import Image
-    if type(images) is list:
-        num_empty = len(images) % num_rows
-    elif images.ndim == 4:
-        num_empty = images.shape[0] % num_rows
-    else:
-        images = [images]
-        num_empty = 0
-    empty = np.ones(images[0].shape, dtype=np.uint8) * 255
-    images = [im.astype(np.uint8) for im in images] + [empty] * num_empty
-    num_items = len(images)
-    h, w, _ = images[0].shape
-    offset = int(h * offset_ratio)
-    num_cols = num_items // num_rows
-    canvas = np.ones((h * num_rows + offset * (num_rows - 1), w * num_cols + offset * (num_cols - 1), 3), dtype=np.uint8) * 255
-    for i in range(num_rows):
-        for j in range(num_cols):
-            canvas[i * (h + offset): i * (h + offset) + h, j * (w + offset): j * (w + offset) + w] = images[i * num_cols + j]
-    pil_img = Image.fromarray(canvas)
+    single = not isinstance(images, list) and np.ndim(images) != 4
+    panels = [np.asarray(p, dtype=np.uint8) for p in ([images] if single else images)]
+    h, w = panels[0].shape[:2]
+    panels += [np.full_like(panels[0], 255)] * (0 if single else len(panels) % num_rows)
+    cols, gap = len(panels) // num_rows, int(h * offset_ratio)
+    v_gutter = np.full((h, gap, 3), 255, np.uint8)
+    strips = []
+    for r in range(num_rows):
+        row = panels[r * cols:(r + 1) * cols]
+        parts = [x for panel in row for x in (panel, v_gutter)][:-1]          # panel | gutter | panel | ... | panel
+        strips.append(np.concatenate(parts, axis=1))
+        strips.append(np.full((gap, strips[-1].shape[1], 3), 255, np.uint8))
+    sheet = Image.fromarray(np.concatenate(strips[:-1], axis=0))
     if display_image:
         try:
             from IPython.display import display
-            display(pil_img)
         except ImportError:
-            pass
-    return pil_img
+            display = None
+        if display is not None:
+            display(sheet)
+    return sheet
 
 
 class ProbsNotCaptured:

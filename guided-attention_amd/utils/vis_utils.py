@@ -11,15 +11,16 @@ from .ptp_utils import AttentionStore, aggregate_attention
 
 
 def get_image_grid(images: List[Image.Image]) -> Image.Image:
-    """Near-square grid, row-major (reference utils/vis_utils.py:63-73)."""
-    num_images = len(images)
-    cols = int(math.ceil(math.sqrt(num_images)))
-    rows = int(math.ceil(num_images / cols))
-    width, height = images[0].size
-    grid_image = Image.new("RGB", (cols * width, rows * height))
-    for i, img in enumerate(images):
-        grid_image.paste(img, ((i % cols) * width, (i // cols) * height))
-    return grid_image
+    """The images of a run on one sheet, filled row by row; the sheet is as square as the count allows (ceil(sqrt(n))
+    columns), unused cells stay black — what run.py:131 saves next to the per-seed images (reference :63-73)."""
+    cols = math.isqrt(max(len(images) - 1, 0)) + 1
+    rows = -(-len(images) // cols)
+    cell_w, cell_h = images[0].size
+    sheet = Image.new("RGB", (cols * cell_w, rows * cell_h))
+    for k, im in enumerate(images):
+        r, c = divmod(k, cols)
+        sheet.paste(im, (c * cell_w, r * cell_h))
+    return sheet
 
 
 def show_image_relevance(image_relevance, image: Image.Image, relevnace_res=16):

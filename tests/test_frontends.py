@@ -13,6 +13,41 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 
 
+def test_gui_rejects_a_second_generation_while_one_runs(tmp_path, monkeypatch):
+    """The captured hipGraphs replay on static buffers: overlapping POSTs must not run concurrently (409 busy)."""
+    import threading
+    pytest.importorskip("flask")
+    from guided_attention_amd import gui
+    from guided_attention_amd.config import RunConfig
+    from guided_attention_amd.utils import shared_state as state
+    state.config = RunConfig(meta_prompt="x", output_path=str(tmp_path))
+    started, release, calls = threading.Event(), threading.Event(), []
+    png = tmp_path / "out.png"
+    png.write_bytes(b"\x89PNG")
+
+    def slow_execute(config):
+        calls.append(config.meta_prompt)
+        started.set()
+        assert release.wait(30)
+        return png
+
+    monkeypatch.setattr(gui, "_execute", slow_execute)
+    first = {}
+    t = threading.Thread(target=lambda: first.update(r=gui.app.test_client().post(
+        "/execute_function", data=json.dumps({"variable1": "a [cat:.1,.1,.5,.5]"}), content_type="application/json")))
+    t.start()
+    assert started.wait(30)
+    second = gui.app.test_client().post("/execute_function", data=json.dumps({"variable1": "a [dog:.1,.1,.5,.5]"}),
+                                        content_type="application/json")
+    assert second.status_code == 409 and "busy" in second.get_json()["error"]
+    release.set()
+    t.join(30)
+    assert first["r"].status_code == 200 and calls == ["a [cat:.1,.1,.5,.5]"]
+    third = gui.app.test_client().post("/execute_function", data=json.dumps({"variable1": "a [dog:.1,.1,.5,.5]"}),
+                                       content_type="application/json")
+    assert third.status_code == 200 and len(calls) == 2
+
+
 def test_gui_contract(tmp_path, monkeypatch):
     """POST /execute_function {variable1} -> config.meta_prompt set, ONE random seed, execute() called, the PNG copied
     to static/output.png, {"result": path} returned (reference gui.py:25-38); GET / serves the page."""

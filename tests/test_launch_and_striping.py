@@ -29,6 +29,39 @@ def test_bench_gpus_2_self_launches_its_ranks():
     assert lines[0] == {"launch_check": True, "world": 2, "backend": "gloo", "sum": 3.0, "self_launched": True}
 
 
+def test_bench_gpus_8_launch_path_rendezvouses_eight_ranks():
+    """The form the driver's scaling run takes (`python bench.py --gpus 8 ...`), exercised without a node: eight gloo
+    ranks rendezvous on 127.0.0.1, all-reduce rank + 1 and rank 0 prints the one line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines == [{"launch_check": True, "world": 8, "backend": "gloo", "sum": 36.0, "self_launched": True}]
+
+
+def test_launcher_deadline_terminates_hung_ranks(tmp_path, monkeypatch):
+    """Ranks that never finish (stuck in a collective) are terminated at the deadline; the launcher returns non-zero and
+    leaves no child behind."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    script = tmp_path / "hang.py"
+    script.write_text("import time, os\nopen(os.environ['GA_PIDFILE'] + os.environ['RANK'], 'w').write(str(os.getpid()))\ntime.sleep(600)\n")
+    monkeypatch.setattr(bench, "__file__", str(script))
+    monkeypatch.setenv("GA_PIDFILE", str(tmp_path / "pid"))
+    rc = bench.launch_ranks(2, [], deadline_s=3.0)
+    assert rc == 124
+    for r in range(2):
+        pid = int((tmp_path / f"pid{r}").read_text())
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except OSError:
+            alive = False
+        assert not alive, f"rank {r} (pid {pid}) survived the launcher"
+
+
 def test_bench_under_an_external_launcher_does_not_spawn():
     """With RANK in the environment (torch.distributed.run) bench.py is a rank, not a launcher."""
     sys.path.insert(0, str(ROOT))
