@@ -11,7 +11,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wal
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/ga_common.h $(CSRC)/attn_common.h include/ga_hip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/ga_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

@@ -261,6 +261,16 @@ def kernel_work(key):
         return "hbm", esz * B * D * (4 if flag else 3)
     if kind == "conv3x3":                            # B, H = Cin, N = H*W, Kt = stride, D = Cout: 2 * M * 9 Cin * Cout
         return "mfma", 2.0 * B * (N // (Kt * Kt)) * 9 * H * D
+    if kind in ("aggregate_maps", "aggregate_loss_fwd"):   # H = head-maps in all, N = pixels, Kt = context tokens: maps in, A out
+        return "hbm", esz * H * N * Kt + 4 * N * Kt
+    if kind == "smooth_loss_fwd":                    # A (f32) in, < 1 KB out   (78.8 KB at 16 x 16 x 77)
+        return "hbm", 4 * N * Kt
+    if kind == "smooth_loss_bwd":                    # A in, dA out (+ the dtype-cast broadcast map)
+        return "hbm", 8 * N * Kt + (esz * N * Kt if flag else 0)
+    if kind in ("latent_axpy", "latent_axpby"):      # latents, grad in; latents out  (98 KB at 16 384 fp16 elements)
+        return "hbm", 3 * esz * N
+    if kind == "cfg_ddim_step":                      # eps_uncond, eps_text, x in; x_prev (, x0) out
+        return "hbm", (5 if flag else 4) * esz * N
     if kind.startswith("group_norm"):
         elems = B * N * D  # here H = groups, N = pixels, D = channels
         return "hbm", esz * elems * (2 if kind == "group_norm_fwd" else 3)
@@ -457,8 +467,15 @@ def main(argv=None):
     import torch.distributed as dist
 
     seed_of = lambda j: rank + world * j   # seeds striped by rank (weak scaling: K images per GPU)
+    first_image_s = None
     for j in range(args.warmup):
-        one_image(one_image.prepare(1000 + seed_of(j)))
+        prepared = one_image.prepare(1000 + seed_of(j))
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        one_image(prepared)
+        torch.cuda.synchronize()
+        if j == 0:   # cold: hipGraph capture, library algorithm search, weight packs, text K/V and timestep caches all inside
+            first_image_s = time.perf_counter() - tw
     inputs = [one_image.prepare(seed_of(j)) for j in range(args.steps)]   # resident in HBM before the timed region
     if world > 1:
         dist.barrier()
@@ -528,6 +545,14 @@ def main(argv=None):
                                            "B=3 pass (every evaluation performed)"),
                        "launch": "eager" if args.eager else "hipGraph replay of the UNet passes (captured in warm-up)",
                        "weights": "seeded random init (no checkpoint offline)",
+                       "amortised_outside_the_clock": "done once in the warm-up image(s), reused by every timed image (same "
+                                                      "prompt, same 50 timesteps): hipGraph capture, packed conv weights, "
+                                                      "the text K/V projections, the timestep-only part of the UNet (time "
+                                                      "MLP + 22 per-block projections per timestep); initial latents and "
+                                                      "the re-noise tensors are staged in HBM before the clock starts",
+                       "roofline_method": "achieved = per-shape hipGraph micro-replay (100 launches between two HIP events "
+                                          "on the launch stream, cold weights for the convolutions) weighted by the timed "
+                                          "region's launch census; not an in-pipeline per-launch timing",
                        "side_effects": "PNG / log dumps of the reference (diagnostics) are off and outside the timed region"},
             "unet_calls_per_image": calls, "finite": ok,
             "weight_broadcast": bcast,
@@ -538,6 +563,8 @@ def main(argv=None):
         }
         if two_pass is not None:
             line["two_pass_images_per_s"] = round(two_pass, 4)
+        if first_image_s is not None:
+            line["cold_first_image_s"] = round(first_image_s, 2)
         if flops_per_fwd:
             tf = flops_per_fwd * (calls["fwd_b1_grad"] + 2 * calls["fwd_b2"] + calls["bwd"]) / 1e12
             line["end_to_end"] = {"tflop_per_image": round(tf, 1),

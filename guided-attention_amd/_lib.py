@@ -50,6 +50,8 @@ PROTOTYPES = {
                            _vp, _vp],
     "ga_smooth_loss_bwd": [_vp, _i, _i, _i, _i, ctypes.POINTER(ga_token_t), _i, ctypes.POINTER(ga_loss_params_t), _vp,
                            _vp, _vp, _f, _i, _vp],
+    "ga_aggregate_loss_fwd": [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i, _i, _i, _i, ctypes.POINTER(ga_token_t), _i,
+                              ctypes.POINTER(ga_loss_params_t), _vp, _vp, _vp, _vp, _i, _vp],
     "ga_gaussian_weights": [_i, _f, ctypes.POINTER(_f)],
     "ga_latent_axpy": [_vp, _vp, _f, _vp, _vp, _i64, _i, _vp],
     "ga_latent_axpby": [_vp, _vp, _f, _f, _vp, _i64, _i, _vp],

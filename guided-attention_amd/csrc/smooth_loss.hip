@@ -16,7 +16,7 @@
 // normalised distance from the box centre, outside: 1; normalised separately over the inside and the outside pixels)
 // and hinge terms  inside = sum_in W * 2*max(0, 1/n_in - Pn),  outside = sum_out W * max(0, Pn).
 // The reference hard-codes res = 16 ("16", "15."); res and res-1 are used here (identical at 16).
-#include "ga_common.h"
+#include "aggregate.h"
 
 using namespace ga;
 
@@ -75,17 +75,34 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
   return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
 }
 
-// per-pixel softmax statistics of 100*A over the text slice: row max and sum of exponentials
+// per-pixel softmax statistics of 100*A over the text slice: row max and sum of exponentials.  One WAVE per pixel row
+// (lanes along the token axis: the row's 77 floats are two coalesced loads; a thread per row read 64 cache lines per
+// load instruction and walked its row serially — most of the 35 us the single-workgroup kernel took in round 2).
 __device__ __forceinline__ void pixel_softmax_stats(const LossArgs& a, float* mx, float* sm) {
-  const int npix = a.res * a.res;
-  for (int p = threadIdx.x; p < npix; p += kThreads) {
-    const float* row = a.A + (size_t)p * a.Kt;
-    float m = -INFINITY;
-    for (int c = a.first; c < a.last; ++c) m = fmaxf(m, row[c] * 100.0f);
-    float s = 0.f;
-    for (int c = a.first; c < a.last; ++c) s += expf(row[c] * 100.0f - m);
-    mx[p] = m;
-    sm[p] = s;
+  const int npix = a.res * a.res, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int width = a.last - a.first;
+  for (int p0 = wave * 4; p0 < npix; p0 += 4 * (kThreads / 64)) {   // 4 rows per trip: their loads are all in flight together
+    float v[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* row = a.A + (size_t)min(p0 + r, npix - 1) * a.Kt + a.first;
+      v[r][0] = lane < width ? row[lane] * 100.0f : -INFINITY;
+      v[r][1] = lane + 64 < width ? row[lane + 64] * 100.0f : -INFINITY;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float m = fmaxf(v[r][0], v[r][1]);
+      const float* row = a.A + (size_t)min(p0 + r, npix - 1) * a.Kt + a.first;
+      for (int c = lane + 128; c < width; c += 64) m = fmaxf(m, row[c] * 100.0f);   // Kt > 129 only
+      m = wave_reduce_max(m);
+      float e = (lane < width ? expf(v[r][0] - m) : 0.f) + (lane + 64 < width ? expf(v[r][1] - m) : 0.f);
+      for (int c = lane + 128; c < width; c += 64) e += expf(row[c] * 100.0f - m);
+      e = wave_reduce_sum(e);
+      if (lane == 0 && p0 + r < npix) {
+        mx[p0 + r] = m;
+        sm[p0 + r] = e;
+      }
+    }
   }
 }
 
@@ -249,9 +266,8 @@ __device__ __forceinline__ TokenLoss token_loss(const LossArgs& a, const ga_toke
   return r;
 }
 
-__global__ __launch_bounds__(kThreads) void smooth_loss_fwd_kernel(LossArgs a, float* __restrict__ terms,
-                                                                   float* __restrict__ loss) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void loss_forward(const LossArgs& a, float* lds, float* __restrict__ terms,
+                                             float* __restrict__ loss) {
   const int npix = a.res * a.res;
   float* mx = lds;
   float* sm = mx + npix;
@@ -281,6 +297,46 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_fwd_kernel(LossArgs a, f
     __syncthreads();
   }
   if (threadIdx.x == 0) loss[0] = total;
+}
+
+__global__ __launch_bounds__(kThreads) void smooth_loss_fwd_kernel(LossArgs a, float* __restrict__ terms,
+                                                                   float* __restrict__ loss) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  loss_forward(a, lds, terms, loss);
+}
+
+// K2 + K3 + K4 in ONE launch (utils/ptp_utils.py:279-289 -> pipeline_guided_attention.py:217-219): every workgroup
+// averages 256 (pixel, token) elements over the head-maps (aggregate.h: list order, no atomics) and stores them to A;
+// the workgroup whose ticket comes last then evaluates the loss on the complete A.  Hand-off: stores drained by every
+// wave, workgroup barrier, one agent-scope release + one relaxed ticket add per workgroup; the last arriver makes one
+// agent-scope acquire before its plain loads of A and returns the ticket word to zero for the next launch.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void aggregate_loss_fwd_kernel(AggArgs g, LossArgs a, int n_elem, float* __restrict__ A,
+                                                                      float* __restrict__ terms, float* __restrict__ loss,
+                                                                      unsigned* __restrict__ ticket) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int e = blockIdx.x * kThreads + threadIdx.x;
+  if (e < n_elem) A[e] = aggregate_element<T>(g, e, n_elem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* flag = reinterpret_cast<int*>(lds);
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the fence's own wait can be dropped by the compiler: keep this one
+    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == gridDim.x - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    flag[0] = last;
+  }
+  __syncthreads();
+  const int last = flag[0];
+  __syncthreads();   // the flag word is part of the loss's LDS image
+  if (!last) return;
+  loss_forward(a, lds, terms, loss);
 }
 
 template <typename T>
@@ -361,9 +417,11 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
     dot[p] = d;
   }
   __syncthreads();
+  // every workgroup has derived the same per-pixel tables (the token work above is 3 x 256 pixels: repeating it costs
+  // less than any hand-off); the element-wise tail over the (pixel, token) grid is split between them
   const float dl = dloss ? dloss[0] : 1.0f;
   const int total = npix * a.Kt;
-  for (int e = threadIdx.x; e < total; e += kThreads) {
+  for (int e = blockIdx.x * kThreads + threadIdx.x; e < total; e += gridDim.x * kThreads) {
     const int p = e / a.Kt, c = e - p * a.Kt;
     float g = 0.f;
     if (c >= a.first && c < a.last) {
@@ -462,7 +520,10 @@ static int launch_loss_bwd(const LossArgs& a, const float* dloss, float* dA, voi
   if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GA_ERR_LAUNCH;
-  hipLaunchKernelGGL(k, dim3(1), dim3(kThreads), lds, s, a, dloss, dA, (T*)dPb, bs);
+  // up to 16 workgroups, at least 4 elements of the tail per thread
+  const int total = a.res * a.res * a.Kt;
+  const int wgs = max(1, min(16, total / (4 * kThreads)));
+  hipLaunchKernelGGL(k, dim3(wgs), dim3(kThreads), lds, s, a, dloss, dA, (T*)dPb, bs);
   return check_launch();
 }
 
@@ -483,6 +544,44 @@ extern "C" int ga_smooth_loss_bwd(const float* A, int res, int Kt, int first, in
       return launch_loss_bwd<bf16_t>(a, dloss, dA, dP_bcast, bcast_scale, lds, s);
     case GA_F32:
       return launch_loss_bwd<float>(a, dloss, dA, dP_bcast, bcast_scale, lds, s);
+    default:
+      return GA_ERR_DTYPE;
+  }
+}
+
+template <typename T>
+static int launch_aggregate_loss(const AggArgs& g, const LossArgs& a, int n_elem, float* A, float* terms, float* loss,
+                                 unsigned* ticket, size_t lds, hipStream_t s) {
+  auto k = aggregate_loss_fwd_kernel<T>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GA_ERR_LAUNCH;
+  hipLaunchKernelGGL(k, dim3((n_elem + kThreads - 1) / kThreads), dim3(kThreads), lds, s, g, a, n_elem, A, terms, loss,
+                     ticket);
+  return check_launch();
+}
+
+extern "C" int ga_aggregate_loss_fwd(const void* const* maps, const int* heads, int n_maps, int res, int Kt, int first,
+                                     int last, const ga_token_t* tokens, int T, const ga_loss_params_t* hp, float* A,
+                                     float* terms, float* loss, unsigned* ticket, int dtype, ga_stream_t stream) {
+  if (!terms || !loss || !ticket) return GA_ERR_NULL;
+  AggArgs g;
+  int rc = fill_agg_args(g, maps, heads, n_maps);
+  if (rc != GA_OK) return rc;
+  LossArgs a;
+  rc = fill_args(a, A, res, Kt, first, last, tokens, T, hp);
+  if (rc != GA_OK) return rc;
+  const size_t lds = fwd_lds(res * res, a.strict);
+  if (lds > 150 * 1024) return GA_ERR_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int n_elem = res * res * Kt;
+  switch (dtype) {
+    case GA_F16:
+      return launch_aggregate_loss<_Float16>(g, a, n_elem, A, terms, loss, ticket, lds, s);
+    case GA_BF16:
+      return launch_aggregate_loss<bf16_t>(g, a, n_elem, A, terms, loss, ticket, lds, s);
+    case GA_F32:
+      return launch_aggregate_loss<float>(g, a, n_elem, A, terms, loss, ticket, lds, s);
     default:
       return GA_ERR_DTYPE;
   }

@@ -17,7 +17,7 @@ ones (same C-ABI calls on the capture stream).
 import torch
 
 from . import ops
-from .utils.ptp_utils import aggregate_attention, pin_context_projections, refresh_context_projections
+from .utils.ptp_utils import pin_context_projections, refresh_context_projections
 
 
 class GraphRunner:
@@ -28,7 +28,8 @@ class GraphRunner:
         custom = getattr(state.config, "custom_loss", None) or {}
         key = (tuple((name, id(fn), str(args)) for name, (fn, args) in sorted(custom.items())), tuple(latents.shape), latents.dtype, tuple(prompt_embeds.shape), pipe._plan_key, attention_res,
                pipe.guidance_forward, normalize_eot, str(pipe.prompt) if normalize_eot else None,
-               getattr(store, "capture", None), bool(getattr(pipe, "batch_loss_only_guidance", False)))
+               getattr(store, "capture", None), bool(getattr(pipe, "batch_loss_only_guidance", False)),
+               bool(pipe.fused_aggregate_loss))
         runner = pipe._graph_cache.get(key)
         if runner is None:
             for old in pipe._graph_cache.values():
@@ -77,8 +78,7 @@ class GraphRunner:
         pipe = self.pipe
         with torch.enable_grad():
             pipe._guidance_forward(self.lat_g, self.t_dev, self.embeds[1:2], time_projection=self.tp[1])
-            A = aggregate_attention(store, self.res, ("up", "down", "mid"), True, 0)
-            parts = pipe._loss_device(A, *self.loss_args)
+            parts = pipe._aggregate_loss_device(store, self.res, *self.loss_args)
         return parts, store.attention_store
 
     def _grad_body(self, loss):
@@ -99,8 +99,7 @@ class GraphRunner:
             # has batch 1); what stays published afterwards is what the CFG pass would have left: samples 1 and 2
             full = store.attention_store
             store.attention_store = {k: [p[: p.shape[0] // 3] for p in v] for k, v in full.items()}
-            A = aggregate_attention(store, self.res, ("up", "down", "mid"), True, 0)
-            parts = pipe._loss_device(A, *self.loss_args)
+            parts = pipe._aggregate_loss_device(store, self.res, *self.loss_args)
             snap = {k: [p[p.shape[0] // 3:] for p in v] for k, v in full.items()}
             store.attention_store = snap
         return out, parts, snap

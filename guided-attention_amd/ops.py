@@ -127,6 +127,40 @@ def replay_launch_us(key, iters=100):
                 def fn():
                     check(lib.ga_add_layer_norm_bwd(_ptr(xn), _ptr(stats), _ptr(w), _ptr(dy), _ptr(g_arg), _ptr(dx), rows,
                                                     C, code, stream_ptr()), "replay ln bwd")
+    elif kind in ("aggregate_maps", "aggregate_loss_fwd", "smooth_loss_fwd", "smooth_loss_bwd"):
+        # B = guided tokens (aggregate_maps: tensors), H = head-maps in all, N = pixels, Kt = tokens of the context
+        npix, res = N, int(round(N ** 0.5))
+        nt = B if kind != "aggregate_maps" else 3
+        entries = [{"index": 2 + i, "kind": "BOX", "geom": (.1 + .05 * i, .3, .4, .55), "subprompt": f"s{i}"}
+                   for i in range(nt)]
+        plan = LossPlan(entries, {"inside_loss_scale": .2, "outside_loss_scale": .2, "shrink_factor": .15})
+        heads_all = max(H, 1)
+        per = 8 if heads_all % 8 == 0 else heads_all
+        maps = [torch.softmax(torch.randn(per, npix, Kt, device=dev), -1).to(dtype) for _ in range(heads_all // per)]
+        A = torch.softmax(torch.randn(npix, Kt, device=dev), -1)
+        if kind == "aggregate_maps":
+            def fn():
+                aggregate_maps(maps)
+        elif kind == "aggregate_loss_fwd":
+            def fn():
+                aggregate_loss_fwd(maps, res, 1, Kt - 1, plan)
+        elif kind == "smooth_loss_fwd":
+            def fn():
+                smooth_loss_fwd(A, res, 1, Kt - 1, plan)
+        else:
+            def fn():
+                smooth_loss_bwd(A, res, 1, Kt - 1, plan, None, dtype if flag else None, 1.0 / 40)
+    elif kind in ("latent_axpy", "latent_axpby", "cfg_ddim_step"):
+        x, y, z = (torch.randn(N, device=dev, dtype=dtype) for _ in range(3))
+        if kind == "latent_axpy":
+            def fn():
+                latent_axpy(x, y, 20.0, bool(flag))
+        elif kind == "latent_axpby":
+            def fn():
+                latent_axpby(x, y, 0.9, 0.1)
+        else:
+            def fn():
+                cfg_ddim_step(x, y, 7.5, z, 0.5, 0.6, bool(flag))
     elif kind.startswith("group_norm"):
         groups, HW, C = H, N, D
         side_len = int(round(HW ** 0.5))
@@ -146,7 +180,7 @@ def replay_launch_us(key, iters=100):
             def fn():
                 check(lib.ga_group_norm_bwd(_ptr(x), None, _ptr(dy), _ptr(w), _ptr(b_), _ptr(stats), _ptr(y), _ptr(ws), B,
                                             HW, C, groups, int(flag), code, stream_ptr()), "replay gn bwd")
-    else:
+    elif kind in ("attn_capture_fwd", "attn_capture_bwd", "self_attn_fwd", "self_attn_bwd"):
         q = torch.randn(B, N, H * D, device=dev, dtype=dtype)
         k = torch.randn(B, Kt, H * D, device=dev, dtype=dtype)
         v = torch.randn(B, Kt, H * D, device=dev, dtype=dtype)
@@ -375,6 +409,7 @@ def aggregate_maps(maps):
     ptrs = (ctypes.c_void_p * n)(*[m.data_ptr() for m in maps])
     heads = (ctypes.c_int * n)(*[m.shape[0] for m in maps])
     A = torch.empty((npix, Kt), dtype=torch.float32, device=maps[0].device)
+    _count(("aggregate_maps", n, sum(m.shape[0] for m in maps), npix, Kt, 0, False, str(maps[0].dtype)))
     check(load().ga_aggregate_maps(ptrs, heads, n, npix, Kt, _ptr(A), dtype_code(maps[0]), stream_ptr()),
           "ga_aggregate_maps")
     return A
@@ -469,6 +504,7 @@ def smooth_loss_fwd(A, res, first, last, plan):
     Kt = A.shape[-1]
     terms = torch.empty((plan.T, _lib.GA_TERMS), dtype=torch.float32, device=A.device)
     loss = torch.empty((1,), dtype=torch.float32, device=A.device)
+    _count(("smooth_loss_fwd", plan.T, 0, res * res, Kt, 0, False, "torch.float32"))
     check(load().ga_smooth_loss_fwd(_ptr(A), res, Kt, first, last, plan.tokens, plan.T, ctypes.byref(plan.params),
                                     _ptr(terms), _ptr(loss), stream_ptr()), "ga_smooth_loss_fwd")
     return terms, loss
@@ -483,6 +519,7 @@ def smooth_loss_bwd(A, res, first, last, plan, dloss=None, bcast_dtype=None, bca
     code = _lib.DTYPE_CODE[bcast_dtype] if bcast_dtype is not None else _lib.GA_F32
     if dloss is not None:
         dloss = dloss.to(torch.float32).contiguous()
+    _count(("smooth_loss_bwd", plan.T, 0, res * res, Kt, 0, bcast_dtype is not None, str(bcast_dtype or torch.float32)))
     check(load().ga_smooth_loss_bwd(_ptr(A), res, Kt, first, last, plan.tokens, plan.T, ctypes.byref(plan.params),
                                     _ptr(dloss), _ptr(dA), _ptr(dPb), float(bcast_scale), code, stream_ptr()),
           "ga_smooth_loss_bwd")
@@ -508,6 +545,63 @@ class SmoothLoss(torch.autograd.Function):
         return dA, None, None, None, None
 
 
+_tickets = {}   # device index -> one zeroed 32-bit word (the arrival counter of the fused aggregate + loss launch)
+
+
+def _ticket(device):
+    t = _tickets.get(device.index)
+    if t is None:
+        t = _tickets[device.index] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def aggregate_loss_fwd(maps, res, first, last, plan):
+    """K2 + K3 + K4 in one launch: maps (list of (heads_i, res*res, Kt) tensors of one dtype) ->
+    (A (res*res, Kt) f32, terms (T, 8), loss (1,))."""
+    require_cuda(*maps)
+    if plan.T == 0:
+        raise GaError("no guided tokens")
+    _check_boxes(plan, res)
+    maps = [m.contiguous() for m in maps]
+    npix, Kt = maps[0].shape[1], maps[0].shape[2]
+    if npix != res * res:
+        raise GaError(f"maps have {npix} pixels, expected {res * res}")
+    n = len(maps)
+    ptrs = (ctypes.c_void_p * n)(*[m.data_ptr() for m in maps])
+    heads = (ctypes.c_int * n)(*[m.shape[0] for m in maps])
+    dev = maps[0].device
+    A = torch.empty((npix, Kt), dtype=torch.float32, device=dev)
+    terms = torch.empty((plan.T, _lib.GA_TERMS), dtype=torch.float32, device=dev)
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    _count(("aggregate_loss_fwd", plan.T, sum(m.shape[0] for m in maps), npix, Kt, 0, False, str(maps[0].dtype)))
+    check(load().ga_aggregate_loss_fwd(ptrs, heads, n, res, Kt, first, last, plan.tokens, plan.T, ctypes.byref(plan.params),
+                                       _ptr(A), _ptr(terms), _ptr(loss), _ptr(_ticket(dev)), dtype_code(maps[0]),
+                                       stream_ptr()), "ga_aggregate_loss_fwd")
+    return A, terms, loss
+
+
+class AggregateSmoothLoss(torch.autograd.Function):
+    """(res, first, last, plan, *maps) -> (A (res*res, Kt) f32 [not differentiable here], terms (T, 8), loss (1,)): the
+    aggregate and the smoothed box loss as ONE launch; the backward is one launch too (ga_smooth_loss_bwd emits the
+    dtype-cast dLoss/dA / n_head_maps map that the capture kernels broadcast over the head-maps)."""
+
+    @staticmethod
+    def forward(ctx, res, first, last, plan, *maps):
+        A, terms, loss = aggregate_loss_fwd(list(maps), res, first, last, plan)
+        ctx.save_for_backward(A)
+        ctx.args = (res, first, last, plan, [m.shape for m in maps], maps[0].dtype)
+        ctx.mark_non_differentiable(A, terms)
+        return A, terms, loss
+
+    @staticmethod
+    def backward(ctx, _dA, _dterms, dloss):
+        (A,) = ctx.saved_tensors
+        res, first, last, plan, shapes, dtype = ctx.args
+        total = sum(s[0] for s in shapes)
+        _, g = smooth_loss_bwd(A, res, first, last, plan, dloss, bcast_dtype=dtype, bcast_scale=1.0 / total)
+        return (None, None, None, None) + tuple(g.unsqueeze(0).expand(s) for s in shapes)
+
+
 def gaussian_weights(kernel_size, sigma):
     w = (ctypes.c_float * (kernel_size * kernel_size))()
     check(load().ga_gaussian_weights(kernel_size, float(sigma), w), "ga_gaussian_weights")
@@ -520,6 +614,7 @@ def latent_axpy(latents, grad, step, want_absmean=False):
     latents, grad = latents.contiguous(), grad.contiguous().to(latents.dtype)
     out = torch.empty_like(latents)
     absmean = torch.empty((1,), dtype=torch.float32, device=latents.device) if want_absmean else None
+    _count(("latent_axpy", 1, 0, latents.numel(), 0, 0, bool(want_absmean), str(latents.dtype)))
     check(load().ga_latent_axpy(_ptr(latents), _ptr(grad), float(step), _ptr(out), _ptr(absmean), latents.numel(),
                                 dtype_code(latents), stream_ptr()), "ga_latent_axpy")
     return out, absmean
@@ -529,6 +624,7 @@ def latent_axpby(x, y, a, b):
     require_cuda(x, y)
     x, y = x.contiguous(), y.contiguous().to(x.dtype)
     out = torch.empty_like(x)
+    _count(("latent_axpby", 1, 0, x.numel(), 0, 0, False, str(x.dtype)))
     check(load().ga_latent_axpby(_ptr(x), _ptr(y), float(a), float(b), _ptr(out), x.numel(), dtype_code(x),
                                  stream_ptr()), "ga_latent_axpby")
     return out
@@ -539,6 +635,7 @@ def cfg_ddim_step(eps_uncond, eps_text, guidance, x, alpha_t, alpha_prev, want_x
     eps_uncond, eps_text, x = eps_uncond.contiguous(), eps_text.contiguous(), x.contiguous()
     prev = torch.empty_like(x)
     x0 = torch.empty_like(x) if want_x0 else None
+    _count(("cfg_ddim_step", 1, 0, x.numel(), 0, 0, bool(want_x0), str(x.dtype)))
     check(load().ga_cfg_ddim_step(_ptr(eps_uncond), _ptr(eps_text), float(guidance), _ptr(x), float(alpha_t),
                                   float(alpha_prev), _ptr(prev), _ptr(x0), x.numel(), dtype_code(x), stream_ptr()),
           "ga_cfg_ddim_step")

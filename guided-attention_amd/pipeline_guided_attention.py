@@ -28,7 +28,7 @@ from ._lib import GaError
 from .scheduler import DDIMScheduler
 from .utils import helpers
 from .utils import shared_state as state
-from .utils.ptp_utils import AttentionStore, aggregate_attention
+from .utils.ptp_utils import AttentionStore, aggregate_attention, stored_maps
 
 TERM = {"max_loss": 0, "col": 1, "row": 2, "inside_loss": 3, "outside_loss": 4, "token_loss": 5, "unscaled": 6}
 
@@ -242,13 +242,37 @@ class GuidedAttention:
             self._plan_key = key
         return self._plan
 
+    def _last_text_index(self, n_tok, normalize_eot):
+        if normalize_eot:
+            prompt = self.prompt[0] if isinstance(self.prompt, list) else self.prompt
+            return len(self.tokenizer(prompt)["input_ids"]) - 1
+        return n_tok - 1
+
+    def _aggregate_loss_device(self, attention_store, attention_res, smooth_attentions, sigma, kernel_size, normalize_eot):
+        """aggregate_attention + the loss evaluation, device half.  The common case — built-in box / coordinate terms
+        only, no diagnostics — is ONE launch (ga_aggregate_loss_fwd: the head-map mean never makes its own pass and its
+        backward is one launch as well); custom Python losses and the PNG dumps need the aggregate as a differentiable
+        tensor of its own and take the two-step form.  Results are identical (GPU test)."""
+        plan = self._loss_plan(smooth_attentions, sigma, kernel_size)
+        custom = getattr(state.config, "custom_loss", None)
+        if plan.T > 0 and not custom and not self._dump and self.fused_aggregate_loss:
+            maps = stored_maps(attention_store, attention_res, ("up", "down", "mid"), True, 0)
+            last_idx = self._last_text_index(maps[0].shape[-1], normalize_eot)
+            _, terms, loss = ops.AggregateSmoothLoss.apply(attention_res, 1, last_idx, plan, *maps)
+            packed = torch.cat([terms.detach().reshape(-1), loss.detach(), loss.new_zeros(1)])
+            return terms, loss, None, plan, packed
+        attention_maps = aggregate_attention(attention_store=attention_store, res=attention_res,
+                                             from_where=("up", "down", "mid"), is_cross=True, select=0)
+        if self._dump and getattr(state.config, "save_individual_CA_maps", False) and state.cur_time_step_iter == 12:
+            self._dump_individual_ca_maps(attention_store, attention_maps, ("up", "down", "mid"))
+        return self._loss_device(attention_maps, smooth_attentions, sigma, kernel_size, normalize_eot)
+
+    fused_aggregate_loss = True   # False: always aggregate_attention + loss as two launches (A/B and parity tests)
+
     def _loss_device(self, attention_maps, smooth_attentions, sigma, kernel_size, normalize_eot):
         """Device half of the loss evaluation (graph-capturable: no host sync): -> (terms, loss, custom, plan)."""
         res, n_tok = attention_maps.shape[0], attention_maps.shape[-1]
-        last_idx = n_tok - 1
-        if normalize_eot:
-            prompt = self.prompt[0] if isinstance(self.prompt, list) else self.prompt
-            last_idx = len(self.tokenizer(prompt)["input_ids"]) - 1
+        last_idx = self._last_text_index(n_tok, normalize_eot)
         plan = self._loss_plan(smooth_attentions, sigma, kernel_size)
         if plan.T > 0:
             terms, loss = ops.SmoothLoss.apply(attention_maps.reshape(res * res, n_tok), res, 1, last_idx, plan)
@@ -359,12 +383,8 @@ class GuidedAttention:
 
     def _aggregate_and_get_max_attention_per_token(self, attention_store, attention_res=16, smooth_attentions=False,
                                                    sigma=0.5, kernel_size=3, normalize_eot=False):
-        attention_maps = aggregate_attention(attention_store=attention_store, res=attention_res,
-                                             from_where=("up", "down", "mid"), is_cross=True, select=0)
-        if self._dump and getattr(state.config, "save_individual_CA_maps", False) and state.cur_time_step_iter == 12:
-            self._dump_individual_ca_maps(attention_store, attention_maps, ("up", "down", "mid"))
-        return self._compute_max_attention_per_index(attention_maps, smooth_attentions, sigma, kernel_size,
-                                                     normalize_eot)
+        return self._loss_host(*self._aggregate_loss_device(attention_store, attention_res, smooth_attentions, sigma,
+                                                            kernel_size, normalize_eot))
 
     @staticmethod
     def group_losses_by_sumprompt(losses):

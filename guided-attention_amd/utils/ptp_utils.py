@@ -403,11 +403,9 @@ class AttentionStore(AttentionControl):
         self.global_store = {}
 
 
-def aggregate_attention(attention_store: AttentionStore, res: int, from_where: List[str], is_cross: bool,
-                        select: int) -> torch.Tensor:
-    """Mean over the heads of every stored map with res^2 pixels, in `from_where` order
-    (reference :273-289).  Runs `ga_aggregate_maps`; returns float32 (res, res, n_keys) and stays
-    differentiable w.r.t. the stored probabilities."""
+def stored_maps(attention_store: AttentionStore, res: int, from_where: List[str], is_cross: bool, select: int = 0):
+    """The tensors `aggregate_attention` averages, in its order (reference :279-286): every stored map with res^2
+    pixels of the listed locations."""
     maps = []
     attention_maps = attention_store.get_average_attention()
     num_pixels = res ** 2
@@ -420,5 +418,13 @@ def aggregate_attention(attention_store: AttentionStore, res: int, from_where: L
                            "(reference: torch.cat of an empty list)")
     if select != 0:
         raise IndexError(f"index {select} is out of bounds for dimension 0 with size 1")
-    out = ops.AggregateMaps.apply(*maps)
+    return maps
+
+
+def aggregate_attention(attention_store: AttentionStore, res: int, from_where: List[str], is_cross: bool,
+                        select: int) -> torch.Tensor:
+    """Mean over the heads of every stored map with res^2 pixels, in `from_where` order
+    (reference :273-289).  Runs `ga_aggregate_maps`; returns float32 (res, res, n_keys) and stays
+    differentiable w.r.t. the stored probabilities."""
+    out = ops.AggregateMaps.apply(*stored_maps(attention_store, res, from_where, is_cross, select))
     return out.view(res, res, out.shape[-1])

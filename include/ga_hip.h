@@ -155,6 +155,19 @@ int ga_smooth_loss_bwd(const float* A, int res, int Kt, int first, int last,
                        const float* dloss, float* dA, void* dP_bcast, float bcast_scale, int dtype,
                        ga_stream_t stream);
 
+/* K2 + K3 + K4 in one launch: ga_aggregate_maps followed by ga_smooth_loss_fwd on its result
+ * (utils/ptp_utils.py:279-289 -> pipeline_guided_attention.py:217-296, one launch instead of two on the serial path
+ * of every refinement iteration).  Every workgroup averages 256 elements of A and stores them; the workgroup that
+ * finishes last evaluates the loss on the complete map.
+ *   A       [res*res][Kt] f32, written (kept: the backward and the diagnostics read it)
+ *   ticket  one zero-initialised 32-bit word of device memory owned by the caller; the kernel leaves it zero.
+ *           Launches sharing a ticket word must be stream-ordered.
+ * Results are bit-identical to the two separate calls. */
+int ga_aggregate_loss_fwd(const void* const* maps, const int* heads, int n_maps, int res, int Kt,
+                          int first, int last, const ga_token_t* tokens, int T,
+                          const ga_loss_params_t* hp, float* A, float* terms, float* loss,
+                          unsigned* ticket, int dtype, ga_stream_t stream);
+
 /* Gaussian weights exactly as utils/gaussian_smoothing.py:21-47 builds them (host helper; w[ksize*ksize]). */
 int ga_gaussian_weights(int ksize, float sigma, float* w);
 

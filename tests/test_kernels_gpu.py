@@ -436,6 +436,39 @@ def test_inside_box_masks_through_the_loss_kernel(ops):
         assert int((got_in == 0).sum()) == c["count"]
 
 
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("res,layout", [(16, (8, 8, 8, 8, 8)), (24, (5, 10, 10, 5)), (32, (20, 3)), (16, (1,))])
+def test_fused_aggregate_loss_is_the_two_launches(ops, res, layout, dt):
+    """ga_aggregate_loss_fwd (one launch; the last-arriving workgroup evaluates the loss) against ga_aggregate_maps
+    followed by ga_smooth_loss_fwd: A, terms and loss bit for bit, on 40 launches in a row that share the ticket word
+    (fresh maps every time: a loss evaluated on an incomplete A would show), and the autograd form against the
+    two-step graph incl. the gradient that reaches the head-maps."""
+    ents = [{"index": 2, "kind": "BOX", "geom": (.6, .3, .4, .55), "subprompt": "robot"},
+            {"index": 5, "kind": "BOX", "geom": (.2, .3, .4, .55), "subprompt": "blue vase"},
+            {"index": 6, "kind": "COOR", "geom": (.3, .7), "subprompt": "blue vase"}]
+    plan = ops.LossPlan(ents, oloss.DEFAULT_HYPER)
+    npix = res * res
+    g = torch.Generator(device="cuda").manual_seed(res + len(layout))
+    for it in range(40):
+        maps = [torch.softmax(torch.randn(h, npix, 77, device="cuda", generator=g) * 3, -1).to(DT[dt]) for h in layout]
+        A, terms, loss = ops.aggregate_loss_fwd(maps, res, 1, 76, plan)
+        A2 = ops.aggregate_maps(maps)
+        terms2, loss2 = ops.smooth_loss_fwd(A2, res, 1, 76, plan)
+        assert torch.equal(A, A2) and torch.equal(terms, terms2) and torch.equal(loss, loss2), it
+    assert int(ops._ticket(torch.device("cuda", torch.cuda.current_device())).item()) == 0
+    # autograd: one launch each way vs aggregate -> loss as separate nodes
+    leaves = [m.clone().requires_grad_(True) for m in maps]
+    _, _, l1 = ops.AggregateSmoothLoss.apply(res, 1, 76, plan, *leaves)
+    g1 = torch.autograd.grad(l1 * 1.5, leaves)
+    leaves2 = [m.clone().requires_grad_(True) for m in maps]
+    _, l2 = ops.SmoothLoss.apply(ops.AggregateMaps.apply(*leaves2), res, 1, 76, plan)
+    g2 = torch.autograd.grad(l2 * 1.5, leaves2)
+    assert torch.equal(l1, l2)
+    for a, b, m in zip(g1, g2, maps):
+        assert a.shape == m.shape and a.stride(0) == 0        # one map broadcast over the head-maps, never materialised
+        close(a[0].float(), b[0].float().cpu().numpy(), TOL[dt], "dLoss/dP")
+
+
 def test_gaussian_weights_host(ops):
     g = load_npz("g1_gaussian.npz")
     for k, s in [(3, 0.5), (3, 1.0), (5, 1.0), (5, 0.75)]:

@@ -39,10 +39,15 @@ def run_product(pipe, meta, embeds, lat0, noise, thr, capture="loss-only", **fla
     ptp_utils.register_attention_control(pipe, controller)
     for k, v in flags.items():
         setattr(pipe, k, v)
+    from guided_attention_amd import ops
+    ops.start_census()
     out = pipe(prompt=None, prompt_embeds=embeds[1:2].cuda(), negative_prompt_embeds=embeds[0:1].cuda(),
                attention_store=controller, attention_res=16, guidance_scale=7.5, num_inference_steps=meta["steps"],
                max_iter_to_alter=meta["max_iter_to_alter"], thresholds=cfg.thresholds, scale_factor=meta["scale_factor"],
                latents=lat0.clone(), renoise_noise=[n.clone() for n in noise], output_type="latent")
+    out.census = {}
+    for key, n in ops.stop_census().items():      # launches per entry point of this image
+        out.census[key[0]] = out.census.get(key[0], 0) + n
     return out, controller
 
 
@@ -65,7 +70,7 @@ MAIN_CALLS = ("fwd_b1_grad", "bwd", "fwd_b2", "loss_evals")
 
 
 @pytest.mark.parametrize("variant", ["rerun", "reference-capture", "truncated", "skip-unused", "graphs", "graphs-truncated",
-                                     "graphs-two-pass"])
+                                     "graphs-two-pass", "two-launch-loss", "graphs-two-launch-loss"])
 def test_variants_are_result_identical(variant):
     """capture='reference', the truncated guidance forward and the skipped log-only guidance passes must
     not change the latents.  Library conv/GEMM kernels may be chosen differently from call to call, so
@@ -86,6 +91,12 @@ def test_variants_are_result_identical(variant):
         assert ctrl.attention_store["down_cross"][0].shape == (2 * 2, 1024, 77)
     elif variant == "truncated":
         out, _ = run_product(pipe, meta, embeds, lat0, noise, thr, guidance_forward="truncated")
+    elif variant.endswith("two-launch-loss"):   # aggregate_attention and the loss as separate launches (base: fused)
+        assert base.census.get("aggregate_loss_fwd", 0) > 0 and base.census.get("aggregate_maps", 0) == 0
+        out, _ = run_product(pipe, meta, embeds, lat0, noise, thr, fused_aggregate_loss=False,
+                             use_graphs=variant.startswith("graphs"))
+        assert out.census.get("aggregate_loss_fwd", 0) == 0 and out.census.get("aggregate_maps", 0) > 0
+        pipe.fused_aggregate_loss = True
     elif variant.startswith("graphs"):
         mode = "truncated" if variant.endswith("truncated") else "full"
         joint = not variant.endswith("two-pass")
@@ -502,3 +513,99 @@ def test_full_width_unet_own_convolutions_match_the_library(batch):
     ey = float((y_own - y_lib).abs().max() / y_lib.abs().max())
     eg = float((g_own - g_lib).abs().max() / g_lib.abs().max())
     assert ey < 2e-2 and eg < 5e-2, (ey, eg)
+
+
+@pytest.mark.parametrize("graphs", [False, True], ids=["eager", "graphs"])
+def test_full_width_guidance_evaluation_vs_oracle_fp16(graphs):
+    """The configuration bench.py times, held to the oracle at its REAL width: the full-width SD-1.x UNet
+    (`UNetConfig.sd15()`, 860 M seeded weights), ONE guidance evaluation in fp16 through the product path — capture
+    kernels, aggregate, smoothed box loss, the backward to the latents and one `_update_latent` — against the fp32 CPU
+    oracle on the same weights, latents and prompt embedding (reference: pipeline_guided_attention.py:946-973, 456-470).
+
+    Stated fp16 tolerances (max |difference| / max |oracle value| unless said otherwise), with the error budget behind
+    each: a stored 16x16 cross map passes through up to ~60 fp16-rounded layers (rel. 2^-11 each, random signs) before
+    its softmax: 3e-2; their 40-map mean: 1e-2; the loss is a sum of O(1) box masses of that mean: 2e-2 relative; the
+    latent gradient additionally runs the whole backward in fp16 (loss gradients ~1e-5 carried under power-of-two
+    scales): 1.5e-1 of its maximum and cosine > 0.99; the updated latents are x - 20 g with |20 g| << |x|: 2e-3."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from guided_attention_amd import run
+    from guided_attention_amd.config import RunConfig
+    from guided_attention_amd.graphs import GraphRunner
+    from guided_attention_amd.pipeline_guided_attention import GuidedAttention
+    from guided_attention_amd.text import SyntheticTextEncoder, WordTokenizer
+    from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig
+    from guided_attention_amd.utils import helpers, ptp_utils, shared_state as state
+    from oracle import attention as oattn
+
+    cfg_u = UNetConfig.sd15()
+    unet = UNet2DConditionModel(cfg_u).init_weights_(seed=0).float()
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator("cpu").manual_seed(1234)
+    embeds = torch.randn(2, 77, cfg_u.cross_attention_dim, generator=g)
+    lat0 = torch.randn(1, 4, 64, 64, generator=torch.Generator("cpu").manual_seed(28))
+    t, step = 981, 20.0
+
+    # ---- product first (the deep copy goes to the GPU in fp16; the fp32 original stays for the oracle)
+    import copy
+    pipe = GuidedAttention(copy.deepcopy(unet).half(), None, None, SyntheticTextEncoder(cfg_u.cross_attention_dim),
+                           WordTokenizer()).to("cuda", torch.float16)
+    rc = RunConfig(meta_prompt="a [robot:.6,.3,.4,.55] and a [blue vase:.2,.3,.4,.55]", output_path="/tmp/ga_test_out")
+    rc.stable = pipe
+    state.curHyperParams = dict(state.hyperParameterOverrides)
+    run.overrideConfig(rc)
+    run.parseMetaPrompt(rc)
+    helpers.log_clear()
+    ctrl = ptp_utils.AttentionStore()
+    ptp_utils.register_attention_control(pipe, ctrl)
+    pipe._attention_store = ctrl
+    emb_g, lat_g = embeds.cuda().half(), lat0.cuda().half()
+    pipe.unet_calls = {k: 0 for k in ("fwd_b1_grad", "bwd", "fwd_b2", "loss_evals", "joint_b3")}
+    pipe._deferred_log = []
+    pipe._truncate_at = None
+    pipe._runner = GraphRunner.for_run(pipe, ctrl, emb_g, lat_g, 16, True, 0.5, 3, False) if graphs else None
+    try:
+        with torch.enable_grad():
+            leaf, losses_dict = pipe._guidance_eval(lat_g, t, emb_g[1:2], ctrl, 16, True, 0.5, 3, False)
+            maps = {k: [m.detach().float().cpu() for m in v] for k, v in ctrl.attention_store.items() if v}
+            A = ptp_utils.aggregate_attention(ctrl, 16, ("up", "down", "mid"), True, 0).detach().float().cpu()
+            loss, _, unscaled = pipe._compute_loss(losses_dict, return_losses=True)
+            if graphs:      # the captured backward pass leaves the latent gradient in the runner's static buffer
+                new_lat = pipe._update_latent(leaf, loss, step)
+                grad = pipe._runner.grad.detach().float().cpu()
+            else:
+                grad = torch.autograd.grad(loss, [leaf], retain_graph=True)[0].detach().float().cpu()
+                new_lat = pipe._update_latent(leaf, loss, step)
+        assert pipe.unet_calls["bwd"] == 1 and pipe.unet_calls["fwd_b1_grad"] == 1
+        loss_v = float(losses_dict["_fused"]["host_total"])
+        new_lat = new_lat.float().cpu()
+    finally:
+        if pipe._runner is not None:
+            pipe._runner.release()
+            pipe._graph_cache.clear()
+            pipe._runner = None
+    assert {k: len(v) for k, v in maps.items()} == {"down_cross": 2, "up_cross": 3}
+
+    # ---- oracle (CPU fp32, ~3 s forward + loss, ~1 s backward)
+    plan = oloss.TokenPlan(BASE_ENTRIES)
+    s = GuidedSampler(unet, plan, thresholds={0: 1.0})
+    with torch.enable_grad():
+        lat_c, r, _ = s._evaluate(lat0, t, embeds[1:2])
+        new_ref = s._update(lat_c, r["loss"], step)
+    g_ref = (lat0 - new_ref) / step
+    A_ref = oattn.aggregate(s.store.attention_store, 16, ("up", "down", "mid"), True)
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max())
+
+    for key in ("down_cross", "up_cross"):
+        refs = [m for m in s.store.attention_store[key] if m.shape[1] == 256]
+        assert len(refs) == len(maps[key])
+        for got, ref in zip(maps[key], refs):
+            assert rel(got, ref.detach()) < 3e-2, (key, rel(got, ref.detach()))
+    assert rel(A, A_ref.detach()) < 1e-2, rel(A, A_ref.detach())
+    assert abs(loss_v - float(r["loss"])) < 2e-2 * abs(float(r["loss"])), (loss_v, float(r["loss"]))
+    cos = float((grad * g_ref).sum() / (grad.norm() * g_ref.norm()))
+    assert rel(grad, g_ref) < 1.5e-1 and cos > 0.99, (rel(grad, g_ref), cos)
+    assert rel(new_lat, new_ref) < 2e-3, rel(new_lat, new_ref)
