@@ -34,6 +34,14 @@ class ga_loss_params_t(ctypes.Structure):
                 ("smooth", ctypes.c_int32), ("strict", ctypes.c_int32), ("_pad", ctypes.c_int32)]
 
 
+class ga_linear_epilogue_t(ctypes.Structure):
+    _fields_ = [("bias", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int64),
+                ("geglu", ctypes.c_int32), ("preact", ctypes.c_void_p), ("ld_pre", ctypes.c_int64),
+                ("ln_partials", ctypes.c_void_p), ("ln_parts", ctypes.c_int32), ("ln_eps", ctypes.c_float),
+                ("ln_colsum", ctypes.c_void_p), ("ln_shift", ctypes.c_void_p), ("ln_stats_out", ctypes.c_void_p),
+                ("row_partials_out", ctypes.c_void_p)]
+
+
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
 # name -> argtypes, exactly the prototypes of include/ga_hip.h
@@ -68,6 +76,9 @@ PROTOTYPES = {
                         ctypes.POINTER(ctypes.c_longlong)],
     "ga_conv3x3_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ga_gemm_nt": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
+    "ga_linear_workspace": [_i64, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(_i)],
+    "ga_linear_fused": [_vp, _i64, _vp, _vp, _i64, ctypes.POINTER(ga_linear_epilogue_t), _vp, _vp, _i64, _i, _i, _i, _i, _i,
+                        _i, _vp],
     "ga_add_layer_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp],
     "ga_add_layer_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
 }

@@ -1,0 +1,491 @@
+// Linear layers of the UNet's transformer blocks (to_q / to_k / to_v / to_out, proj_in / proj_out, the GEGLU feed-forward:
+// diffusers 0.12.1 CrossAttention / BasicTransformerBlock called from utils/ptp_utils.py:70-91 and
+// pipeline_guided_attention.py:647-738) as ONE kernel family with the element-wise neighbours folded in:
+//
+//   Y[m][n] = epilogue( sum_k X[m][k] * W[n][k] )            X [M][K] (row stride ldx), W [N][K] (the framework's layout)
+//
+//   LayerNorm in front   LN(x) W^T = rstd[m] * (x W'^T - mean[m] * colsum[n]) + shift[n],  W' = gamma o W,
+//                        colsum[n] = sum_k W'[n][k], shift[n] = sum_k beta[k] W[n][k] + bias[n]  (host, once per weight):
+//                        the GEMM runs on the RAW residual stream and the normalisation is two FMAs per output element.
+//                        mean / rstd come from per-(row, column-tile) partial sums that the PRODUCING call's epilogue
+//                        left behind (row_partials_out) — the row never makes a pass of its own.
+//   bias + residual      the attention / feed-forward output projections land on the residual stream directly.
+//   GEGLU                W = [h rows | gate rows]; a workgroup takes BN/2 h columns and the matching gate columns and
+//                        writes h * gelu(gate): the [M][2F] projection never exists (no-grad passes) or is written
+//                        beside the result for the backward (grad passes).
+//
+// Why an own kernel: at guidance batch 1 these are 160 launches per UNet pass of 5 - 40 k-steps each (M = 4096 ... 64
+// tokens) — prologue, epilogue and memory latency, not MFMA time.  Structure:
+//   * operands go global -> LDS directly (buffer_load ... lds, 16 bytes per lane, no staging registers, no ds_write),
+//     into a ring of NSTAGE k-steps of 64; NSTAGE - 1 steps stay in flight behind counted s_waitcnt vmcnt(N) and raw
+//     s_barrier (one barrier per k-step);  __syncthreads() would drain the ring (it waits vmcnt(0) with an LDS-DMA pending);
+//   * an LDS-DMA wave-instruction writes 1 KiB contiguously (8 rows of 128 bytes), so rows cannot be padded: the image is
+//     XOR-swizzled in 16-byte units, physical column = logical column ^ ((row >> 1) & 7), applied on the SOURCE address
+//     and on the fragment reads (the ds_read_b128 lane groups of a 32-row fragment then cover all 64 banks);
+//   * 256 threads = 2 x 2 waves, v_mfma_f32_32x32x16; the weight fragment is the A operand, the token fragment the B
+//     operand: a lane ends with 4 consecutive output features of one token per register quad, and the tile leaves through
+//     LDS as whole 16-byte row pieces;
+//   * split-K for the small-M shapes with the reduction INSIDE the launch: every slice stores its f32 accumulators
+//     write-through (sc1) in its own thread order, drains, and one lane takes a ticket; the slice whose ticket is last
+//     re-reads the others with sc1 loads IN SLICE ORDER (bitwise reproducible), runs the epilogue and returns the ticket
+//     word to zero.  No second launch, no atomics on data.
+#include "attn_common.h"
+
+using namespace ga;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBK = 64;          // depth of one k-step (elements): 128-byte LDS rows
+constexpr int kThreads = 256;
+#define GA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <typename T>
+struct Mma32L;
+template <>
+struct Mma32L<_Float16> {
+  __device__ static __forceinline__ f32x16 run(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma32L<bf16_t> {
+  __device__ static __forceinline__ f32x16 run(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+struct LinArgs {
+  int M, N, K;               // N = rows of W (GEGLU: 2F)
+  int ldx, ldy, ld_res, ld_pre;
+  int tm, tn, splits, steps, steps_per, n_fastest;
+  int F;                     // GEGLU: features of the result (N / 2); 0 otherwise
+  int ln_parts;              // LayerNorm fold: partial sums per row; 0 = no fold
+  float ln_eps, ln_inv_k;
+  unsigned x_bytes, w_bytes;
+};
+
+struct LinPtrs {
+  const void* bias;          // [N] T or null
+  const void* residual;      // [M][ld_res] T or null
+  void* preact;              // GEGLU: optional [M][ld_pre] T, the projection before the gate
+  const float* ln_partials;  // [M][ln_parts][2]
+  const float* ln_colsum;    // [N]
+  const float* ln_shift;     // [N]
+  float* ln_stats_out;       // optional [M][2] (mean, rstd)
+  float* row_partials_out;   // optional [M][tn][2]
+  float* slabs;              // split-K: [splits][tm * tn][BM * BN] f32, thread order
+  unsigned* tickets;         // split-K: [tm * tn], zero on entry and on exit
+};
+
+// workgroup -> (m tile, n tile, k slice): an XCD (workgroup ids equal mod 8) owns a contiguous run of the logical order, so
+// the tiles that share a weight slice (or a token slab) meet in one L2.  Bijective for any grid size.
+template <int BM, int BN>
+__device__ __forceinline__ void lin_tile(const LinArgs& a, int& mt, int& nt, int& split) {
+  const int total = gridDim.x, q = total >> 3, r = total & 7;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  if (a.n_fastest) {
+    nt = logical % a.tn;
+    const int rest = logical / a.tn;
+    mt = rest % a.tm;
+    split = rest / a.tm;
+  } else {
+    mt = logical % a.tm;
+    const int rest = logical / a.tm;
+    nt = rest % a.tn;
+    split = rest / a.tn;
+  }
+}
+
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
+
+// GEGLU: BN columns of the tile = BN/2 h features followed by the BN/2 gate features of the same output columns
+template <typename T, int BM, int BN, int NSTAGE, bool GEGLU, bool LN>
+__global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 64 * 1024 ? 2 : 1) void linear_kernel(
+    const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ Y, LinArgs a, LinPtrs p) {
+  constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, JN = WN / 32;
+  constexpr int kStage = (BM + BN) * kBK;                  // elements per ring slot
+  constexpr int IPS = (BM + BN) / 32;                      // LDS-DMA wave-instructions per slot and wave (8 rows each)
+  constexpr int LDC = BN + 8;                              // output staging row stride
+  constexpr int kLds = NSTAGE * kStage > BM * LDC ? NSTAGE * kStage : BM * LDC;
+  __shared__ __attribute__((aligned(1024))) T lds[kLds];   // the ONE LDS object of the kernel (ring, flags, output tile)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+  int mt, nt, split;
+  lin_tile<BM, BN>(a, mt, nt, split);
+  const int m0 = mt * BM;
+  const int n0 = GEGLU ? nt * (BN / 2) : nt * BN;          // first output column of the tile
+  const int it0 = split * a.steps_per, it1 = min(a.steps, it0 + a.steps_per);
+  const int nsteps = it1 - it0;
+
+  // ---- LDS-DMA source addresses: instruction q of this wave fills rows 8 g .. 8 g + 7 of the slot, g = wave + 4 q; lane l
+  // lands at row 8 g + (l >> 3), physical 16-byte column l & 7, and therefore fetches logical column (l & 7) ^ swizzle(row)
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W), 0, a.w_bytes, 0x00020000);
+  unsigned voff[IPS];
+#pragma unroll
+  for (int q = 0; q < IPS; ++q) {
+    const int row = 8 * (wave + 4 * q) + (lane >> 3);
+    const int col = (lane & 7) ^ ((row >> 1) & 7);
+    if (row < BM) {
+      const int m = min(m0 + row, a.M - 1);                // rows past M repeat the last one (never stored)
+      voff[q] = (unsigned)((m * a.ldx + 8 * col) * (int)sizeof(T));
+    } else {
+      const int r = row - BM;
+      int n;
+      if (GEGLU) n = r < BN / 2 ? min(n0 + r, a.F - 1) : a.F + min(n0 + r - BN / 2, a.F - 1);
+      else n = min(n0 + r, a.N - 1);
+      voff[q] = (unsigned)((n * a.K + 8 * col) * (int)sizeof(T));
+    }
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue = [&](int step, int slot) {                   // k-step `step` of this slice into ring slot `slot`
+    const unsigned koff = (unsigned)((it0 + step) * kBK * (int)sizeof(T));
+#pragma unroll
+    for (int q = 0; q < IPS; ++q) {
+      T* dst = lds + slot * kStage + (wave_u + 4 * q) * 8 * kBK;
+      if (8 * (wave_u + 4 * q) < BM)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, GA_LDS_PTR(dst), 16, voff[q], koff, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, GA_LDS_PTR(dst), 16, voff[q], koff, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses (LDS byte addresses inside slot 0): row * 128 + 16 * ((2 kk + fh) ^ swizzle(row)).  The reads
+  // are inline asm: a C++ LDS load makes the compiler wait vmcnt(0) first (any pending LDS-DMA may alias it as far as its
+  // wait-count pass can tell, and the counted waits below are invisible to it) — the ring would drain at every k-step.
+  unsigned a_adr[IM], a_sw[IM], b_adr[JN], b_sw[JN];
+  const unsigned lds0 = (unsigned)(uintptr_t)GA_LDS_PTR(lds);
+#pragma unroll
+  for (int i = 0; i < IM; ++i) {
+    const int row = wm * WM + i * 32 + fr;
+    a_adr[i] = lds0 + row * (kBK * (int)sizeof(T));
+    a_sw[i] = (unsigned)(((row >> 1) & 7) ^ fh);
+  }
+#pragma unroll
+  for (int j = 0; j < JN; ++j) {
+    const int row = BM + wn * WN + j * 32 + fr;
+    b_adr[j] = lds0 + row * (kBK * (int)sizeof(T));
+    b_sw[j] = (unsigned)(((row >> 1) & 7) ^ fh);
+  }
+
+  f32x16 acc[JN][IM];
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  // ---- LayerNorm fold: this lane's rows' statistics from the producer's partial sums (loads issued before the ring starts)
+  float ln_mean[IM], ln_rstd[IM];
+  if constexpr (LN) {
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+      const int m = min(m0 + wm * WM + i * 32 + fr, a.M - 1);
+      float s1 = 0.f, s2 = 0.f;
+      for (int q = 0; q < a.ln_parts; ++q) {
+        const float2 v = *reinterpret_cast<const float2*>(p.ln_partials + ((size_t)m * a.ln_parts + q) * 2);
+        s1 += v.x;
+        s2 += v.y;
+      }
+      const float mean = s1 * a.ln_inv_k;
+      ln_mean[i] = mean;
+      ln_rstd[i] = rsqrtf(fmaxf(s2 * a.ln_inv_k - mean * mean, 0.f) + a.ln_eps);
+    }
+  }
+
+  // ---- main loop: ring of NSTAGE slots, NSTAGE - 1 k-steps in flight
+  constexpr int PRE = NSTAGE - 1;
+#pragma unroll
+  for (int s = 0; s < PRE; ++s)
+    if (s < nsteps) issue(s, s);
+  for (int it = 0; it < nsteps; ++it) {
+    // my loads of step `it` have landed when at most the younger steps' instructions are outstanding
+    const int younger = min(nsteps - 1 - it, PRE - 1);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPS) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // everyone's part of step `it` is in LDS; everyone is done reading step it - 1
+    if (it + PRE < nsteps) issue(it + PRE, (it + PRE) % NSTAGE);   // refills the slot step it - 1 occupied
+    const unsigned slot_off = (unsigned)((it % NSTAGE) * kStage * (int)sizeof(T));
+    // fragments of sub-step kk + 1 are requested before the MFMAs of kk; LDS returns in order, so "all but the reads just
+    // issued" (a counted lgkmcnt) means the operands of kk are in their registers
+    u32x4 fa[2][IM], fb[2][JN];
+    auto request = [&](int kk, int set) {
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set][i]) : "v"(a_adr[i] + slot_off + 16u * ((2u * kk) ^ a_sw[i])) : "memory");
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][j]) : "v"(b_adr[j] + slot_off + 16u * ((2u * kk) ^ b_sw[j])) : "memory");
+    };
+    request(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < kBK / 16; ++kk) {
+      if (kk + 1 < kBK / 16) {
+        request(kk + 1, (kk + 1) & 1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(IM + JN) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the MFMAs below must not be hoisted above the wait (register-only: "memory" does not order them)
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int i = 0; i < IM; ++i)
+          acc[j][i] = Mma32L<T>::run(__builtin_bit_cast(uint4, fb[kk & 1][j]), __builtin_bit_cast(uint4, fa[kk & 1][i]), acc[j][i]);
+    }
+  }
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "the counted waits above cover up to three k-steps in flight");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // every wave's fragment reads are done: the ring memory is free for the epilogue
+
+  // ---- split-K: publish, take a ticket; only the last slice of a tile goes on
+  if (a.splits > 1) {
+    const int tile = nt * a.tm + mt;
+    const __amdgpu_buffer_rsrc_t srsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.slabs, 0, 0x7ffffff0, 0x00020000);
+    constexpr int QUADS = JN * IM * 4;
+    const unsigned per_slice = (unsigned)(a.tm * a.tn) * (BM * BN * 4u);
+    const unsigned tbase = (unsigned)tile * (BM * BN * 4u) + (unsigned)tid * 16u;
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int q = (j * IM + i) * 4 + qd;
+          const u32x4 v = {__float_as_uint(acc[j][i][4 * qd]), __float_as_uint(acc[j][i][4 * qd + 1]),
+                           __float_as_uint(acc[j][i][4 * qd + 2]), __float_as_uint(acc[j][i][4 * qd + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, srsrc, tbase + q * (kThreads * 16u), split * per_slice, 16);   // sc1
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(lds);
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag[0] = old == (unsigned)a.splits - 1;
+      if (old == (unsigned)a.splits - 1) __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int last = flag[0];
+    __syncthreads();
+    if (!last) return;
+    // fixed summation order 0, 1, ..., splits - 1 whoever arrived last (the own slice comes back from memory like the others)
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    for (int s = 0; s < a.splits; ++s) {
+      u32x4 v[QUADS];
+#pragma unroll
+      for (int q = 0; q < QUADS; ++q)
+        v[q] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, tbase + q * (kThreads * 16u), s * per_slice, 16);         // sc1
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int i = 0; i < IM; ++i)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][i][4 * qd + r] += __uint_as_float(v[(j * IM + i) * 4 + qd][r]);
+    }
+  }
+
+  // ---- epilogue.  acc[j][i][r]: tile column c = wn * WN + j * 32 + 8 * (r >> 2) + 4 * fh + (r & 3), tile row wm * WM + i * 32 + fr
+  const T* bias = static_cast<const T*>(p.bias);
+  T* Cs = lds;
+#pragma unroll
+  for (int i = 0; i < IM; ++i)
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int c = wn * WN + j * 32 + 8 * qd + 4 * fh;
+        int n;                                               // row of W this column came from
+        if (GEGLU) n = c < BN / 2 ? n0 + c : a.F + n0 + c - BN / 2;
+        else n = n0 + c;
+        const bool ok = GEGLU ? (c < BN / 2 ? n0 + c : n0 + c - BN / 2) < a.F : n < a.N;
+        float add[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          if constexpr (LN) {
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(p.ln_shift + n), cv = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) add[r] = sv[r], cs[r] = cv[r];
+          } else if (bias != nullptr) {
+            const typename Traits<T>::frag bv = load_frag<T>(bias + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) add[r] = Traits<T>::to_f32(bv[r]);
+          }
+        }
+        typename Traits<T>::frag f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[j][i][4 * qd + r];
+          if constexpr (LN) v = ln_rstd[i] * (v - ln_mean[i] * cs[r]) + add[r];
+          else v += add[r];
+          f[r] = Traits<T>::from_f32(v);
+        }
+        store_frag<T>(Cs + (wm * WM + i * 32 + fr) * LDC + c, f);
+      }
+  if constexpr (LN) {
+    if (p.ln_stats_out != nullptr && nt == 0 && wn == 0 && fh == 0) {
+#pragma unroll
+      for (int i = 0; i < IM; ++i) {
+        const int m = m0 + wm * WM + i * 32 + fr;
+        if (m < a.M) *reinterpret_cast<float2*>(p.ln_stats_out + (size_t)m * 2) = float2{ln_mean[i], ln_rstd[i]};
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int OUTC = GEGLU ? BN / 2 : BN;       // columns of Y this tile writes
+  constexpr int VPR = OUTC / 8;                   // 16-byte vectors per output row
+  static_assert((VPR & (VPR - 1)) == 0 && VPR <= 64, "the row reduction below shuffles inside a wave");
+  const T* residual = static_cast<const T*>(p.residual);
+  const int n_out = GEGLU ? a.F : a.N;
+  for (int v = tid; v < BM * VPR; v += kThreads) {
+    const int r = v / VPR, cv = (v - r * VPR) * 8;
+    const int m = m0 + r, n = n0 + cv;
+    const bool ok = m < a.M && n < n_out;
+    uint4 val = *reinterpret_cast<const uint4*>(Cs + r * LDC + cv);
+    T* e = reinterpret_cast<T*>(&val);
+    if constexpr (GEGLU) {
+      if (ok && p.preact != nullptr) {
+        T* pre = static_cast<T*>(p.preact) + (size_t)m * a.ld_pre;
+        *reinterpret_cast<uint4*>(pre + n) = val;
+        *reinterpret_cast<uint4*>(pre + a.F + n) = *reinterpret_cast<const uint4*>(Cs + r * LDC + BN / 2 + cv);
+      }
+      const uint4 gv = *reinterpret_cast<const uint4*>(Cs + r * LDC + BN / 2 + cv);
+      const T* ge = reinterpret_cast<const T*>(&gv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = Traits<T>::from_f32(Traits<T>::to_f32(e[k]) * gelu_erf(Traits<T>::to_f32(ge[k])));
+    } else if (residual != nullptr && ok) {
+      const uint4 rv = *reinterpret_cast<const uint4*>(residual + (size_t)m * a.ld_res + n);
+      const T* re = reinterpret_cast<const T*>(&rv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = Traits<T>::from_f32(Traits<T>::to_f32(e[k]) + Traits<T>::to_f32(re[k]));
+    }
+    if (ok) *reinterpret_cast<uint4*>(Y + (size_t)m * a.ldy + n) = val;
+    if (p.row_partials_out != nullptr) {
+      // (sum, sum of squares) of the values AS STORED over this tile's columns of the row: VPR adjacent lanes hold one row
+      float s1 = 0.f, s2 = 0.f;
+      if (ok) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float x = Traits<T>::to_f32(e[k]);
+          s1 += x;
+          s2 += x * x;
+        }
+      }
+#pragma unroll
+      for (int o = VPR >> 1; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+      }
+      if ((v & (VPR - 1)) == 0 && m < a.M)
+        *reinterpret_cast<float2*>(p.row_partials_out + ((size_t)m * a.tn + nt) * 2) = float2{s1, s2};
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int NSTAGE>
+int launch_lin(const T* X, const T* W, T* Y, LinArgs a, const LinPtrs& p, hipStream_t s) {
+  const int outc = a.F ? BN / 2 : BN, n_out = a.F ? a.F : a.N;
+  a.tm = (a.M + BM - 1) / BM;
+  a.tn = (n_out + outc - 1) / outc;
+  a.steps = a.K / kBK;
+  a.steps_per = (a.steps + a.splits - 1) / a.splits;
+  {  // bytes that reach the fabric if each XCD fetches what its run of workgroups shares once (as in conv3x3.hip)
+    const double xb = (double)a.M * a.K, wb = (double)a.N * a.K;
+    const double m_first = wb + xb * (a.tn * a.splits < 8 ? a.tn * a.splits : 8), n_first = xb + wb * (a.tm < 8 ? a.tm : 8);
+    a.n_fastest = n_first < m_first ? 1 : 0;
+  }
+  const dim3 grid((unsigned)(a.tm * a.tn * a.splits));
+  const bool ln = a.ln_parts > 0;
+#define GA_LIN_LAUNCH(G, L) hipLaunchKernelGGL((linear_kernel<T, BM, BN, NSTAGE, G, L>), grid, dim3(kThreads), 0, s, X, W, Y, a, p)
+  if (a.F) {
+    if (ln) GA_LIN_LAUNCH(true, true);
+    else GA_LIN_LAUNCH(true, false);
+  } else {
+    if (ln) GA_LIN_LAUNCH(false, true);
+    else GA_LIN_LAUNCH(false, false);
+  }
+#undef GA_LIN_LAUNCH
+  return check_launch();
+}
+
+template <typename T>
+int lin_t(const void* X, const void* W, void* Y, const LinArgs& a, const LinPtrs& p, int bm, int bn, hipStream_t s) {
+  const T* x = (const T*)X;
+  const T* w = (const T*)W;
+  if (bm == 128 && bn == 128) return launch_lin<T, 128, 128, 3>(x, w, (T*)Y, a, p, s);
+  if (bm == 128 && bn == 64) return launch_lin<T, 128, 64, 4>(x, w, (T*)Y, a, p, s);
+  if (bm == 64 && bn == 128) return launch_lin<T, 64, 128, 4>(x, w, (T*)Y, a, p, s);
+  if (bm == 64 && bn == 64) return launch_lin<T, 64, 64, 4>(x, w, (T*)Y, a, p, s);
+  return GA_ERR_SHAPE;
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int ga_linear_workspace(int64_t M, int N, int bm, int bn, int splits, int geglu, long long* slab_floats, int* tiles) {
+  if (!slab_floats || !tiles) return GA_ERR_NULL;
+  if (M < 1 || N < 8 || splits < 1 || (bm != 64 && bm != 128) || (bn != 64 && bn != 128)) return GA_ERR_SHAPE;
+  const int outc = geglu ? bn / 2 : bn, n_out = geglu ? N / 2 : N;
+  const long long tm = (M + bm - 1) / bm, tn = (n_out + outc - 1) / outc;
+  *tiles = (int)(tm * tn);
+  *slab_floats = splits > 1 ? (long long)splits * tm * tn * bm * bn : 0;
+  return GA_OK;
+}
+
+extern "C" int ga_linear_fused(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, const ga_linear_epilogue_t* ep,
+                               float* slabs, unsigned* tickets, int64_t M, int K, int N, int bm, int bn, int splits,
+                               int dtype, ga_stream_t stream) {
+  if (!X || !W || !Y || !ep) return GA_ERR_NULL;
+  if (M < 1 || K < kBK || K % kBK != 0 || N < 8 || N % 8 != 0 || ldx < K || ldx % 8 != 0 || ldy % 8 != 0) return GA_ERR_SHAPE;
+  if (splits < 1 || splits > 64 || K / kBK < splits || (splits > 1 && (!slabs || !tickets))) return GA_ERR_SHAPE;
+  const int n_out = ep->geglu ? N / 2 : N;
+  if (ep->geglu && (N % 16 != 0 || ep->residual)) return GA_ERR_SHAPE;
+  if (ldy < n_out || (ep->residual && (ep->ld_res < n_out || ep->ld_res % 8 != 0))) return GA_ERR_SHAPE;
+  if (ep->preact && (!ep->geglu || ep->ld_pre < N || ep->ld_pre % 8 != 0)) return GA_ERR_SHAPE;
+  if (ep->ln_partials && (ep->ln_parts < 1 || !ep->ln_colsum || !ep->ln_shift)) return GA_ERR_NULL;
+  if (!al16(X) || !al16(W) || !al16(Y) || (ep->bias && !al16(ep->bias)) || (ep->residual && !al16(ep->residual)) ||
+      (ep->preact && !al16(ep->preact)) || (ep->ln_colsum && !al16(ep->ln_colsum)) || (ep->ln_shift && !al16(ep->ln_shift)))
+    return GA_ERR_ALIGN;
+  const long long xb = ((long long)(M - 1) * ldx + K) * 2, wb = (long long)N * K * 2;
+  if (xb >= (1LL << 31) || wb >= (1LL << 31)) return GA_ERR_SHAPE;   // 32-bit byte offsets in the buffer loads
+  LinArgs a;
+  a.M = (int)M; a.N = N; a.K = K;
+  a.ldx = (int)ldx; a.ldy = (int)ldy; a.ld_res = (int)ep->ld_res; a.ld_pre = (int)ep->ld_pre;
+  a.splits = splits;
+  a.F = ep->geglu ? N / 2 : 0;
+  a.ln_parts = ep->ln_partials ? ep->ln_parts : 0;
+  a.ln_eps = ep->ln_eps;
+  a.ln_inv_k = 1.0f / (float)K;
+  a.x_bytes = (unsigned)xb;
+  a.w_bytes = (unsigned)wb;
+  if (splits > 1) {
+    long long need; int tiles;
+    if (ga_linear_workspace(M, N, bm, bn, splits, ep->geglu, &need, &tiles) != GA_OK) return GA_ERR_SHAPE;
+    if (need * 4 >= (1LL << 31)) return GA_ERR_SHAPE;
+  }
+  LinPtrs p;
+  p.bias = ep->bias; p.residual = ep->residual; p.preact = ep->preact;
+  p.ln_partials = ep->ln_partials; p.ln_colsum = ep->ln_colsum; p.ln_shift = ep->ln_shift;
+  p.ln_stats_out = ep->ln_stats_out; p.row_partials_out = ep->row_partials_out;
+  p.slabs = slabs; p.tickets = tickets;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case GA_F16: return lin_t<_Float16>(X, W, Y, a, p, bm, bn, s);
+    case GA_BF16: return lin_t<bf16_t>(X, W, Y, a, p, bm, bn, s);
+    default: return GA_ERR_DTYPE;
+  }
+}

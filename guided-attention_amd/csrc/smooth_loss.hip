@@ -17,6 +17,7 @@
 // and hinge terms  inside = sum_in W * 2*max(0, 1/n_in - Pn),  outside = sum_out W * max(0, Pn).
 // The reference hard-codes res = 16 ("16", "15."); res and res-1 are used here (identical at 16).
 #include "aggregate.h"
+#include "attn_common.h"
 
 using namespace ga;
 
@@ -30,6 +31,7 @@ struct LossArgs {
   const float* A;
   int res, Kt, first, last, T;
   int ksize, smooth, strict;
+  int stage_rows;   // pixel rows of A staged through LDS per pass of the softmax statistics (0: read from global memory)
   float w_in, w_out3, w_c;
   double shrink;
   ga_token_t tok[kMaxTok];
@@ -75,34 +77,41 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
   return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
 }
 
-// per-pixel softmax statistics of 100*A over the text slice: row max and sum of exponentials.  One WAVE per pixel row
-// (lanes along the token axis: the row's 77 floats are two coalesced loads; a thread per row read 64 cache lines per
-// load instruction and walked its row serially — most of the 35 us the single-workgroup kernel took in round 2).
-__device__ __forceinline__ void pixel_softmax_stats(const LossArgs& a, float* mx, float* sm) {
-  const int npix = a.res * a.res, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int width = a.last - a.first;
-  for (int p0 = wave * 4; p0 < npix; p0 += 4 * (kThreads / 64)) {   // 4 rows per trip: their loads are all in flight together
-    float v[4][2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* row = a.A + (size_t)min(p0 + r, npix - 1) * a.Kt + a.first;
-      v[r][0] = lane < width ? row[lane] * 100.0f : -INFINITY;
-      v[r][1] = lane + 64 < width ? row[lane + 64] * 100.0f : -INFINITY;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float m = fmaxf(v[r][0], v[r][1]);
-      const float* row = a.A + (size_t)min(p0 + r, npix - 1) * a.Kt + a.first;
-      for (int c = lane + 128; c < width; c += 64) m = fmaxf(m, row[c] * 100.0f);   // Kt > 129 only
-      m = wave_reduce_max(m);
-      float e = (lane < width ? expf(v[r][0] - m) : 0.f) + (lane + 64 < width ? expf(v[r][1] - m) : 0.f);
-      for (int c = lane + 128; c < width; c += 64) e += expf(row[c] * 100.0f - m);
-      e = wave_reduce_sum(e);
-      if (lane == 0 && p0 + r < npix) {
-        mx[p0 + r] = m;
-        sm[p0 + r] = e;
-      }
-    }
+// per-pixel softmax statistics of 100*A over the text slice: row max and sum of exponentials, each row summed in token
+// order by ONE thread (the order the fixtures of the reference's fp32 softmax were matched with: a tree-ordered sum moves
+// the near-one-hot rows by more than the 3e-5 bar after the x100 backward).  The rows are staged through LDS in chunks
+// of `stage_rows` pixels with coalesced 16-byte loads (a chunk of A is contiguous), and a thread then walks its row in LDS
+// (row stride Kt words: conflict-free for the odd Kt of the text context).  Walking the rows straight from global memory
+// — 64 different cache lines per load instruction, 150 dependent-latency loads per thread — was most of the 35 us the
+// single-workgroup kernel took in round 2; `stage_rows` = 0 (maps too large for the LDS budget) keeps that form.
+__device__ __forceinline__ float* align16(float* p) {
+  return reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
+}
+
+__device__ __forceinline__ void row_stats(const LossArgs& a, const float* row, float& m_out, float& s_out) {
+  float m = -INFINITY;
+  for (int c = a.first; c < a.last; ++c) m = fmaxf(m, row[c] * 100.0f);
+  float s = 0.f;
+  for (int c = a.first; c < a.last; ++c) s += expf(row[c] * 100.0f - m);
+  m_out = m;
+  s_out = s;
+}
+
+__device__ __forceinline__ void pixel_softmax_stats(const LossArgs& a, float* mx, float* sm, float* stage) {
+  const int npix = a.res * a.res;
+  if (a.stage_rows == 0) {
+    for (int p = threadIdx.x; p < npix; p += kThreads) row_stats(a, a.A + (size_t)p * a.Kt, mx[p], sm[p]);
+    return;
+  }
+  for (int p0 = 0; p0 < npix; p0 += a.stage_rows) {
+    const int rows = min(a.stage_rows, npix - p0), n = rows * a.Kt;
+    const float* src = a.A + (size_t)p0 * a.Kt;      // 16-byte aligned: stage_rows is a multiple of 4, A is
+    for (int e = 4 * threadIdx.x; e + 3 < n; e += 4 * kThreads)
+      *reinterpret_cast<f32x4*>(stage + e) = *reinterpret_cast<const f32x4*>(src + e);
+    for (int e = (n & ~3) + threadIdx.x; e < n; e += kThreads) stage[e] = src[e];
+    __syncthreads();
+    for (int r = threadIdx.x; r < rows; r += kThreads) row_stats(a, stage + r * a.Kt, mx[p0 + r], sm[p0 + r]);
+    __syncthreads();
   }
 }
 
@@ -275,7 +284,8 @@ __device__ __forceinline__ void loss_forward(const LossArgs& a, float* lds, floa
   float* Pn = M + npix;
   float* scratch = Pn + npix;  // 16 floats
   float* W = scratch + 16;     // [npix], strict mode only
-  pixel_softmax_stats(a, mx, sm);
+  float* stage = align16(W + (a.strict ? npix : 0));   // [stage_rows][Kt]
+  pixel_softmax_stats(a, mx, sm, stage);
   __syncthreads();
   float total = 0.f;
   for (int t = 0; t < a.T; ++t) {
@@ -355,8 +365,9 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
   int* colmap = reinterpret_cast<int*>(scratch + 16);  // [Kt]: guided-token slot of column c, or -1
   float* dS = reinterpret_cast<float*>(colmap + ((a.Kt + 3) & ~3));  // [T][npix]
   float* W = dS + (size_t)a.T * npix;                                // [npix], strict mode only
+  float* stage = align16(W + (a.strict ? npix : 0));                 // [stage_rows][Kt]
 
-  pixel_softmax_stats(a, mx, sm);
+  pixel_softmax_stats(a, mx, sm, stage);
   for (int c = threadIdx.x; c < a.Kt; c += kThreads) colmap[c] = -1;
   __syncthreads();
   const int pad = a.ksize >> 1;
@@ -438,6 +449,17 @@ size_t fwd_lds(int npix, int strict) { return sizeof(float) * ((4 + (strict ? 1 
 size_t bwd_lds(int npix, int Kt, int T, int strict) {
   return sizeof(float) * ((6 + (strict ? 1 : 0)) * (size_t)npix + 16 + ((Kt + 3) & ~3) + (size_t)T * npix);
 }
+constexpr size_t kLdsBudget = 150 * 1024;
+// rows of A staged per pass: as many as fit beside the kernel's tables, at most one per thread, a multiple of 4
+int choose_stage_rows(size_t base_lds, int npix, int Kt, const float* A) {
+  if ((reinterpret_cast<uintptr_t>(A) & 15) != 0) return 0;
+  base_lds += 16;   // the staging area starts on a 16-byte boundary
+  for (int rows = kThreads; rows >= 32; rows >>= 1) {
+    const int r = rows < npix ? rows : ((npix + 3) & ~3);
+    if (base_lds + sizeof(float) * (size_t)r * Kt <= kLdsBudget) return r;
+  }
+  return 0;
+}
 
 int fill_args(LossArgs& a, const float* A, int res, int Kt, int first, int last, const ga_token_t* tokens, int T,
               const ga_loss_params_t* hp) {
@@ -502,12 +524,11 @@ extern "C" int ga_smooth_loss_fwd(const float* A, int res, int Kt, int first, in
   LossArgs a;
   int rc = fill_args(a, A, res, Kt, first, last, tokens, T, hp);
   if (rc != GA_OK) return rc;
-  const size_t lds = fwd_lds(res * res, a.strict);
-  if (lds > 150 * 1024) return GA_ERR_SHAPE;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(smooth_loss_fwd_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return GA_ERR_LAUNCH;
+  size_t lds = fwd_lds(res * res, a.strict);
+  if (lds > kLdsBudget) return GA_ERR_SHAPE;
+  a.stage_rows = choose_stage_rows(lds, res * res, Kt, A);
+  lds += sizeof(float) * (size_t)a.stage_rows * Kt + 16;
+  if (set_dyn_lds(smooth_loss_fwd_kernel, lds) != GA_OK) return GA_ERR_LAUNCH;
   hipLaunchKernelGGL(smooth_loss_fwd_kernel, dim3(1), dim3(kThreads), lds, static_cast<hipStream_t>(stream), a, terms,
                      loss);
   return check_launch();
@@ -517,9 +538,7 @@ template <typename T>
 static int launch_loss_bwd(const LossArgs& a, const float* dloss, float* dA, void* dPb, float bs, size_t lds,
                            hipStream_t s) {
   auto k = smooth_loss_bwd_kernel<T>;
-  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return GA_ERR_LAUNCH;
+  if (set_dyn_lds(k, lds) != GA_OK) return GA_ERR_LAUNCH;
   // up to 16 workgroups, at least 4 elements of the tail per thread
   const int total = a.res * a.res * a.Kt;
   const int wgs = max(1, min(16, total / (4 * kThreads)));
@@ -534,8 +553,10 @@ extern "C" int ga_smooth_loss_bwd(const float* A, int res, int Kt, int first, in
   LossArgs a;
   int rc = fill_args(a, A, res, Kt, first, last, tokens, T, hp);
   if (rc != GA_OK) return rc;
-  const size_t lds = bwd_lds(res * res, Kt, T, a.strict);
-  if (lds > 150 * 1024) return GA_ERR_SHAPE;
+  size_t lds = bwd_lds(res * res, Kt, T, a.strict);
+  if (lds > kLdsBudget) return GA_ERR_SHAPE;
+  a.stage_rows = choose_stage_rows(lds, res * res, Kt, A);
+  lds += sizeof(float) * (size_t)a.stage_rows * Kt + 16;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case GA_F16:
@@ -553,9 +574,7 @@ template <typename T>
 static int launch_aggregate_loss(const AggArgs& g, const LossArgs& a, int n_elem, float* A, float* terms, float* loss,
                                  unsigned* ticket, size_t lds, hipStream_t s) {
   auto k = aggregate_loss_fwd_kernel<T>;
-  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return GA_ERR_LAUNCH;
+  if (set_dyn_lds(k, lds) != GA_OK) return GA_ERR_LAUNCH;
   hipLaunchKernelGGL(k, dim3((n_elem + kThreads - 1) / kThreads), dim3(kThreads), lds, s, g, a, n_elem, A, terms, loss,
                      ticket);
   return check_launch();
@@ -571,8 +590,10 @@ extern "C" int ga_aggregate_loss_fwd(const void* const* maps, const int* heads, 
   LossArgs a;
   rc = fill_args(a, A, res, Kt, first, last, tokens, T, hp);
   if (rc != GA_OK) return rc;
-  const size_t lds = fwd_lds(res * res, a.strict);
-  if (lds > 150 * 1024) return GA_ERR_SHAPE;
+  size_t lds = fwd_lds(res * res, a.strict);
+  if (lds > kLdsBudget) return GA_ERR_SHAPE;
+  a.stage_rows = choose_stage_rows(lds, res * res, Kt, A);
+  lds += sizeof(float) * (size_t)a.stage_rows * Kt + 16;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int n_elem = res * res * Kt;
   switch (dtype) {

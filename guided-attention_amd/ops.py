@@ -1051,3 +1051,141 @@ class SelfAttentionFusedQKV(torch.autograd.Function):
 def self_attention_supported(q, heads, channels=None):
     d = (channels or q.shape[-1]) // heads
     return q.is_cuda and d % 8 == 0 and d <= (80 if q.dtype == torch.float32 else 160) and q.dtype in _lib.DTYPE_CODE
+
+
+# --------------------------------------------------------------------------------------- Linear layers with folded neighbours
+_lin_ws = {}        # device index -> {"slabs": f32 tensor, "tickets": int32 tensor}; never freed (captured graphs hold the pointers)
+_lin_plan_cache = {}
+_lin_plan_table = None
+LIN_SLAB_FLOATS = 16 * 2 ** 20     # 64 MB of split-K slabs per device, allocated once (outside any capture)
+LIN_TICKETS = 1 << 16
+
+
+def linear_workspace(device):
+    ws = _lin_ws.get(device.index)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise GaError("the Linear workspace must exist before a hipGraph capture (call ops.prepare_device first)")
+        ws = _lin_ws[device.index] = {"slabs": torch.empty(LIN_SLAB_FLOATS, dtype=torch.float32, device=device),
+                                      "tickets": torch.zeros(LIN_TICKETS, dtype=torch.int32, device=device)}
+    return ws
+
+
+def prepare_device(device):
+    """Allocate the persistent per-device scratch of the kernels (split-K slabs, arrival tickets) — once, before any
+    hipGraph capture, so that captured launches and eager launches share the same, never-moving buffers."""
+    device = torch.device(device)
+    if device.type == "cuda":
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        linear_workspace(device)
+        _ticket(device)
+
+
+def _measured_linear_plans():
+    global _lin_plan_table
+    if _lin_plan_table is None:
+        import json
+        from pathlib import Path
+        path = Path(__file__).resolve().parent / "linear_plans.json"
+        _lin_plan_table = {}
+        if path.exists():
+            for k, v in json.loads(path.read_text()).items():
+                _lin_plan_table[tuple(int(x) for x in k.split(","))] = tuple(v)
+    return _lin_plan_table
+
+
+def linear_plan(M, K, N, geglu=False):
+    """(bm, bn, splits) for Y[M][N or N/2] = X[M][K] W[N][K]^T: the measured table (tools/linear_tune.py) or a rule:
+    about one workgroup per CU and more; the depth is split when the tiles alone leave most of the chip idle."""
+    key = (int(M), int(K), int(N), int(bool(geglu)))
+    plan = _lin_plan_cache.get(key)
+    if plan is None:
+        plan = _measured_linear_plans().get(key)
+        if plan is None:
+            n_out = N // 2 if geglu else N
+            steps = K // 64
+            best, best_cost = None, None
+            for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64)):
+                outc = bn // 2 if geglu else bn
+                tiles = -(-M // bm) * -(-n_out // outc)
+                waste = (-(-M // bm) * bm) * (-(-n_out // outc) * outc) / (M * n_out)
+                for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+                    if sp > 1 and steps // sp < 4:
+                        break
+                    wgs = tiles * sp
+                    rounds = -(-wgs // 256)
+                    per_wg = -(-steps // sp) * (0.09 if bm * bn == 128 * 128 else 0.055 if bm * bn == 128 * 64 else 0.04)
+                    cost = rounds * (1.2 + per_wg) * waste ** 0.5 + (1.5 + sp * bm * bn * 4 / 100e3 if sp > 1 else 0.0)
+                    if best_cost is None or cost < best_cost:
+                        best, best_cost = (bm, bn, sp), cost
+            plan = best
+        _lin_plan_cache[key] = plan
+    return plan
+
+
+def linear_fused(x, weight, bias=None, residual=None, geglu=False, want_preact=False, ln=None, want_ln_stats=False,
+                 want_row_partials=False, plan=None, out=None):
+    """Y = epilogue(X W^T) through ga_linear_fused (see include/ga_hip.h).
+    x (..., K): rows `x.stride(-2)` elements apart, last dimension contiguous; weight (N, K) contiguous.
+    ln = (partials (M, parts, 2) f32, colsum (N,) f32, shift (N,) f32, eps): LayerNorm folded in front (then `weight` is
+    gamma o W and `bias` is ignored).  -> dict(y, preact, ln_stats, row_partials, parts)."""
+    require_cuda(x, weight, bias, residual)
+    if x.stride(-1) != 1 or not weight.is_contiguous():
+        raise GaError("linear_fused needs unit-stride feature axes")
+    K = x.shape[-1]
+    lead = x.shape[:-1]
+    M = 1
+    for d in lead:
+        M *= d
+    ldx = x.stride(-2) if x.dim() > 1 else K
+    if x.dim() > 2 and any(x.stride(i) != x.stride(i + 1) * x.shape[i + 1] for i in range(x.dim() - 2)):
+        x = x.contiguous()
+        ldx = K
+    N = weight.shape[0]
+    n_out = N // 2 if geglu else N
+    bm, bn, splits = plan or linear_plan(M, K, N, geglu)
+    y = out if out is not None else torch.empty(lead + (n_out,), dtype=x.dtype, device=x.device)
+    ep = _lib.ga_linear_epilogue_t()
+    ep.bias = bias.data_ptr() if bias is not None else None
+    if residual is not None:
+        if residual.stride(-1) != 1 or tuple(residual.shape) != tuple(y.shape):
+            raise GaError("residual must have the result's shape and a unit-stride feature axis")
+        if residual.dim() > 2 and any(residual.stride(i) != residual.stride(i + 1) * residual.shape[i + 1]
+                                      for i in range(residual.dim() - 2)):
+            residual = residual.contiguous()
+        ep.residual, ep.ld_res = residual.data_ptr(), residual.stride(-2) if residual.dim() > 1 else n_out
+    ep.geglu = int(bool(geglu))
+    preact = None
+    if geglu and want_preact:
+        preact = torch.empty(lead + (N,), dtype=x.dtype, device=x.device)
+        ep.preact, ep.ld_pre = preact.data_ptr(), N
+    ln_stats = None
+    if ln is not None:
+        partials, colsum, shift, eps = ln
+        if partials.dtype != torch.float32 or tuple(partials.shape) != (M, partials.shape[1], 2) or not partials.is_contiguous():
+            raise GaError("LayerNorm partial sums must be a contiguous (M, parts, 2) float32 tensor")
+        ep.ln_partials, ep.ln_parts, ep.ln_eps = partials.data_ptr(), partials.shape[1], float(eps)
+        ep.ln_colsum, ep.ln_shift = colsum.data_ptr(), shift.data_ptr()
+        if want_ln_stats:
+            ln_stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+            ep.ln_stats_out = ln_stats.data_ptr()
+    outc = bn // 2 if geglu else bn
+    parts = -(-n_out // outc)
+    row_partials = None
+    if want_row_partials:
+        row_partials = torch.empty((M, parts, 2), dtype=torch.float32, device=x.device)
+        ep.row_partials_out = row_partials.data_ptr()
+    slabs = tickets = None
+    if splits > 1:
+        ws = linear_workspace(x.device)
+        tiles = -(-M // bm) * parts
+        if splits * tiles * bm * bn > ws["slabs"].numel() or tiles > ws["tickets"].numel():
+            raise GaError(f"split-K workspace too small for M={M} N={N} plan {(bm, bn, splits)}")
+        slabs, tickets = ws["slabs"], ws["tickets"]
+    _count(("linear", M, K, 0, int(bool(geglu)) + 2 * int(ln is not None) + 4 * int(residual is not None), N, bias is not None,
+            str(x.dtype)))
+    check(load().ga_linear_fused(_ptr(x), ldx, _ptr(weight), _ptr(y), y.stride(-2) if y.dim() > 1 else n_out,
+                                 ctypes.byref(ep), _ptr(slabs), _ptr(tickets), M, K, N, bm, bn, splits, dtype_code(x),
+                                 stream_ptr()), "ga_linear_fused")
+    return {"y": y, "preact": preact, "ln_stats": ln_stats, "row_partials": row_partials, "parts": parts}

@@ -270,6 +270,51 @@ int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* workspace, co
 int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspace, const void* bias, const void* residual, int64_t M,
                int K, int N, int bm, int bn, int splits, int dtype, ga_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Linear layers of the transformer blocks with their element-wise neighbours folded in
+ * (diffusers 0.12.1 CrossAttention.to_q/to_k/to_v/to_out, Transformer2DModel.proj_in/proj_out, FeedForward:
+ * utils/ptp_utils.py:70-91 and the blocks called from pipeline_guided_attention.py:647-738):
+ *
+ *     Y[m][n] = epilogue( sum_k X[m][k] * W[n][k] )      X [M][K] T (row stride ldx), W [N][K] T, Y row stride ldy
+ *
+ *   bias        [N] T or NULL            added before anything else (ignored with ln_partials: ln_shift carries it)
+ *   residual    [M][ld_res] T or NULL    added to the result (the residual stream)
+ *   geglu       1: W = [F h rows | F gate rows], Y [M][F] = (h + bias_h) * gelu(g + bias_g)  (diffusers GEGLU);
+ *               preact (optional) [M][ld_pre] T receives the [M][2F] projection for the backward
+ *   ln_partials [M][ln_parts][2] f32 or NULL: (sum, sum of squares) of X's rows in ln_parts pieces (what an earlier call
+ *               left in row_partials_out).  The call then computes LayerNorm(X) W0^T + bias0 as
+ *                   rstd[m] * (sum_k X[m][k] W[n][k] - mean[m] * ln_colsum[n]) + ln_shift[n]
+ *               where the caller passes W = gamma o W0, ln_colsum[n] = sum_k W[n][k] (f32),
+ *               ln_shift[n] = sum_k beta[k] W0[n][k] + bias0[n] (f32), eps = ln_eps.
+ *   ln_stats_out     optional [M][2] f32 (mean, rstd) of the rows (what ga_add_layer_norm_bwd reads)
+ *   row_partials_out optional [M][tn][2] f32, tn = ceil(N_out / bn): (sum, sum of squares) of the STORED result rows per
+ *               column tile — the ln_partials of the next call (ln_parts = tn)
+ * bm x bn in {64,128} x {64,128} is the tile (geglu: bn/2 result columns per tile); splits > 1 divides K over
+ * workgroups: each slice stores its f32 accumulators to `slabs`, the slice that arrives last sums them in slice order
+ * (bitwise reproducible) and runs the epilogue — one launch.  ga_linear_workspace gives the sizes: `slabs` f32
+ * [slab_floats], `tickets` [tiles] 32-bit words that are ZERO on entry (the kernel leaves them zero); launches that
+ * share them must be stream-ordered.  K % 64 == 0, N % 8 == 0, 16-bit dtypes. */
+typedef struct {
+  const void* bias;
+  const void* residual;
+  int64_t ld_res;
+  int geglu;
+  void* preact;
+  int64_t ld_pre;
+  const float* ln_partials;
+  int ln_parts;
+  float ln_eps;
+  const float* ln_colsum;
+  const float* ln_shift;
+  float* ln_stats_out;
+  float* row_partials_out;
+} ga_linear_epilogue_t;
+
+int ga_linear_workspace(int64_t M, int N, int bm, int bn, int splits, int geglu, long long* slab_floats, int* tiles);
+int ga_linear_fused(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, const ga_linear_epilogue_t* ep,
+                    float* slabs, unsigned* tickets, int64_t M, int K, int N, int bm, int bn, int splits, int dtype,
+                    ga_stream_t stream);
+
 /* Residual add + LayerNorm (diffusers 0.12.1 BasicTransformerBlock.forward: x = attn(norm(x)) + x; norm_next(x)):
  *   fwd: x_new = a + x (rounded to T), y = LayerNorm(x_new) * gamma + beta, stats [rows][2] f32 = (mean, rstd).
  *        a == NULL: plain LayerNorm of x (x_new is not written and may be NULL).  stats may be NULL (inference).

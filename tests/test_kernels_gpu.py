@@ -814,3 +814,98 @@ def test_gemm_nt(ops, shape, dt):
             assert rc == 0
             close(y, ref.numpy(), TOL[dt] * 2, f"gemm tile {bm}x{bn} splits {sp}")
     assert load().ga_gemm_nt(P(x), P(w), P(y), None, None, None, M, K + 8, N, 64, 64, 1, dtype_code(x), stream_ptr()) < 0
+
+
+# ------------------------------------------------------------------------------------- Linear layers with folded neighbours
+LIN_SHAPES = [  # M, K, N
+    (4096, 320, 320), (1024, 640, 1920), (256, 1280, 1280), (64, 1280, 640), (200, 64, 72), (130, 192, 264), (768, 2560, 640)]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", LIN_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_linear_fused(ops, shape, dt):
+    """ga_linear_fused against fp64 on the CPU, every tile, with and without the in-launch split-K reduction:
+    bias / bias + residual; GEGLU (incl. the pre-activation copy for the backward); LayerNorm folded in front with the
+    row statistics taken from the partial sums an earlier call's epilogue left (the producer -> consumer chain of a
+    transformer block), its (mean, rstd) output; ragged M and N.  Split-K results must not depend on arrival order:
+    repeated launches are bitwise equal."""
+    M, K, N = shape
+    T = DT[dt]
+    x = dev(hashrand.normalish((M, K), 70 + M) * 1.5 + 0.3, T)
+    w = dev(hashrand.normalish((N, K), 71 + N) * K ** -0.5, T)
+    bias = dev(hashrand.normalish((N,), 72) * 0.3, T)
+    res = dev(hashrand.normalish((M, N), 73), T)
+    xd, wd, bd, rd = x.double().cpu(), w.double().cpu(), bias.double().cpu(), res.double().cpu()
+    ref_plain = xd @ wd.T + bd
+    tol = TOL[dt] * 2
+    steps = K // 64
+    for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64)):
+        for splits in (1, 2, 5):
+            if steps // splits < 1:
+                continue
+            plan = (bm, bn, splits)
+            y = ops.linear_fused(x, w, bias, plan=plan)["y"]
+            close(y, ref_plain.numpy(), tol, f"bias {plan}")
+            y = ops.linear_fused(x, w, bias, residual=res, plan=plan)["y"]
+            close(y, (ref_plain + rd).numpy(), tol, f"bias + residual {plan}")
+            y = ops.linear_fused(x, w, None, plan=plan)["y"]
+            close(y, (xd @ wd.T).numpy(), tol, f"no bias {plan}")
+            if splits > 1:
+                again = [ops.linear_fused(x, w, bias, residual=res, plan=plan)["y"] for _ in range(3)]
+                first = ops.linear_fused(x, w, bias, residual=res, plan=plan)["y"]
+                assert all(torch.equal(first, a) for a in again), f"split-K not reproducible {plan}"
+            if N % 16 == 0:
+                F_ = N // 2
+                out = ops.linear_fused(x, w, bias, geglu=True, want_preact=True, plan=plan)
+                pre = out["preact"].double().cpu()          # the rounded projection is what the gate sees
+                close(out["preact"], ref_plain.numpy(), tol, f"geglu preact {plan}")
+                g = pre[:, F_:]
+                ref_g = pre[:, :F_] * (0.5 * g * (1.0 + torch.erf(g / math.sqrt(2.0))))
+                close(out["y"], ref_g.numpy(), tol, f"geglu {plan}")
+                y2 = ops.linear_fused(x, w, bias, geglu=True, plan=plan)["y"]
+                assert torch.equal(y2, out["y"])
+    assert int(ops.linear_workspace(x.device)["tickets"].abs().sum().item()) == 0      # every ticket word is back to zero
+    # LayerNorm fold: x itself comes out of a producing call (so that its row partial sums exist)
+    gamma = dev(hashrand.normalish((K,), 74) * 0.2 + 1.0, T)
+    beta = dev(hashrand.normalish((K,), 75) * 0.2, T)
+    w0 = dev(hashrand.normalish((K, K), 76) * K ** -0.5, T)
+    for pplan in ((128, 64, 1), (64, 64, 1), (128, 128, 1)):
+        prod = ops.linear_fused(x, w0, None, residual=x, want_row_partials=True, plan=pplan)
+        h = prod["y"]                                   # (M, K): the "residual stream" the LayerNorm reads
+        hd = h.double().cpu()
+        s = hd.sum(-1)
+        close(prod["row_partials"][:, :, 0].sum(1), s.numpy(), 1e-5, "row partial sums")
+        close(prod["row_partials"][:, :, 1].sum(1), (hd * hd).sum(-1).numpy(), 1e-5, "row partial sums of squares")
+        wg = (w.float() * gamma.float()[None, :]).to(T)                   # gamma o W, rounded once (what the host caches)
+        colsum = wg.float().sum(1)
+        shift = (w.float() @ beta.float()) + bias.float()
+        mean, var = hd.mean(-1, keepdim=True), hd.var(-1, unbiased=False, keepdim=True)
+        ln = (hd - mean) / torch.sqrt(var + 1e-5) * gamma.double().cpu() + beta.double().cpu()
+        ref_ln = ln @ wd.T + bd
+        for plan in ((128, 64, 1), (64, 64, 2), (128, 128, 1), (64, 128, 1)):
+            if K // 64 < plan[2]:
+                continue
+            out = ops.linear_fused(h, wg, None, ln=(prod["row_partials"], colsum, shift, 1e-5), want_ln_stats=True, plan=plan)
+            close(out["y"], ref_ln.numpy(), tol * 2, f"LayerNorm fold {pplan} -> {plan}")
+            close(out["ln_stats"][:, 0], mean[:, 0].numpy(), 1e-4, "mean")
+            close(out["ln_stats"][:, 1], (1.0 / torch.sqrt(var + 1e-5))[:, 0].numpy(), 1e-3, "rstd")
+            if N % 16 == 0:
+                og = ops.linear_fused(h, wg, None, geglu=True, ln=(prod["row_partials"], colsum, shift, 1e-5), plan=plan)["y"]
+                pre = out["y"].double().cpu()
+                g = pre[:, N // 2:]
+                close(og, (pre[:, :N // 2] * (0.5 * g * (1.0 + torch.erf(g / math.sqrt(2.0))))).numpy(), tol * 2,
+                      f"LayerNorm + GEGLU {plan}")
+
+
+def test_linear_fused_strided_rows_and_errors(ops):
+    """Column slices of a wider tensor as input / residual (row stride > K), and the argument checks."""
+    big = dev(hashrand.normalish((300, 3 * 128), 80), torch.float16)
+    w = dev(hashrand.normalish((64, 128), 81) * 0.1, torch.float16)
+    for j in range(3):
+        xs = big[:, 128 * j:128 * (j + 1)]
+        y = ops.linear_fused(xs, w, None, plan=(64, 64, 1))["y"]
+        close(y, (xs.double().cpu() @ w.double().cpu().T).numpy(), 4e-3, f"slice {j}")
+    with pytest.raises(ops.GaError):
+        ops.linear_fused(big[:, :100], w[:, :100].contiguous(), None)       # K not a multiple of 64
+    with pytest.raises(ops.GaError):
+        ops.linear_fused(big[:, :128].float(), w.float(), None)             # fp32 is not served
