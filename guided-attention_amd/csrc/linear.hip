@@ -100,6 +100,28 @@ __device__ __forceinline__ void lin_tile(const LinArgs& a, int& mt, int& nt, int
   }
 }
 
+// Inline asm with GPU register constraints only exists in the device pass: the host pass parses kernel bodies too, and a
+// constraint it does not know silently voids the kernel's definition there (the launch stub then stays undefined).
+__device__ __forceinline__ void lds_read128(u32x4& dst, unsigned byte_address) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(byte_address) : "memory");
+#else
+  dst = u32x4{byte_address, 0u, 0u, 0u};
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
 
 // GEGLU: BN columns of the tile = BN/2 h features followed by the BN/2 gate features of the same output columns
@@ -149,9 +171,9 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 64 * 1024 ? 2
     for (int q = 0; q < IPS; ++q) {
       T* dst = lds + slot * kStage + (wave_u + 4 * q) * 8 * kBK;
       if (8 * (wave_u + 4 * q) < BM)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, GA_LDS_PTR(dst), 16, voff[q], koff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, GA_LDS_PTR(dst), 16, (int)voff[q], (int)koff, 0, 0);
       else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, GA_LDS_PTR(dst), 16, voff[q], koff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, GA_LDS_PTR(dst), 16, (int)voff[q], (int)koff, 0, 0);
     }
   };
 
@@ -207,9 +229,9 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 64 * 1024 ? 2
   for (int it = 0; it < nsteps; ++it) {
     // my loads of step `it` have landed when at most the younger steps' instructions are outstanding
     const int younger = min(nsteps - 1 - it, PRE - 1);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPS) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (younger >= 2) wait_vmcnt<2 * IPS>();
+    else if (younger == 1) wait_vmcnt<IPS>();
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's part of step `it` is in LDS; everyone is done reading step it - 1
     if (it + PRE < nsteps) issue(it + PRE, (it + PRE) % NSTAGE);   // refills the slot step it - 1 occupied
     const unsigned slot_off = (unsigned)((it % NSTAGE) * kStage * (int)sizeof(T));
@@ -219,19 +241,19 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 64 * 1024 ? 2
     auto request = [&](int kk, int set) {
 #pragma unroll
       for (int i = 0; i < IM; ++i)
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set][i]) : "v"(a_adr[i] + slot_off + 16u * ((2u * kk) ^ a_sw[i])) : "memory");
+        lds_read128(fa[set][i], a_adr[i] + slot_off + 16u * ((2u * kk) ^ a_sw[i]));
 #pragma unroll
       for (int j = 0; j < JN; ++j)
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][j]) : "v"(b_adr[j] + slot_off + 16u * ((2u * kk) ^ b_sw[j])) : "memory");
+        lds_read128(fb[set][j], b_adr[j] + slot_off + 16u * ((2u * kk) ^ b_sw[j]));
     };
     request(0, 0);
 #pragma unroll
     for (int kk = 0; kk < kBK / 16; ++kk) {
       if (kk + 1 < kBK / 16) {
         request(kk + 1, (kk + 1) & 1);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(IM + JN) : "memory");
+        wait_lgkmcnt<IM + JN>();
       } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_lgkmcnt<0>();
       }
       __builtin_amdgcn_sched_barrier(0);   // the MFMAs below must not be hoisted above the wait (register-only: "memory" does not order them)
 #pragma unroll
@@ -242,7 +264,7 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 64 * 1024 ? 2
     }
   }
   static_assert(NSTAGE >= 2 && NSTAGE <= 4, "the counted waits above cover up to three k-steps in flight");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wait_lgkmcnt<0>();
   __builtin_amdgcn_s_barrier();   // every wave's fragment reads are done: the ring memory is free for the epilogue
 
   // ---- split-K: publish, take a ticket; only the last slice of a tile goes on
