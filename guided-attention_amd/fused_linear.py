@@ -1,0 +1,105 @@
+"""Linear layers of the transformer blocks on `ga_linear_fused` (csrc/linear.hip), with their neighbours folded in and
+the autograd glue the guidance backward needs (reference: the diffusers 0.12.1 CrossAttention / BasicTransformerBlock /
+Transformer2DModel forwards called from utils/ptp_utils.py:70-91 and pipeline_guided_attention.py:647-738).
+
+    linear(x, W, b, residual, want_partials)         y = x W^T + b (+ residual); optionally the per-(row, column-tile) partial
+                                                     sums of the STORED result — what a following LayerNorm fold consumes
+    ln_linear(x, partials, norm, W, b, geglu)        y = LayerNorm(x) W^T + b, optionally through GEGLU: the GEMM runs on the
+                                                     raw rows, the normalisation is applied in its epilogue (csrc/linear.hip)
+
+Weights are frozen on this path (only the latents are differentiated, pipeline_guided_attention.py:466): the backward
+produces dX only — dX = dY W by the library GEMM, then the existing LayerNorm / GEGLU backward kernels.
+The gamma-scaled weights, their column sums and the beta / bias shifts are built once per (weight, norm) pair and
+re-built when a version counter moves."""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import GaError
+
+
+def supported(x, in_features, out_features):
+    return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and in_features % 64 == 0 and out_features % 16 == 0
+            and x.stride(-1) == 1)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b (+ residual) [, row partial sums of y].  Differentiable w.r.t. x and the residual."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, want_partials):
+        if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
+            raise GaError("Linear weight gradients are not part of the guided-attention path (frozen UNet)")
+        out = ops.linear_fused(x, weight, bias, residual=residual, want_row_partials=want_partials)
+        ctx.weight, ctx.has_res = weight, residual is not None
+        partials = out["row_partials"]
+        if partials is None:
+            partials = x.new_empty(0)
+        ctx.mark_non_differentiable(partials)
+        return out["y"], partials
+
+    @staticmethod
+    def backward(ctx, gy, _gp):
+        gx = torch.matmul(gy, ctx.weight) if ctx.needs_input_grad[0] else None
+        return gx, None, None, (gy if ctx.has_res else None), None
+
+
+def linear(x, weight, bias=None, residual=None, want_partials=False):
+    """-> (y, partials or None)"""
+    y, partials = _Linear.apply(x, weight, bias, residual, want_partials)
+    return y, (partials if want_partials else None)
+
+
+def _folded(weight, bias, norm):
+    """(gamma o W rounded to the activation type, its f32 column sums, beta . W^T + bias in f32) of a Linear behind a
+    LayerNorm — cached on the norm module per (weight storage, versions)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), None if bias is None else (bias.data_ptr(), bias._version),
+           norm.weight._version, norm.bias._version, weight.dtype)
+    cache = norm.__dict__.setdefault("_ga_folded", {})
+    hit = cache.get(key)
+    if hit is None:
+        with torch.no_grad():
+            wg = (weight.float() * norm.weight.float()[None, :]).to(weight.dtype).contiguous()
+            colsum = wg.float().sum(1).contiguous()
+            shift = weight.float() @ norm.bias.float()
+            if bias is not None:
+                shift = shift + bias.float()
+            hit = (wg, colsum, shift.contiguous())
+        if len(cache) > 8:
+            cache.clear()
+        cache[key] = hit
+    return hit
+
+
+class _LNLinear(torch.autograd.Function):
+    """y = [GEGLU](LayerNorm(x) W^T + b) with the statistics taken from `partials`.  Differentiable w.r.t. x."""
+
+    @staticmethod
+    def forward(ctx, x, partials, norm, weight, bias, geglu):
+        need = ctx.needs_input_grad[0]
+        wg, colsum, shift = _folded(weight, bias, norm)
+        out = ops.linear_fused(x, wg, None, geglu=geglu, want_preact=geglu and need,
+                               ln=(partials, colsum, shift, norm.eps), want_ln_stats=need)
+        if need:
+            ctx.save_for_backward(x, out["ln_stats"], out["preact"] if geglu else None)
+            ctx.norm, ctx.weight, ctx.geglu = norm, weight, geglu
+        return out["y"]
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, preact = ctx.saved_tensors
+        if ctx.geglu:
+            gy = ops.geglu_backward(preact, gy)
+        g_ln = torch.matmul(gy, ctx.weight)                      # gradient at the LayerNorm's output (gamma applied inside)
+        gx = ops._ln_bwd(x.contiguous(), stats, ctx.norm.weight, g_ln, None)
+        return gx, None, None, None, None, None
+
+
+def ln_linear(x, partials, norm, weight, bias=None, geglu=False):
+    return _LNLinear.apply(x, partials, norm, weight, bias, geglu)
+
+
+def conv1x1_weight(conv):
+    """(Cout, Cin) view of a 1x1 Conv2d weight (any memory format): free."""
+    w = conv.weight
+    return w.reshape(w.shape[0], w.shape[1])

@@ -729,6 +729,18 @@ def geglu(x):
     return Geglu.apply(x)
 
 
+def geglu_backward(x, dy):
+    """d(h * gelu(gate)) w.r.t. the projection x = [h | gate] (..., 2F) given dy (..., F)."""
+    require_cuda(x, dy)
+    x, dy = x.contiguous(), dy.contiguous()
+    F2 = x.shape[-1]
+    dx = torch.empty_like(x)
+    _count(("geglu_bwd", x.numel() // F2, 0, 0, 0, F2 // 2, False, str(x.dtype)))
+    check(load().ga_geglu_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.numel() // F2, F2 // 2, dtype_code(x), stream_ptr()),
+          "ga_geglu_bwd")
+    return dx
+
+
 class BiasResidualAdd(torch.autograd.Function):
     """out = y + bias[c] + residual on channels-last activations (ResnetBlock2D: conv2's bias and the skip
     connection in one pass).  bias receives no gradient (frozen UNet)."""

@@ -131,7 +131,12 @@ class GuidedAttention:
             self.unet.set_norm_impl(ops.group_norm_act)
             import os
             conv = ops.conv3x3 if os.environ.get("GA_LIBRARY_CONV", "0") != "1" else None   # GA_LIBRARY_CONV=1: MIOpen
-            self.unet.set_fused_impl(ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm), conv)
+            # GA_LIBRARY_LINEAR=1: the transformer blocks' Linear layers stay on hipBLASLt with separate LayerNorm / GEGLU /
+            # add launches (A/B runs); default: ga_linear_fused with those folded in (16-bit dtypes; fp32 keeps the library)
+            from . import fused_linear
+            linear = fused_linear if os.environ.get("GA_LIBRARY_LINEAR", "0") != "1" else None
+            ops.prepare_device(self.unet.device)   # split-K slabs / tickets exist before any hipGraph capture
+            self.unet.set_fused_impl(ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm), conv, linear)
             # MIOpen: time the candidate conv kernels once per shape — for the 16-bit production dtypes only.  In
             # fp32 (parity runs) the library's default choice is kept: the exhaustive search executes every
             # candidate solver, and the fp32 96x96 backward-data search was seen to abort the process once.

@@ -110,11 +110,20 @@ class Attention(nn.Module):
         bh, n, d = t.shape
         return t.reshape(bh // self.heads, self.heads, n, d).permute(0, 2, 1, 3).reshape(bh // self.heads, n, d * self.heads)
 
-    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None):
+    def _processor(self):
         proc = self.processor
         if proc is None:
             from .utils.ptp_utils import default_processor
             proc = self.processor = default_processor()
+        return proc
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, folded=None):
+        """folded (this build's transformer blocks, processors that declare `supports_folded_layer_norm`): see
+        utils/ptp_utils.AttendExciteCrossAttnProcessor.__call__."""
+        proc = self._processor()
+        if folded is not None:
+            return proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask,
+                        folded=folded)
         return proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask)
 
 
@@ -202,6 +211,26 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     ln_impl = None  # (layer_norm, add_layer_norm) from ops: residual add + next LayerNorm in one launch
+    lin_impl = None  # fused_linear module: LayerNorm folded into the projections, residual adds into their epilogues
+
+    def folds(self, x):
+        """Whether this block takes the folded form for x: the module is installed, the dtype / widths are served and both
+        attention processors understand the `folded` keyword (a foreign processor keeps the reference's protocol)."""
+        lin = self.lin_impl
+        return (lin is not None and lin.supported(x, x.shape[-1], x.shape[-1]) and
+                all(getattr(a._processor(), "supports_folded_layer_norm", False) for a in (self.attn1, self.attn2)))
+
+    def forward_folded(self, x, xp, context, want_partials):
+        """x: raw residual stream (B, N, C); xp: its row partial sums (from the producing GEMM).  Every LayerNorm is applied
+        inside the projection that consumes it, every residual add inside the projection that produces the new stream:
+        8 launches (6 GEMMs + 2 attention kernels) where the unfused block takes 14.  -> (x, partial sums or None)."""
+        lin = self.lin_impl
+        x, xp = self.attn1(x, folded={"partials": xp, "norm": self.norm1, "residual": x, "want_partials": True})
+        x, xp = self.attn2(x, encoder_hidden_states=context,
+                           folded={"partials": xp, "norm": self.norm2, "residual": x, "want_partials": True})
+        proj, out = self.ff.net[0].proj, self.ff.net[2]
+        h = lin.ln_linear(x, xp, self.norm3, proj.weight, proj.bias, geglu=True)
+        return lin.linear(h, out.weight, out.bias, residual=x, want_partials=want_partials)
 
     def forward(self, x, context):
         if self.ln_impl is not None and x.shape[-1] % 8 == 0:
@@ -231,10 +260,25 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)
                                                  for _ in range(depth)])
 
+    def _proj_weights(self, proj):
+        if self.use_linear_projection:
+            return proj.weight, proj.bias
+        return proj.weight.reshape(proj.out_channels, proj.in_channels), proj.bias
+
     def forward(self, x, context):
         b, c, h, w = x.shape
         res = x
         x = nchw_to_tokens(self.norm(x))
+        blocks = self.transformer_blocks
+        lin = blocks[0].lin_impl
+        if lin is not None and x.is_contiguous() and lin.supported(x, c, blocks[0].norm1.normalized_shape[0]) and \
+                res.is_contiguous(memory_format=torch.channels_last) and all(blk.folds(x) for blk in blocks):
+            # proj_in leaves the row sums the first LayerNorm needs; proj_out lands on the block's input (its residual)
+            x, xp = lin.linear(x, *self._proj_weights(self.proj_in), want_partials=True)
+            for i, blk in enumerate(blocks):
+                x, xp = blk.forward_folded(x, xp, context, want_partials=i + 1 < len(blocks))
+            x, _ = lin.linear(x, *self._proj_weights(self.proj_out), residual=nchw_to_tokens(res))
+            return tokens_to_nchw(x, h, w)
         x = self.proj_in(x) if self.use_linear_projection else pointwise_conv_tokens(x, self.proj_in)
         for blk in self.transformer_blocks:
             x = blk(x, context)
@@ -254,6 +298,7 @@ class ResnetBlock2D(nn.Module):
 
     add_impl = None   # fused conv2-bias + residual add (ops.bias_residual_add)
     conv_impl = None  # implicit-GEMM 3x3 convolution with bias / residual epilogue (ops.conv3x3)
+    lin_impl = None   # fused_linear module: the 1x1 shortcut as ga_linear_fused
 
     def forward(self, x, temb_act):
         """temb_act = SiLU(time embedding), computed once per UNet forward; or the dict the UNet prepared with this
@@ -268,7 +313,13 @@ class ResnetBlock2D(nn.Module):
         h = self.norm2(h, chan_bias=tproj)  # the time term is added inside the norm's loads
         if self.conv_shortcut is not None:
             _, _, hh, ww = x.shape
-            x = tokens_to_nchw(pointwise_conv_tokens(nchw_to_tokens(x), self.conv_shortcut), hh, ww)
+            xt = nchw_to_tokens(x)
+            sc = self.conv_shortcut
+            if self.lin_impl is not None and xt.is_contiguous() and self.lin_impl.supported(xt, sc.in_channels, sc.out_channels):
+                xt, _ = self.lin_impl.linear(xt, sc.weight.reshape(sc.out_channels, sc.in_channels), sc.bias)
+            else:
+                xt = pointwise_conv_tokens(xt, sc)
+            x = tokens_to_nchw(xt, hh, ww)
         if self.conv_impl is not None and self.conv_impl.supported(h, self.conv2.weight, 1):
             return self.conv_impl(h, self.conv2.weight, self.conv2.bias, x, 1)   # bias + skip connection in the epilogue
         if self.add_impl is not None and self.conv2.out_channels % 8 == 0:
@@ -572,9 +623,10 @@ class UNet2DConditionModel(nn.Module):
             if isinstance(m, GroupNormAct):
                 m.impl = impl
 
-    def set_fused_impl(self, geglu=None, bias_residual_add=None, layer_norms=None, conv=None):
+    def set_fused_impl(self, geglu=None, bias_residual_add=None, layer_norms=None, conv=None, linear=None):
         """Install (or with None remove) the fused element-wise epilogues: GEGLU, conv-bias + residual, and
-        (layer_norm, add_layer_norm) for the transformer blocks; `conv` = the implicit-GEMM 3x3 convolution."""
+        (layer_norm, add_layer_norm) for the transformer blocks; `conv` = the implicit-GEMM 3x3 convolution; `linear` = the
+        fused_linear module (LayerNorm / GEGLU / residual folded into the transformer blocks' GEMMs, 1x1 shortcuts)."""
         for m in self.modules():
             if isinstance(m, (Downsample2D, Upsample2D)):
                 m.conv_impl = conv
@@ -583,8 +635,10 @@ class UNet2DConditionModel(nn.Module):
             elif isinstance(m, ResnetBlock2D):
                 m.add_impl = bias_residual_add
                 m.conv_impl = conv
+                m.lin_impl = linear
             elif isinstance(m, BasicTransformerBlock):
                 m.ln_impl = layer_norms
+                m.lin_impl = linear
 
     @property
     def dtype(self):

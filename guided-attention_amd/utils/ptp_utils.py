@@ -149,9 +149,9 @@ def pin_context_projections(unet, storages, delta):
     return n
 
 
-def fused_qkv_projection(attn, hidden_states):
-    """[to_q | to_k | to_v](hidden_states) as ONE GEMM against the row-concatenated weights (built once per module,
-    rebuilt if a weight changes).  Parameter names / state_dict are untouched."""
+def fused_qkv_weight(attn):
+    """[to_q | to_k | to_v] weights row-concatenated (built once per module, rebuilt if a weight changes).  Parameter
+    names / state_dict are untouched."""
     ws = (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight)
     key = tuple((w.data_ptr(), w._version) for w in ws)
     cache = attn.__dict__.get("_qkv_cache")
@@ -159,7 +159,12 @@ def fused_qkv_projection(attn, hidden_states):
         with torch.no_grad():
             cache = (key, torch.cat(ws, dim=0))
         attn.__dict__["_qkv_cache"] = cache
-    return F.linear(hidden_states, cache[1])
+    return cache[1]
+
+
+def fused_qkv_projection(attn, hidden_states):
+    """[to_q | to_k | to_v](hidden_states) as ONE GEMM."""
+    return F.linear(hidden_states, fused_qkv_weight(attn))
 
 
 def refresh_context_projections(unet):
@@ -217,24 +222,48 @@ class AttendExciteCrossAttnProcessor:
         self.attnstore = attnstore
         self.place_in_unet = place_in_unet
 
-    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None):
+    supports_folded_layer_norm = True   # accepts `folded=` (see __call__); a foreign processor gets the plain protocol
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, folded=None):
+        """The reference's protocol, plus `folded` (this build's transformer blocks only): dict(partials, norm, residual,
+        want_partials).  Then `hidden_states` is the RAW residual stream: the block's LayerNorm is applied inside the
+        q / qkv projection (fused_linear.ln_linear), the output projection adds its bias and the residual in its epilogue
+        and the call returns (new residual stream, its row partial sums or None) — no LayerNorm launch, no add launch."""
         if attention_mask is not None:
             raise GaError("attention masks are not part of the guided-attention path")
+        from .. import fused_linear as fl
         is_cross = encoder_hidden_states is not None
         store = self.attnstore
+
+        def finish(out):
+            if folded is not None:
+                return fl.linear(out, attn.to_out[0].weight, attn.to_out[0].bias, residual=folded["residual"],
+                                 want_partials=folded["want_partials"])
+            return attn.to_out[1](attn.to_out[0](out))
+
         if not is_cross:
             n_pix = hidden_states.shape[1]
             fused_ok = (n_pix > MAX_CAPTURE_KEYS or torch.is_grad_enabled()) and hidden_states.is_cuda and \
                 ops.self_attention_supported(hidden_states, attn.heads, attn.to_q.out_features)
             if fused_ok and not (store is not None and store.wants_probs(False, n_pix)):
                 # self-attention without capture: one fused QKV GEMM, flash kernels on its column slices
-                out = ops.SelfAttentionFusedQKV.apply(fused_qkv_projection(attn, hidden_states), attn.heads, attn.scale)
+                if folded is not None:
+                    qkv = fl.ln_linear(hidden_states, folded["partials"], folded["norm"], fused_qkv_weight(attn))
+                else:
+                    qkv = fused_qkv_projection(attn, hidden_states)
+                out = ops.SelfAttentionFusedQKV.apply(qkv, attn.heads, attn.scale)
                 if store is not None:
                     store(ProbsNotCaptured((hidden_states.shape[0] * attn.heads, n_pix, n_pix), out.dtype, out.device),
                           False, self.place_in_unet)
-                return attn.to_out[1](attn.to_out[0](out))
+                return finish(out)
+            if folded is not None:   # the materialising self-attention paths read the normalised rows themselves
+                norm = folded["norm"]
+                hidden_states = ops.layer_norm(hidden_states, norm.weight, norm.bias, norm.eps)
         context = encoder_hidden_states if is_cross else hidden_states
-        query = attn.to_q(hidden_states)
+        if folded is not None and is_cross:
+            query = fl.ln_linear(hidden_states, folded["partials"], folded["norm"], attn.to_q.weight)
+        else:
+            query = attn.to_q(hidden_states)
         if is_cross and not context.requires_grad:
             key, value = cached_context_projections(attn, context)
         else:
@@ -264,8 +293,7 @@ class AttendExciteCrossAttnProcessor:
             if probs is None:
                 probs = ProbsNotCaptured((query.shape[0] * attn.heads, n_pix, n_keys), query.dtype, query.device)
             store(probs, is_cross, self.place_in_unet)
-        out = attn.to_out[0](out)
-        return attn.to_out[1](out)
+        return finish(out)
 
 
 def default_processor():

@@ -465,7 +465,7 @@ def test_fused_aggregate_loss_is_the_two_launches(ops, res, layout, dt):
     g2 = torch.autograd.grad(l2 * 1.5, leaves2)
     assert torch.equal(l1, l2)
     for a, b, m in zip(g1, g2, maps):
-        assert a.shape == m.shape and a.stride(0) == 0        # one map broadcast over the head-maps, never materialised
+        assert a.shape == m.shape and (a.stride(0) == 0 or a.shape[0] == 1)   # one map broadcast over the head-maps, never materialised
         close(a[0].float(), b[0].float().cpu().numpy(), TOL[dt], "dLoss/dP")
 
 

@@ -73,9 +73,9 @@ def main():
                     if sp > 1 and steps // sp < 2:
                         continue
                     tiles = -(-M // bm) * -(-N // bn)
-                    if tiles * sp > 2048 or (tiles * sp < 96 and sp < 16 and steps // (sp + 1) >= 2):
+                    if (tiles * sp > 2048 and sp > 1) or (tiles * sp < 96 and sp < 16 and steps // (sp + 1) >= 2):
                         continue
-                    if sp * tiles * bm * bn > ops.LIN_SLAB_FLOATS:
+                    if sp > 1 and sp * tiles * bm * bn > ops.LIN_SLAB_FLOATS:
                         continue
                     plan = (bm, bn, sp)
                     res[plan] = replay_us(lambda: ops.linear_fused(x, nxt(), bias, plan=plan), iters=20, reps=2)
