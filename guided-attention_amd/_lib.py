@@ -74,11 +74,12 @@ PROTOTYPES = {
     "ga_conv3x3_pack_weights": [_vp, _vp, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp],
     "ga_conv3x3_plan": [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i),
                         ctypes.POINTER(ctypes.c_longlong)],
-    "ga_conv3x3_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "ga_gemm_nt": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
+    "ga_splitk_workspace_floats": [_i64, _i, _i, _i, _i],
+    "ga_conv3x3_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ga_gemm_nt": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
     "ga_linear_workspace": [_i64, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(_i)],
     "ga_linear_fused": [_vp, _i64, _vp, _vp, _i64, ctypes.POINTER(ga_linear_epilogue_t), _vp, _vp, _i64, _i, _i, _i, _i, _i,
-                        _i, _vp],
+                        _i, _i, _vp],
     "ga_add_layer_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp],
     "ga_add_layer_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
 }
@@ -97,7 +98,8 @@ def load():
         for name, argtypes in PROTOTYPES.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_char_p if name == "ga_strerror" else ctypes.c_int
+            fn.restype = (ctypes.c_char_p if name == "ga_strerror" else
+                          ctypes.c_longlong if name == "ga_splitk_workspace_floats" else ctypes.c_int)
         _lib = lib
     return _lib
 

@@ -76,6 +76,7 @@ struct ConvArgs {
   int steps;        // k-steps in all: 9 * Cin / 32
   int steps_per;    // k-steps per split
   int tm, tn;       // m tiles, n tiles of the launch (grid = tm * tn * splits workgroups, one dimension)
+  int splits;       // k slices per tile (split-K)
   int n_fastest;    // workgroup order inside an XCD's run: n tiles fastest (1) or m tiles fastest (0)
   int pad;          // 1: 3x3 taps around the pixel; 0: a single tap (plain GEMM  Y[m][n] = sum_c X[m][c] W[n][c])
   int lane_rot;     // patch kernel on 16-wide maps: lanes 16..31 of a 32-pixel block take their row's pixels rotated by 2
@@ -115,33 +116,75 @@ __device__ __forceinline__ void tile_of_workgroup(const ConvArgs& a, int& m0, in
 
 // Epilogue of both kernels.  acc[j][i][r]: output channel n = n0 + wn*WN + j*32 + (r & 3) + 8 * (r >> 2) + 4 * fh,
 //                                          pixel          m = m0 + wm*WM + i*32 + fr
-// OUT_F32: raw f32 partial tile to part[split][m][n]; else through LDS (every wave has passed the loop's last barrier:
-// the staging buffers are free) and out as whole 16-byte row pieces with bias and residual added.
-template <typename T, int BM, int BN, bool OUT_F32>
+// SPLITK: the depth is divided over `splits` workgroups per tile and the reduction happens INSIDE the launch (round 2
+// ran a second kernel over f32 slabs: 42 k launches and 4 % of the kernel time per bench run).  Every slice stores its f32
+// accumulators write-through (sc1) in its own thread order — 16 bytes per lane, perfectly coalesced, and the reducer's
+// thread t reads exactly what thread t of the other slices wrote — drains, and one lane takes a ticket; the slice whose
+// ticket is last re-reads all of them with sc1 loads IN SLICE ORDER (bitwise reproducible whoever arrives last), goes on
+// to the common epilogue below and returns the ticket word to zero for the next launch.
+// Then through LDS (every wave has passed the loop's last barrier: the staging buffers are free) and out as whole
+// 16-byte row pieces with bias and residual added.
+template <typename T, int BM, int BN, bool SPLITK>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T* lds, T* __restrict__ Y,
-                                              float* __restrict__ part, const T* __restrict__ bias,
-                                              const T* __restrict__ residual, const ConvArgs& a, int m0, int n0,
-                                              int split) {
+                                              float* __restrict__ part, unsigned* __restrict__ tickets,
+                                              const T* __restrict__ bias, const T* __restrict__ residual,
+                                              const ConvArgs& a, int m0, int n0, int split) {
   constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, JN = WN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, fr = lane_pixel(lane & 31, a.lane_rot), fh = lane >> 5;
-  if constexpr (OUT_F32) {
-    float* dst = part + (size_t)split * a.M * a.Cout;
+  if constexpr (SPLITK) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int QUADS = JN * IM * 4;
+    const int tile = (n0 / BN) * a.tm + m0 / BM;
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(part, 0, 0x7ffffff0, 0x00020000);
+    const unsigned per_slice = (unsigned)(a.tm * a.tn) * (BM * BN * 4u);
+    const unsigned tbase = (unsigned)tile * (BM * BN * 4u) + (unsigned)tid * 16u;
 #pragma unroll
-    for (int i = 0; i < IM; ++i) {
-      const int m = m0 + wm * WM + i * 32 + fr;
-      if (m >= a.M) continue;
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const u32x4 v = {__float_as_uint(acc[j][i][4 * qd]), __float_as_uint(acc[j][i][4 * qd + 1]),
+                           __float_as_uint(acc[j][i][4 * qd + 2]), __float_as_uint(acc[j][i][4 * qd + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, srsrc, tbase + ((j * IM + i) * 4 + qd) * (kThreads * 16u),
+                                                 split * per_slice, 16);   // aux 16 = sc1: write-through
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(lds);
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == (unsigned)a.splits - 1;
+      if (last) __hip_atomic_store(tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag[0] = last;
+    }
+    __syncthreads();
+    const int last = flag[0];
+    __syncthreads();
+    if (!last) return;
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    for (int sp = 0; sp < a.splits; ++sp) {
+      u32x4 v[QUADS];
+#pragma unroll
+      for (int q = 0; q < QUADS; ++q)
+        v[q] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, tbase + q * (kThreads * 16u), sp * per_slice, 16);   // sc1
 #pragma unroll
       for (int j = 0; j < JN; ++j)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int n = n0 + wn * WN + j * 32 + 8 * qd + 4 * fh;
-          if (n < a.Cout)
-            *reinterpret_cast<f32x4*>(dst + (size_t)m * a.Cout + n) =
-                f32x4{acc[j][i][4 * qd], acc[j][i][4 * qd + 1], acc[j][i][4 * qd + 2], acc[j][i][4 * qd + 3]};
-        }
+        for (int i = 0; i < IM; ++i)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][i][4 * qd + r] += __uint_as_float(v[(j * IM + i) * 4 + qd][r]);
     }
-  } else {
+  }
+  {
     constexpr int LDC = BN + 8;
     T* Cs = lds;
 #pragma unroll
@@ -178,10 +221,11 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T
   }
 }
 
-// OUT_F32 = true: this workgroup's split writes its raw f32 partial tile to part[split][m][n] (no bias / residual).
+// OUT_F32 = true: split-K launch (the reduction happens in conv_epilogue)
 template <typename T, int BM, int BN, bool OUT_F32>
 __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restrict__ X, const T* __restrict__ Wp,
                                                            T* __restrict__ Y, float* __restrict__ part,
+                                                           unsigned* __restrict__ tickets,
                                                            const T* __restrict__ bias, const T* __restrict__ residual,
                                                            ConvArgs a) {
   constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
@@ -344,7 +388,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
     __syncthreads();             // the epilogue reuses the buffers: every wave's fragment reads must be done
   }
 
-  conv_epilogue<T, BM, BN, OUT_F32>(acc, lds, Y, part, bias, residual, a, m0, n0, split);
+  conv_epilogue<T, BM, BN, OUT_F32>(acc, lds, Y, part, tickets, bias, residual, a, m0, n0, split);
 }
 
 // ---- variant with the input patch kept in LDS (stride 1, tiles made of whole image rows) ---------------------------
@@ -385,6 +429,7 @@ __host__ __device__ inline bool patch_geometry(int BM, int H, int W, PatchGeom& 
 template <typename T, int BM, int BN, bool OUT_F32, bool WIDE = false>
 __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_patch_kernel(const T* __restrict__ X, const T* __restrict__ Wp,
                                                                     T* __restrict__ Y, float* __restrict__ part,
+                                                                    unsigned* __restrict__ tickets,
                                                                     const T* __restrict__ bias,
                                                                     const T* __restrict__ residual, ConvArgs a) {
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -546,42 +591,7 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
       __syncthreads();
     }
   }
-  conv_epilogue<T, BM, BN, OUT_F32>(acc, lds, Y, part, bias, residual, a, m0, n0, split);
-}
-
-// split-K epilogue: Y[m][n] = sum_s part[s][m][n] (+ bias[n] + R[m][n]), fixed summation order s = 0, 1, ...; 4 channels
-// per thread.  S > 0: the split count is a compile-time constant and every slab's load is issued before the first add
-// (the runtime-count loop waited out one memory round trip per slab); S = 0: generic loop.
-template <typename T, int S>
-__global__ __launch_bounds__(kThreads) void conv_splitk_sum_kernel(const float* __restrict__ part, int splits, T* __restrict__ Y,
-                                                                   const T* __restrict__ bias,
-                                                                   const T* __restrict__ residual, long long MN, int Cout) {
-  const long long v = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4;
-  if (v >= MN) return;
-  f32x4 acc;
-  if constexpr (S > 0) {
-    f32x4 p[S];
-#pragma unroll
-    for (int sp = 0; sp < S; ++sp) p[sp] = *reinterpret_cast<const f32x4*>(part + (size_t)sp * MN + v);
-    acc = p[0];
-#pragma unroll
-    for (int sp = 1; sp < S; ++sp) acc += p[sp];
-  } else {
-    acc = *reinterpret_cast<const f32x4*>(part + v);
-    for (int sp = 1; sp < splits; ++sp) acc += *reinterpret_cast<const f32x4*>(part + (size_t)sp * MN + v);
-  }
-  const int n = (int)(v % Cout);
-  typename Traits<T>::frag bv, rv, out;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    bv[k] = Traits<T>::from_f32(0.f);
-    rv[k] = Traits<T>::from_f32(0.f);
-  }
-  if (bias != nullptr) bv = load_frag<T>(bias + n);
-  if (residual != nullptr) rv = load_frag<T>(residual + v);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) out[k] = Traits<T>::from_f32(acc[k] + Traits<T>::to_f32(bv[k]) + Traits<T>::to_f32(rv[k]));
-  store_frag<T>(Y + v, out);
+  conv_epilogue<T, BM, BN, OUT_F32>(acc, lds, Y, part, tickets, bias, residual, a, m0, n0, split);
 }
 
 // pre-pack: W [Cout][Cin][3][3] in whatever strides the framework holds (element strides given) ->
@@ -631,7 +641,7 @@ Plan choose_plan(int M, int N, int steps) {
       const double wgs = (double)tiles * s;
       const double fill = wgs <= 512.0 ? 480.0 / (wgs < 480.0 ? wgs : 480.0) : ((double)((long long)((wgs + 511) / 512)) * 512.0) / wgs;
       const double compute_us = flops * waste * fill / (rate[ci] * 1e6);
-      const double split_us = s > 1 ? (double)s * (double)M * (double)N * 8.0 / 4.0e6 + 6.0 : 0.0;
+      const double split_us = s > 1 ? (double)s * (double)M * (double)N * 8.0 / 4.0e6 + 3.0 : 0.0;   // slabs out and back + the hand-off
       const double us = compute_us + split_us;
       if (us < best_us) {
         best_us = us;
@@ -651,32 +661,15 @@ inline bool force_v1() {
   return v;
 }
 
-template <typename T>
-int launch_split_sum(float* ws, int splits, T* Y, const T* bias, const T* residual, const ConvArgs& a, hipStream_t s) {
-  const long long MN = (long long)a.M * a.Cout;
-  const dim3 sgrid((unsigned)((MN / 4 + kThreads - 1) / kThreads));
-#define GA_SUM_CASE(S)                                                                                                 \
-  case S:                                                                                                              \
-  hipLaunchKernelGGL((conv_splitk_sum_kernel<T, S>), sgrid, dim3(kThreads), 0, s, (const float*)ws, splits, Y, bias,   \
-                     residual, MN, a.Cout);                                                                          \
-  break;
-  switch (splits) {
-    GA_SUM_CASE(2) GA_SUM_CASE(3) GA_SUM_CASE(4) GA_SUM_CASE(6) GA_SUM_CASE(8) GA_SUM_CASE(12) GA_SUM_CASE(16)
-    default:
-      hipLaunchKernelGGL((conv_splitk_sum_kernel<T, 0>), sgrid, dim3(kThreads), 0, s, (const float*)ws, splits, Y, bias,
-                         residual, MN, a.Cout);
-  }
-#undef GA_SUM_CASE
-  return check_launch();
-}
-
 template <typename T, int BM, int BN>
-int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T* residual, const ConvArgs& a_in, int splits,
-                hipStream_t s) {
+int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, const T* bias, const T* residual,
+                const ConvArgs& a_in, int splits, hipStream_t s) {
   ConvArgs a = a_in;
   a.lane_rot = 0;
+  a.splits = splits;
   a.tm = (a.M + BM - 1) / BM;
   a.tn = (a.Cout + BN - 1) / BN;
+  if (splits > 1 && (long long)splits * a.tm * a.tn * BM * BN * 4 >= (1LL << 31)) return GA_ERR_SHAPE;   // 32-bit slab offsets
   {  // bytes that reach the fabric if each XCD fetches what its run of workgroups shares once
     const double xb = (double)a.B * a.H * a.W * a.Cin, wb = (a.pad ? 9.0 : 1.0) * a.Cin * a.Cout;
     const double m_first = wb + xb * (a.tn * splits < 8 ? a.tn * splits : 8), n_first = xb + wb * (a.tm < 8 ? a.tm : 8);
@@ -691,14 +684,13 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T
   if (patch_wide) {   // a 128-pixel tile of one 128-wide row: the 13-piece instantiation
     a.steps_per = (a.Cin / kKC + splits - 1) / splits;
     if constexpr (BM == 128) {
-      if (splits == 1) {
+      if (splits == 1)
         hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, false, true>), grid, dim3(kThreads), 0, s, X, Wp, Y,
-                           (float*)nullptr, bias, residual, a);
-        return check_launch();
-      }
-      hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, true, true>), grid, dim3(kThreads), 0, s, X, Wp, (T*)nullptr, ws,
-                         (const T*)nullptr, (const T*)nullptr, a);
-      return launch_split_sum<T>(ws, splits, Y, bias, residual, a, s);
+                           (float*)nullptr, (unsigned*)nullptr, bias, residual, a);
+      else
+        hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, true, true>), grid, dim3(kThreads), 0, s, X, Wp, Y, ws, tickets,
+                           bias, residual, a);
+      return check_launch();
     }
   }
   if (patch) {
@@ -708,40 +700,49 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, const T* bias, const T
   if (splits == 1) {
     if (patch)
       hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, false>), grid, dim3(kThreads), 0, s, X, Wp, Y, (float*)nullptr,
-                         bias, residual, a);
+                         (unsigned*)nullptr, bias, residual, a);
     else
-      hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, false>), grid, dim3(kThreads), 0, s, X, Wp, Y, (float*)nullptr, bias,
-                         residual, a);
+      hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, false>), grid, dim3(kThreads), 0, s, X, Wp, Y, (float*)nullptr,
+                         (unsigned*)nullptr, bias, residual, a);
   } else {
     if (patch)
-      hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, true>), grid, dim3(kThreads), 0, s, X, Wp, (T*)nullptr, ws,
-                         (const T*)nullptr, (const T*)nullptr, a);
+      hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, true>), grid, dim3(kThreads), 0, s, X, Wp, Y, ws, tickets, bias,
+                         residual, a);
     else
-      hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, true>), grid, dim3(kThreads), 0, s, X, Wp, (T*)nullptr, ws,
-                         (const T*)nullptr, (const T*)nullptr, a);
-    return launch_split_sum<T>(ws, splits, Y, bias, residual, a, s);
+      hipLaunchKernelGGL((conv3x3_kernel<T, BM, BN, true>), grid, dim3(kThreads), 0, s, X, Wp, Y, ws, tickets, bias,
+                         residual, a);
   }
   return check_launch();
 }
 
 template <typename T>
-int conv_t(const void* X, const void* Wp, void* Y, float* ws, const void* bias, const void* residual, ConvArgs a, int bm,
-           int bn, int splits, hipStream_t s) {
+int conv_t(const void* X, const void* Wp, void* Y, float* ws, unsigned* tickets, const void* bias, const void* residual,
+           ConvArgs a, int bm, int bn, int splits, hipStream_t s) {
   a.steps = (a.pad ? 9 : 1) * a.Cin / kKC;
   a.steps_per = (a.steps + splits - 1) / splits;
   const T* x = (const T*)X;
   const T* w = (const T*)Wp;
   const T* b = (const T*)bias;
   const T* r = (const T*)residual;
-  if (bm == 128 && bn == 128) return launch_tile<T, 128, 128>(x, w, (T*)Y, ws, b, r, a, splits, s);
-  if (bm == 128 && bn == 64) return launch_tile<T, 128, 64>(x, w, (T*)Y, ws, b, r, a, splits, s);
-  if (bm == 64 && bn == 64) return launch_tile<T, 64, 64>(x, w, (T*)Y, ws, b, r, a, splits, s);
+  if (bm == 128 && bn == 128) return launch_tile<T, 128, 128>(x, w, (T*)Y, ws, tickets, b, r, a, splits, s);
+  if (bm == 128 && bn == 64) return launch_tile<T, 128, 64>(x, w, (T*)Y, ws, tickets, b, r, a, splits, s);
+  if (bm == 64 && bn == 64) return launch_tile<T, 64, 64>(x, w, (T*)Y, ws, tickets, b, r, a, splits, s);
   return GA_ERR_SHAPE;
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// f32 slab floats of a split-K launch: every slice of every (padded) tile keeps BM x BN accumulators
+long long conv_workspace_floats(long long M, int N, int bm, int bn, int splits) {
+  if (splits <= 1) return 0;
+  return (long long)splits * ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * bm * bn;
+}
+
 }  // namespace
+
+extern "C" long long ga_splitk_workspace_floats(int64_t M, int N, int bm, int bn, int splits) {
+  return conv_workspace_floats(M, N, bm, bn, splits);
+}
 
 extern "C" int ga_conv3x3_plan(int B, int H, int W, int Cin, int Cout, int stride, int* bm, int* bn, int* splits,
                                long long* workspace_floats) {
@@ -753,7 +754,7 @@ extern "C" int ga_conv3x3_plan(int B, int H, int W, int Cin, int Cout, int strid
   *bm = p.bm;
   *bn = p.bn;
   *splits = p.splits;
-  *workspace_floats = p.splits > 1 ? (long long)p.splits * B * Ho * Wo * Cout : 0;
+  *workspace_floats = conv_workspace_floats(B * Ho * Wo, Cout, p.bm, p.bn, p.splits);
   return GA_OK;
 }
 
@@ -780,13 +781,13 @@ extern "C" int ga_conv3x3_pack_weights(const void* W, void* Wp, int Cout, int Ci
   return check_launch();
 }
 
-extern "C" int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* workspace, const void* bias,
+extern "C" int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets, const void* bias,
                                const void* residual, int B, int H, int W, int Cin, int Cout, int stride, int bm, int bn,
                                int splits, int dtype, ga_stream_t stream) {
   if (!X || !Wp || !Y) return GA_ERR_NULL;
   if (B < 1 || H < 1 || W < 1 || Cin < kKC || Cin % kKC != 0 || Cout < 8 || Cout % 8 != 0 || (stride != 1 && stride != 2))
     return GA_ERR_SHAPE;
-  if (splits < 1 || splits > 64 || (splits > 1 && !workspace)) return GA_ERR_SHAPE;
+  if (splits < 1 || splits > 64 || (splits > 1 && (!workspace || !tickets))) return GA_ERR_SHAPE;
   if (!al16(X) || !al16(Wp) || !al16(Y) || (bias && !al16(bias)) || (residual && !al16(residual))) return GA_ERR_ALIGN;
   ConvArgs a;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stride = stride;
@@ -800,19 +801,20 @@ extern "C" int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* wo
   a.w_bytes = (unsigned)wb;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case GA_F16: return conv_t<_Float16>(X, Wp, Y, workspace, bias, residual, a, bm, bn, splits, s);
-    case GA_BF16: return conv_t<bf16_t>(X, Wp, Y, workspace, bias, residual, a, bm, bn, splits, s);
+    case GA_F16: return conv_t<_Float16>(X, Wp, Y, workspace, tickets, bias, residual, a, bm, bn, splits, s);
+    case GA_BF16: return conv_t<bf16_t>(X, Wp, Y, workspace, tickets, bias, residual, a, bm, bn, splits, s);
     default: return GA_ERR_DTYPE;
   }
 }
 
 /* Y[M][N] = X[M][K] * W[N][K]^T (+ bias[N]) (+ residual[M][N]): the Linear layers and 1x1 convolutions of the UNet (weights
  * in the framework's own [out][in] layout, no packing) on the same pipelined MFMA kernel, as a one-tap convolution. */
-extern "C" int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspace, const void* bias, const void* residual,
-                          int64_t M, int K, int N, int bm, int bn, int splits, int dtype, ga_stream_t stream) {
+extern "C" int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspace, unsigned* tickets, const void* bias,
+                          const void* residual, int64_t M, int K, int N, int bm, int bn, int splits, int dtype,
+                          ga_stream_t stream) {
   if (!X || !W || !Y) return GA_ERR_NULL;
   if (M < 1 || K < kKC || K % kKC != 0 || N < 8 || N % 8 != 0) return GA_ERR_SHAPE;
-  if (splits < 1 || splits > 64 || (splits > 1 && !workspace)) return GA_ERR_SHAPE;
+  if (splits < 1 || splits > 64 || (splits > 1 && (!workspace || !tickets))) return GA_ERR_SHAPE;
   if (!al16(X) || !al16(W) || !al16(Y) || (bias && !al16(bias)) || (residual && !al16(residual))) return GA_ERR_ALIGN;
   const long long xb = (long long)M * K * 2, wb = (long long)N * K * 2;
   if (xb >= (1LL << 31) || wb >= (1LL << 31) || (long long)M * N >= (1LL << 31)) return GA_ERR_SHAPE;
@@ -824,8 +826,8 @@ extern "C" int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspac
   a.w_bytes = (unsigned)wb;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case GA_F16: return conv_t<_Float16>(X, W, Y, workspace, bias, residual, a, bm, bn, splits, s);
-    case GA_BF16: return conv_t<bf16_t>(X, W, Y, workspace, bias, residual, a, bm, bn, splits, s);
+    case GA_F16: return conv_t<_Float16>(X, W, Y, workspace, tickets, bias, residual, a, bm, bn, splits, s);
+    case GA_BF16: return conv_t<bf16_t>(X, W, Y, workspace, tickets, bias, residual, a, bm, bn, splits, s);
     default: return GA_ERR_DTYPE;
   }
 }

@@ -443,14 +443,25 @@ int launch_lin(const T* X, const T* W, T* Y, LinArgs a, const LinPtrs& p, hipStr
   return check_launch();
 }
 
+// ring depth per tile: `stages` = 0 takes the first listed.  The shallower rings fit two workgroups per CU (LDS <= 80 KB):
+// with one wave per SIMD nothing covers a wave's LDS-DMA issue (8 pieces per k-step cost about as much issue time as its
+// 16 MFMAs), with two the partner's MFMAs do — what the large batch-3 shapes want; the deep rings hide more memory
+// latency per workgroup — what the short small-M shapes want.
 template <typename T>
-int lin_t(const void* X, const void* W, void* Y, const LinArgs& a, const LinPtrs& p, int bm, int bn, hipStream_t s) {
+int lin_t(const void* X, const void* W, void* Y, const LinArgs& a, const LinPtrs& p, int bm, int bn, int stages, hipStream_t s) {
   const T* x = (const T*)X;
   const T* w = (const T*)W;
-  if (bm == 128 && bn == 128) return launch_lin<T, 128, 128, 3>(x, w, (T*)Y, a, p, s);
-  if (bm == 128 && bn == 64) return launch_lin<T, 128, 64, 4>(x, w, (T*)Y, a, p, s);
-  if (bm == 64 && bn == 128) return launch_lin<T, 64, 128, 4>(x, w, (T*)Y, a, p, s);
-  if (bm == 64 && bn == 64) return launch_lin<T, 64, 64, 4>(x, w, (T*)Y, a, p, s);
+  if (bm == 128 && bn == 128) {
+    if (stages == 2) return launch_lin<T, 128, 128, 2>(x, w, (T*)Y, a, p, s);
+    if (stages == 0 || stages == 3) return launch_lin<T, 128, 128, 3>(x, w, (T*)Y, a, p, s);
+  } else if ((bm == 128 && bn == 64) || (bm == 64 && bn == 128)) {
+    const bool tall = bm == 128;
+    if (stages == 3) return tall ? launch_lin<T, 128, 64, 3>(x, w, (T*)Y, a, p, s) : launch_lin<T, 64, 128, 3>(x, w, (T*)Y, a, p, s);
+    if (stages == 0 || stages == 4)
+      return tall ? launch_lin<T, 128, 64, 4>(x, w, (T*)Y, a, p, s) : launch_lin<T, 64, 128, 4>(x, w, (T*)Y, a, p, s);
+  } else if (bm == 64 && bn == 64) {
+    if (stages == 0 || stages == 4) return launch_lin<T, 64, 64, 4>(x, w, (T*)Y, a, p, s);
+  }
   return GA_ERR_SHAPE;
 }
 
@@ -470,7 +481,7 @@ extern "C" int ga_linear_workspace(int64_t M, int N, int bm, int bn, int splits,
 
 extern "C" int ga_linear_fused(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, const ga_linear_epilogue_t* ep,
                                float* slabs, unsigned* tickets, int64_t M, int K, int N, int bm, int bn, int splits,
-                               int dtype, ga_stream_t stream) {
+                               int stages, int dtype, ga_stream_t stream) {
   if (!X || !W || !Y || !ep) return GA_ERR_NULL;
   if (M < 1 || K < kBK || K % kBK != 0 || N < 8 || N % 8 != 0 || ldx < K || ldx % 8 != 0 || ldy % 8 != 0) return GA_ERR_SHAPE;
   if (splits < 1 || splits > 64 || K / kBK < splits || (splits > 1 && (!slabs || !tickets))) return GA_ERR_SHAPE;
@@ -506,8 +517,8 @@ extern "C" int ga_linear_fused(const void* X, int64_t ldx, const void* W, void* 
   p.slabs = slabs; p.tickets = tickets;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case GA_F16: return lin_t<_Float16>(X, W, Y, a, p, bm, bn, s);
-    case GA_BF16: return lin_t<bf16_t>(X, W, Y, a, p, bm, bn, s);
+    case GA_F16: return lin_t<_Float16>(X, W, Y, a, p, bm, bn, stages, s);
+    case GA_BF16: return lin_t<bf16_t>(X, W, Y, a, p, bm, bn, stages, s);
     default: return GA_ERR_DTYPE;
   }
 }

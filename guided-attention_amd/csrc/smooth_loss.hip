@@ -97,20 +97,45 @@ __device__ __forceinline__ void row_stats(const LossArgs& a, const float* row, f
   s_out = s;
 }
 
-__device__ __forceinline__ void pixel_softmax_stats(const LossArgs& a, float* mx, float* sm, float* stage) {
+// gcol[t][p] = A[p][column of guided token t]: taken while the row is at hand, so that the token loops never go back to
+// global memory (one dependent ~1-2 us load per token and phase otherwise: the launch is one workgroup, nothing hides it)
+__device__ __forceinline__ void gather_guided(const LossArgs& a, const float* row, int p, int npix, float* gcol) {
+  for (int t = 0; t < a.T; ++t) gcol[t * npix + p] = row[a.first + a.tok[t].token - 1];
+}
+
+__device__ __forceinline__ void pixel_softmax_stats(const LossArgs& a, float* mx, float* sm, float* stage, float* gcol) {
   const int npix = a.res * a.res;
   if (a.stage_rows == 0) {
-    for (int p = threadIdx.x; p < npix; p += kThreads) row_stats(a, a.A + (size_t)p * a.Kt, mx[p], sm[p]);
+    for (int p = threadIdx.x; p < npix; p += kThreads) {
+      row_stats(a, a.A + (size_t)p * a.Kt, mx[p], sm[p]);
+      gather_guided(a, a.A + (size_t)p * a.Kt, p, npix, gcol);
+    }
     return;
   }
   for (int p0 = 0; p0 < npix; p0 += a.stage_rows) {
     const int rows = min(a.stage_rows, npix - p0), n = rows * a.Kt;
     const float* src = a.A + (size_t)p0 * a.Kt;      // 16-byte aligned: stage_rows is a multiple of 4, A is
-    for (int e = 4 * threadIdx.x; e + 3 < n; e += 4 * kThreads)
-      *reinterpret_cast<f32x4*>(stage + e) = *reinterpret_cast<const f32x4*>(src + e);
+    // eight 16-byte loads per thread in flight before the first LDS store (a load -> store loop pays one memory round
+    // trip per iteration: 19 of them for the 16 x 16 x 77 map, most of what this launch took)
+    for (int e0 = 0; e0 + 3 < n; e0 += 4 * kThreads * 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 4 * (threadIdx.x + u * kThreads);
+        v[u] = *reinterpret_cast<const f32x4*>(src + min(e, (n & ~3) - 4));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 4 * (threadIdx.x + u * kThreads);
+        if (e + 3 < n) *reinterpret_cast<f32x4*>(stage + e) = v[u];
+      }
+    }
     for (int e = (n & ~3) + threadIdx.x; e < n; e += kThreads) stage[e] = src[e];
     __syncthreads();
-    for (int r = threadIdx.x; r < rows; r += kThreads) row_stats(a, stage + r * a.Kt, mx[p0 + r], sm[p0 + r]);
+    for (int r = threadIdx.x; r < rows; r += kThreads) {
+      row_stats(a, stage + r * a.Kt, mx[p0 + r], sm[p0 + r]);
+      gather_guided(a, stage + r * a.Kt, p0 + r, npix, gcol);
+    }
     __syncthreads();
   }
 }
@@ -179,13 +204,14 @@ __device__ __forceinline__ float strict_weights(const LossArgs& a, const ga_toke
 
 // Forward of one token into LDS: M (raw map), Pn (smoothed, normalised).  Returns the reductions.
 __device__ __forceinline__ TokenStats token_forward(const LossArgs& a, const ga_token_t& tk, const float* mx,
-                                                    const float* sm, float* M, float* Pn, float* W, float* scratch) {
+                                                    const float* sm, const float* gcol_t, float* M, float* Pn, float* W,
+                                                    float* scratch) {
   const int res = a.res, npix = res * res;
   const bool strict = a.strict && tk.kind == GA_TOK_BOX;
   float at_most = 0.f;
   if (strict) at_most = strict_weights(a, tk, W, scratch);
-  const int colA = a.first + tk.token - 1;  // pipeline:228 "index - 1" into the [first:last) slice
-  for (int p = threadIdx.x; p < npix; p += kThreads) M[p] = expf(a.A[(size_t)p * a.Kt + colA] * 100.0f - mx[p]) / sm[p];
+  // gcol_t[p] = A[p][first + token - 1]  (pipeline:228 "index - 1" into the [first:last) slice)
+  for (int p = threadIdx.x; p < npix; p += kThreads) M[p] = expf(gcol_t[p] * 100.0f - mx[p]) / sm[p];
   __syncthreads();
   const int pad = a.ksize >> 1;
   float v2[2] = {0.f, 0.f};
@@ -284,13 +310,14 @@ __device__ __forceinline__ void loss_forward(const LossArgs& a, float* lds, floa
   float* Pn = M + npix;
   float* scratch = Pn + npix;  // 16 floats
   float* W = scratch + 16;     // [npix], strict mode only
-  float* stage = align16(W + (a.strict ? npix : 0));   // [stage_rows][Kt]
-  pixel_softmax_stats(a, mx, sm, stage);
+  float* gcol = W + (a.strict ? npix : 0);             // [T][npix]
+  float* stage = align16(gcol + (size_t)a.T * npix);   // [stage_rows][Kt]
+  pixel_softmax_stats(a, mx, sm, stage, gcol);
   __syncthreads();
   float total = 0.f;
   for (int t = 0; t < a.T; ++t) {
     const ga_token_t& tk = a.tok[t];
-    const TokenStats st = token_forward(a, tk, mx, sm, M, Pn, W, scratch);
+    const TokenStats st = token_forward(a, tk, mx, sm, gcol + (size_t)t * npix, M, Pn, W, scratch);
     const TokenLoss tl = token_loss(a, tk, st);
     total += tk.weight * tl.item;
     if (threadIdx.x == 0) {
@@ -365,16 +392,17 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
   int* colmap = reinterpret_cast<int*>(scratch + 16);  // [Kt]: guided-token slot of column c, or -1
   float* dS = reinterpret_cast<float*>(colmap + ((a.Kt + 3) & ~3));  // [T][npix]
   float* W = dS + (size_t)a.T * npix;                                // [npix], strict mode only
-  float* stage = align16(W + (a.strict ? npix : 0));                 // [stage_rows][Kt]
+  float* gcol = W + (a.strict ? npix : 0);                           // [T][npix]
+  float* stage = align16(gcol + (size_t)a.T * npix);                 // [stage_rows][Kt]
 
-  pixel_softmax_stats(a, mx, sm, stage);
+  pixel_softmax_stats(a, mx, sm, stage, gcol);
   for (int c = threadIdx.x; c < a.Kt; c += kThreads) colmap[c] = -1;
   __syncthreads();
   const int pad = a.ksize >> 1;
   const float rm1 = (float)res - 1.0f;
   for (int t = 0; t < a.T; ++t) {
     const ga_token_t& tk = a.tok[t];
-    const TokenStats st = token_forward(a, tk, mx, sm, M, Pn, W, scratch);
+    const TokenStats st = token_forward(a, tk, mx, sm, gcol + (size_t)t * npix, M, Pn, W, scratch);
     const TokenLoss tl = token_loss(a, tk, st);
     if (threadIdx.x == 0) colmap[a.first + tk.token - 1] = t;
     const float sgc = tl.dc > 0.f ? 1.f : (tl.dc < 0.f ? -1.f : 0.f);
@@ -421,10 +449,7 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
   // softmax backward: dA[p][c] = 100 * S[p][c] * (dS[p][c] - sum_k dS[p][k] S[p][k]) on the text slice
   for (int p = threadIdx.x; p < npix; p += kThreads) {
     float d = 0.f;
-    for (int t = 0; t < a.T; ++t) {
-      const int colA = a.first + a.tok[t].token - 1;
-      d += dS[(size_t)t * npix + p] * (expf(a.A[(size_t)p * a.Kt + colA] * 100.0f - mx[p]) / sm[p]);
-    }
+    for (int t = 0; t < a.T; ++t) d += dS[(size_t)t * npix + p] * (expf(gcol[(size_t)t * npix + p] * 100.0f - mx[p]) / sm[p]);
     dot[p] = d;
   }
   __syncthreads();
@@ -432,22 +457,30 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
   // less than any hand-off); the element-wise tail over the (pixel, token) grid is split between them
   const float dl = dloss ? dloss[0] : 1.0f;
   const int total = npix * a.Kt;
-  for (int e = blockIdx.x * kThreads + threadIdx.x; e < total; e += gridDim.x * kThreads) {
-    const int p = e / a.Kt, c = e - p * a.Kt;
-    float g = 0.f;
-    if (c >= a.first && c < a.last) {
-      const float S = expf(a.A[e] * 100.0f - mx[p]) / sm[p];
-      const int t = colmap[c];
-      g = dl * 100.0f * S * ((t >= 0 ? dS[(size_t)t * npix + p] : 0.f) - dot[p]);
+  for (int e0 = blockIdx.x * kThreads + threadIdx.x; e0 < total; e0 += 4 * gridDim.x * kThreads) {
+    float av[4];   // four loads in flight per thread, then the math
+#pragma unroll
+    for (int u = 0; u < 4; ++u) av[u] = a.A[min(e0 + u * (int)(gridDim.x * kThreads), total - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * (int)(gridDim.x * kThreads);
+      if (e >= total) break;
+      const int p = e / a.Kt, c = e - p * a.Kt;
+      float g = 0.f;
+      if (c >= a.first && c < a.last) {
+        const float S = expf(av[u] * 100.0f - mx[p]) / sm[p];
+        const int t = colmap[c];
+        g = dl * 100.0f * S * ((t >= 0 ? dS[(size_t)t * npix + p] : 0.f) - dot[p]);
+      }
+      dA[e] = g;
+      if (dPb) dPb[e] = Traits<T>::from_f32(g * bcast_scale);
     }
-    dA[e] = g;
-    if (dPb) dPb[e] = Traits<T>::from_f32(g * bcast_scale);
   }
 }
 
-size_t fwd_lds(int npix, int strict) { return sizeof(float) * ((4 + (strict ? 1 : 0)) * (size_t)npix + 16); }
+size_t fwd_lds(int npix, int T, int strict) { return sizeof(float) * ((4 + (strict ? 1 : 0) + (size_t)T) * (size_t)npix + 16); }
 size_t bwd_lds(int npix, int Kt, int T, int strict) {
-  return sizeof(float) * ((6 + (strict ? 1 : 0)) * (size_t)npix + 16 + ((Kt + 3) & ~3) + (size_t)T * npix);
+  return sizeof(float) * ((6 + (strict ? 1 : 0)) * (size_t)npix + 16 + ((Kt + 3) & ~3) + 2 * (size_t)T * npix);
 }
 constexpr size_t kLdsBudget = 150 * 1024;
 // rows of A staged per pass: as many as fit beside the kernel's tables, at most one per thread, a multiple of 4
@@ -524,7 +557,7 @@ extern "C" int ga_smooth_loss_fwd(const float* A, int res, int Kt, int first, in
   LossArgs a;
   int rc = fill_args(a, A, res, Kt, first, last, tokens, T, hp);
   if (rc != GA_OK) return rc;
-  size_t lds = fwd_lds(res * res, a.strict);
+  size_t lds = fwd_lds(res * res, T, a.strict);
   if (lds > kLdsBudget) return GA_ERR_SHAPE;
   a.stage_rows = choose_stage_rows(lds, res * res, Kt, A);
   lds += sizeof(float) * (size_t)a.stage_rows * Kt + 16;
@@ -590,7 +623,7 @@ extern "C" int ga_aggregate_loss_fwd(const void* const* maps, const int* heads, 
   LossArgs a;
   rc = fill_args(a, A, res, Kt, first, last, tokens, T, hp);
   if (rc != GA_OK) return rc;
-  size_t lds = fwd_lds(res * res, a.strict);
+  size_t lds = fwd_lds(res * res, T, a.strict);
   if (lds > kLdsBudget) return GA_ERR_SHAPE;
   a.stage_rows = choose_stage_rows(lds, res * res, Kt, A);
   lds += sizeof(float) * (size_t)a.stage_rows * Kt + 16;

@@ -67,6 +67,7 @@ def replay_launch_us(key, iters=100):
     dtype = {"torch.float16": torch.float16, "torch.bfloat16": torch.bfloat16, "torch.float32": torch.float32}[dt]
     dev = torch.device("cuda", torch.cuda.current_device())
     lib = load()
+    fn = None
     if kind == "conv3x3":          # key = (kind, B, Cin, H*W, stride, Cout, epilogue?, dtype); the UNet's maps are square
         cin, hw, stride, cout = H, N, Kt, D
         side_len = int(round(hw ** 0.5))
@@ -81,15 +82,15 @@ def replay_launch_us(key, iters=100):
         bias = torch.randn(cout, device=dev, dtype=dtype) if flag else None
         res = (torch.randn(B, cout, ho, wo, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
                if flag else None)
-        bm, bn, splits, ws_floats = conv3x3_plan(B, side_len, hw // side_len, cin, cout, stride)
+        bm, bn, splits, _ = conv3x3_plan(B, side_len, hw // side_len, cin, cout, stride)
         y = torch.empty(B, cout, ho, wo, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
-        ws = torch.empty(max(1, ws_floats), device=dev, dtype=torch.float32)
+        ws, tickets = splitk_workspace(dev, B * ho * wo, cout, bm, bn, splits)
         code = dtype_code(x)
 
         def fn():
             wp = wps[turn[0] % n_copies]
             turn[0] += 1
-            check(lib.ga_conv3x3_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(bias), _ptr(res), B, side_len,
+            check(lib.ga_conv3x3_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(tickets), _ptr(bias), _ptr(res), B, side_len,
                                       hw // side_len, cin, cout, stride, bm, bn, splits, code, stream_ptr()), "replay conv")
     elif kind in ("geglu_fwd", "geglu_bwd", "bias_residual_add", "add_layer_norm_fwd", "add_layer_norm_bwd"):
         rows, C = B, D
@@ -127,6 +128,23 @@ def replay_launch_us(key, iters=100):
                 def fn():
                     check(lib.ga_add_layer_norm_bwd(_ptr(xn), _ptr(stats), _ptr(w), _ptr(dy), _ptr(g_arg), _ptr(dx), rows,
                                                     C, code, stream_ptr()), "replay ln bwd")
+    elif kind == "linear":        # key = (kind, M, K, 0, geglu | 2 ln | 4 residual, N, bias?, dtype)
+        M, K, flags, N = B, H, Kt, D
+        x = torch.randn(M, K, device=dev, dtype=dtype)
+        n_copies = max(2, min(64, -(-320 * 2 ** 20 // (N * K * 2))))       # cold weights, as for the convolutions
+        ws = [torch.randn(N, K, device=dev, dtype=dtype) * K ** -0.5 for _ in range(n_copies)]
+        bias = torch.randn(N, device=dev, dtype=dtype) if flag else None
+        geglu_, ln_, res_ = bool(flags & 1), bool(flags & 2), bool(flags & 4)
+        n_out = N // 2 if geglu_ else N
+        res = torch.randn(M, n_out, device=dev, dtype=dtype) if res_ else None
+        ln = None
+        if ln_:
+            ln = (torch.rand(M, 5, 2, device=dev) * K, torch.randn(N, device=dev), torch.randn(N, device=dev), 1e-5)
+        turn = [0]
+
+        def fn():
+            turn[0] += 1
+            linear_fused(x, ws[turn[0] % n_copies], bias, residual=res, geglu=geglu_, ln=ln)
     elif kind in ("aggregate_maps", "aggregate_loss_fwd", "smooth_loss_fwd", "smooth_loss_bwd"):
         # B = guided tokens (aggregate_maps: tensors), H = head-maps in all, N = pixels, Kt = tokens of the context
         npix, res = N, int(round(N ** 0.5))
@@ -217,6 +235,8 @@ def replay_launch_us(key, iters=100):
                 check(lib.ga_self_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(d_o), _ptr(lse), _ptr(delta),
                                            _ptr(dq), _ptr(dk), _ptr(dv), B, H, N, D, 0, scale, code, stream_ptr()),
                       "replay sa bwd")
+    if fn is None:
+        raise GaError(f"no replay recipe for kernel kind {kind!r}")
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -876,7 +896,7 @@ def conv3x3_plan(B, H, W, Cin, Cout, stride):
         hit = _measured_conv_plans().get((B * Ho * Wo, Cin, Cout, stride))
         if hit is not None:
             bm, bn, sp = hit
-            plan = _conv_plan_cache[key] = (bm, bn, sp, sp * B * Ho * Wo * Cout if sp > 1 else 0)
+            plan = _conv_plan_cache[key] = (bm, bn, sp, int(load().ga_splitk_workspace_floats(B * Ho * Wo, Cout, bm, bn, sp)))
             return plan
         bm, bn, sp, ws = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
         check(load().ga_conv3x3_plan(B, H, W, Cin, Cout, stride, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp),
@@ -923,14 +943,14 @@ def conv3x3_nhwc(x, wp, cout, stride=1, bias=None, residual=None, plan=None):
     x = _nhwc(x)
     B, Cin, H, W = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    bm, bn, splits, ws_floats = plan or conv3x3_plan(B, H, W, Cin, cout, stride)
+    bm, bn, splits = (plan or conv3x3_plan(B, H, W, Cin, cout, stride))[:3]
     y = torch.empty((B, cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    ws = torch.empty(ws_floats, dtype=torch.float32, device=x.device) if splits > 1 else None
+    ws, tickets = splitk_workspace(x.device, B * Ho * Wo, cout, bm, bn, splits)
     if residual is not None:
         residual = _nhwc(residual)
     _count(("conv3x3", B, Cin, H * W, stride, cout, bias is not None or residual is not None, str(x.dtype)))
-    check(load().ga_conv3x3_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(bias), _ptr(residual), B, H, W, Cin, cout,
-                                 stride, bm, bn, splits, dtype_code(x), stream_ptr()), "ga_conv3x3_nhwc")
+    check(load().ga_conv3x3_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(tickets), _ptr(bias), _ptr(residual), B, H, W,
+                                 Cin, cout, stride, bm, bn, splits, dtype_code(x), stream_ptr()), "ga_conv3x3_nhwc")
     return y
 
 
@@ -1083,6 +1103,17 @@ def linear_workspace(device):
     return ws
 
 
+def splitk_workspace(device, M, N, bm, bn, splits):
+    """(f32 slabs, tickets) of an in-launch split-K reduction from the persistent per-device scratch, or (None, None)."""
+    if splits <= 1:
+        return None, None
+    ws = linear_workspace(device)
+    need = int(load().ga_splitk_workspace_floats(M, N, bm, bn, splits))
+    if need > ws["slabs"].numel() or -(-M // bm) * -(-N // bn) > ws["tickets"].numel():
+        raise GaError(f"split-K workspace too small: M={M} N={N} plan {(bm, bn, splits)} needs {need} floats")
+    return ws["slabs"], ws["tickets"]
+
+
 def prepare_device(device):
     """Allocate the persistent per-device scratch of the kernels (split-K slabs, arrival tickets) — once, before any
     hipGraph capture, so that captured launches and eager launches share the same, never-moving buffers."""
@@ -1156,7 +1187,9 @@ def linear_fused(x, weight, bias=None, residual=None, geglu=False, want_preact=F
         ldx = K
     N = weight.shape[0]
     n_out = N // 2 if geglu else N
-    bm, bn, splits = plan or linear_plan(M, K, N, geglu)
+    plan = tuple(plan or linear_plan(M, K, N, geglu))
+    bm, bn, splits = plan[:3]
+    stages = plan[3] if len(plan) > 3 else 0
     y = out if out is not None else torch.empty(lead + (n_out,), dtype=x.dtype, device=x.device)
     ep = _lib.ga_linear_epilogue_t()
     ep.bias = bias.data_ptr() if bias is not None else None
@@ -1198,6 +1231,6 @@ def linear_fused(x, weight, bias=None, residual=None, geglu=False, want_preact=F
     _count(("linear", M, K, 0, int(bool(geglu)) + 2 * int(ln is not None) + 4 * int(residual is not None), N, bias is not None,
             str(x.dtype)))
     check(load().ga_linear_fused(_ptr(x), ldx, _ptr(weight), _ptr(y), y.stride(-2) if y.dim() > 1 else n_out,
-                                 ctypes.byref(ep), _ptr(slabs), _ptr(tickets), M, K, N, bm, bn, splits, dtype_code(x),
-                                 stream_ptr()), "ga_linear_fused")
+                                 ctypes.byref(ep), _ptr(slabs), _ptr(tickets), M, K, N, bm, bn, splits, stages,
+                                 dtype_code(x), stream_ptr()), "ga_linear_fused")
     return {"y": y, "preact": preact, "ln_stats": ln_stats, "row_partials": row_partials, "parts": parts}

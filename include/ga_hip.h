@@ -83,6 +83,10 @@ int ga_attn_capture_bwd(const void* Q, const void* K, const void* V, const void*
  *                             bias_grad[0] (f32 atomics; may be NULL) — the gradient the reference's autograd sends
  *                             on through `.max()`, which the host adds to dQ at the maximum's position.
  * Kt <= 80 (the reference applies the mask to the text context only).
+ * Ties: when several scores equal the maximum bit for bit, `packed` names the one with the HIGHEST flat index and the
+ * whole d loss / d coef gradient goes to that position; torch's full-reduction `.max()` backward (what the reference
+ * runs) spreads it evenly over the tied positions.  The two agree whenever the maximum is unique (every fixture and
+ * pipeline test); a tie needs two identical (query, key) pairs.  tests/test_kernels_gpu.py pins this rule.
  */
 int ga_attn_scores_max(const void* Q, const void* K, int B, int H, int N, int Kt, int D, float scale, int dtype,
                        unsigned long long* packed, ga_stream_t stream);
@@ -247,28 +251,33 @@ int ga_bias_residual_add(const void* y, const void* bias, const void* residual, 
  *                             N = Cin, C = Cout, taps mirrored — with it the same kernel computes the backward to the
  *                             input of a stride-1 convolution from the upstream gradient.  Once per weight version.
  *   ga_conv3x3_plan         : tile (bm x bn) and split-K factor for a shape, and the f32 workspace it needs
- *                             (splits * B * Ho * Wo * Cout floats, 0 when splits == 1).  Pure host function.
+ *                             (ga_splitk_workspace_floats(B * Ho * Wo, Cout, bm, bn, splits); 0 when splits == 1).
+ *                             Pure host function.
  *   ga_conv3x3_nhwc         : Y [B][Ho][Wo][Cout] = conv(X [B][H][W][Cin], Wp) (+ bias[Cout]) (+ residual like Y);
  *                             bias / residual may be NULL; Ho = (H - 1) / stride + 1.  splits > 1 runs the GEMM depth
- *                             in `splits` slices into `workspace` and a second small launch sums them in fixed order.
+ *                             in `splits` slices per tile: each slice stores its f32 accumulators to `workspace`, the slice
+ *                             that arrives last sums them in slice order (bitwise reproducible) and writes Y — ONE
+ *                             launch.  `tickets`: ceil(M / bm) * ceil(Cout / bn) 32-bit words, ZERO on entry; the kernel
+ *                             leaves them zero.  Launches sharing workspace / tickets must be stream-ordered.
  */
+long long ga_splitk_workspace_floats(int64_t M, int N, int bm, int bn, int splits);
 int ga_conv3x3_pack_weights(const void* W, void* Wp, int Cout, int Cin, int64_t stride_o, int64_t stride_i,
                             int64_t stride_y, int64_t stride_x, int transpose_flip, int dtype, ga_stream_t stream);
 int ga_conv3x3_plan(int B, int H, int W, int Cin, int Cout, int stride, int* bm, int* bn, int* splits,
                     long long* workspace_floats);
-int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* workspace, const void* bias, const void* residual,
-                    int B, int H, int W, int Cin, int Cout, int stride, int bm, int bn, int splits, int dtype,
-                    ga_stream_t stream);
+int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets, const void* bias,
+                    const void* residual, int B, int H, int W, int Cin, int Cout, int stride, int bm, int bn, int splits,
+                    int dtype, ga_stream_t stream);
 
 /* Linear layers / 1x1 convolutions of the UNet (diffusers 0.12.1 CrossAttention.to_q/to_k/to_v/to_out, FeedForward,
  * Transformer2DModel.proj_in/proj_out, ResnetBlock2D.conv_shortcut — called from pipeline_guided_attention.py:647-738
  * and utils/ptp_utils.py:70-91 through torch.nn.functional.linear / conv2d) on the convolution's pipelined MFMA kernel
  * as a one-tap convolution:  Y[M][N] = X[M][K] * W[N][K]^T (+ bias[N]) (+ residual[M][N]).
  * W is the framework's own [out_features][in_features] layout (no packing).  16-bit types; K % 64 == 0, N % 8 == 0;
- * bm x bn in {128x128, 128x64, 64x64}; splits > 1 needs workspace of splits * M * N floats.
+ * bm x bn in {128x128, 128x64, 64x64}; splits > 1: workspace (ga_splitk_workspace_floats) and tickets as for ga_conv3x3_nhwc.
  */
-int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspace, const void* bias, const void* residual, int64_t M,
-               int K, int N, int bm, int bn, int splits, int dtype, ga_stream_t stream);
+int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspace, unsigned* tickets, const void* bias,
+               const void* residual, int64_t M, int K, int N, int bm, int bn, int splits, int dtype, ga_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Linear layers of the transformer blocks with their element-wise neighbours folded in
@@ -293,7 +302,8 @@ int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspace, const vo
  * workgroups: each slice stores its f32 accumulators to `slabs`, the slice that arrives last sums them in slice order
  * (bitwise reproducible) and runs the epilogue — one launch.  ga_linear_workspace gives the sizes: `slabs` f32
  * [slab_floats], `tickets` [tiles] 32-bit words that are ZERO on entry (the kernel leaves them zero); launches that
- * share them must be stream-ordered.  K % 64 == 0, N % 8 == 0, 16-bit dtypes. */
+ * share them must be stream-ordered.  `stages` = k-steps of the LDS ring (0: the tile's default; 128x128: 2 or 3,
+ * 128x64 / 64x128: 3 or 4, 64x64: 4): shallow rings fit two workgroups per CU.  K % 64 == 0, N % 8 == 0, 16-bit dtypes. */
 typedef struct {
   const void* bias;
   const void* residual;
@@ -312,8 +322,8 @@ typedef struct {
 
 int ga_linear_workspace(int64_t M, int N, int bm, int bn, int splits, int geglu, long long* slab_floats, int* tiles);
 int ga_linear_fused(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, const ga_linear_epilogue_t* ep,
-                    float* slabs, unsigned* tickets, int64_t M, int K, int N, int bm, int bn, int splits, int dtype,
-                    ga_stream_t stream);
+                    float* slabs, unsigned* tickets, int64_t M, int K, int N, int bm, int bn, int splits, int stages,
+                    int dtype, ga_stream_t stream);
 
 /* Residual add + LayerNorm (diffusers 0.12.1 BasicTransformerBlock.forward: x = attn(norm(x)) + x; norm_next(x)):
  *   fwd: x_new = a + x (rounded to T), y = LayerNorm(x_new) * gamma + beta, stats [rows][2] f32 = (mean, rstd).

@@ -132,11 +132,11 @@ def test_conv_plan_is_a_host_function(lib):
     assert rc == 0 and ws == (sp * 1024 * 320 if sp > 1 else 0)
     assert plan(1, 16, 16, 100, 1280, 1)[0] == -2                # Cin not a multiple of 64
     assert plan(1, 16, 16, 1280, 1280, 3)[0] == -2               # stride 3
-    assert lib.ga_conv3x3_nhwc(None, None, None, None, None, None, 1, 16, 16, 64, 64, 1, 64, 64, 1, 0, None) == -1
-    assert lib.ga_gemm_nt(None, None, None, None, None, None, 16, 64, 64, 64, 64, 1, 0, None) == -1
+    assert lib.ga_conv3x3_nhwc(None, None, None, None, None, None, None, 1, 16, 16, 64, 64, 1, 64, 64, 1, 0, None) == -1
+    assert lib.ga_gemm_nt(None, None, None, None, None, None, None, 16, 64, 64, 64, 64, 1, 0, None) == -1
     p = ctypes.c_void_p(4096)
-    assert lib.ga_gemm_nt(p, p, p, None, None, None, 16, 72, 64, 64, 64, 1, 0, None) == -2   # K not a multiple of 64
-    assert lib.ga_conv3x3_nhwc(p, p, p, None, None, None, 1, 16, 16, 64, 64, 1, 96, 64, 1, 0, None) == -2   # no 96-pixel tile
+    assert lib.ga_gemm_nt(p, p, p, None, None, None, None, 16, 72, 64, 64, 64, 1, 0, None) == -2   # K not a multiple of 64
+    assert lib.ga_conv3x3_nhwc(p, p, p, None, None, None, None, 1, 16, 16, 64, 64, 1, 96, 64, 1, 0, None) == -2   # no 96-pixel tile
 
 
 def test_product_refuses_cpu_tensors():

@@ -353,6 +353,42 @@ def test_aggregate_backward_is_broadcast(ops):
         close(m.grad, np.broadcast_to((w / 40).half().double().cpu().numpy(), (8, 256, 77)), 1e-6, "dP")
 
 
+def test_paint_with_words_maximum_tie_rule(ops):
+    """include/ga_hip.h: with several bitwise-equal maxima ga_attn_scores_max reports the HIGHEST flat index and the whole
+    gradient through the maximum goes there (the reference's torch `.max()` backward would split it evenly): two identical
+    query rows against two identical key rows give four tied scores."""
+    B, H, N, Kt, D = 1, 2, 64, 77, 16
+    q = torch.from_numpy(hashrand.normalish((B, N, H * D), 91)).cuda() * 0.1
+    k = torch.from_numpy(hashrand.normalish((B, Kt, H * D), 92)).cuda() * 0.1
+    v = torch.from_numpy(hashrand.normalish((B, Kt, H * D), 93)).cuda()
+    big = torch.full((D,), 1.5, device="cuda")
+    for n in (5, 40):                       # head 1: rows 5 and 40 of q, keys 3 and 60 carry the same large vector
+        q[0, n, D:2 * D] = big
+    for kk in (3, 60):
+        k[0, kk, D:2 * D] = big
+    scale = D ** -0.5
+    value, arg = ops.attn_scores_max(q, k, H, scale)
+    scores = torch.einsum("nhd,khd->hnk", q[0].view(N, H, D), k[0].view(Kt, H, D)) * scale
+    assert float(value) == float(scores.max())
+    ties = (scores.reshape(-1) == scores.max()).nonzero().reshape(-1)
+    assert len(ties) == 4 and int(arg) == int(ties.max()) == (1 * N + 40) * Kt + 60
+    # autograd: only that position receives the gradient through the maximum
+    mask = torch.zeros(N, Kt, device="cuda")
+    mask[:, 7] = 1.0
+    qa = q.clone().requires_grad_(True)
+    out, _ = ops.AttnCapturePaintWithWords.apply(qa, k, v, H, scale, False, mask, 0.3)
+    out.sum().backward()
+    qb = q.clone().requires_grad_(True)      # the same with the coefficient held constant: no path through the maximum
+    coef = (value * 0.3).detach()
+    o2, _ = ops.attn_capture_fwd_biased(qb.detach(), k, v, H, scale, False, mask, coef)
+    dq_const, gsum = ops.attn_capture_bwd_biased(q, k, v, torch.ones_like(o2), None, H, scale, mask, coef)
+    extra = (qa.grad - dq_const).view(N, H, D)
+    touched = (extra.abs().sum(-1) > 0).nonzero().tolist()
+    assert touched == [[40, 1]], touched      # row 40, head 1: the highest flat index among the four tied maxima
+    ref = k[0, 60, D:2 * D] * (float(gsum) * 0.3 * scale)
+    close(extra[40, 1], ref.cpu().numpy(), 1e-4, "gradient through the maximum")
+
+
 # ------------------------------------------------------------------------------------- loss (G4)
 G4 = load_json("g4_loss.json")
 
@@ -777,6 +813,10 @@ def test_conv3x3_implicit_gemm(ops, shape, dt):
             close(y, yr.detach().numpy(), tol, f"y tile {bm}x{bn} splits {splits}")
             y0 = ops.conv3x3_nhwc(x, wp, Cout, stride, None, None, plan=(bm, bn, splits, ws))
             close(y0, y_plain.numpy(), tol, f"plain y tile {bm}x{bn} splits {splits}")
+            if splits > 1:   # the in-launch reduction sums the slices in slice order whoever arrives last
+                assert all(torch.equal(y, ops.conv3x3_nhwc(x, wp, Cout, stride, bias, res, plan=(bm, bn, splits, ws)))
+                           for _ in range(3)), f"split-K not reproducible: tile {bm}x{bn} splits {splits}"
+    assert int(ops.linear_workspace(x.device)["tickets"].abs().sum().item()) == 0   # every ticket word is back to zero
     # autograd wrapper with the planner's own choice; weights in channels-last strides too (what the UNet holds)
     xa, ra = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
     ya = ops.conv3x3(xa, w.contiguous(memory_format=torch.channels_last), bias, ra, stride)
@@ -809,11 +849,12 @@ def test_gemm_nt(ops, shape, dt):
             if sp > K // ops.CONV_KC:
                 continue
             y = torch.empty(M, N, device="cuda", dtype=DT[dt])
-            ws = torch.empty(sp * M * N, device="cuda", dtype=torch.float32) if sp > 1 else None
-            rc = load().ga_gemm_nt(P(x), P(w), P(y), P(ws), P(bias), P(res), M, K, N, bm, bn, sp, dtype_code(x), stream_ptr())
+            ws, tickets = ops.splitk_workspace(x.device, M, N, bm, bn, sp)
+            rc = load().ga_gemm_nt(P(x), P(w), P(y), P(ws), P(tickets), P(bias), P(res), M, K, N, bm, bn, sp, dtype_code(x),
+                                   stream_ptr())
             assert rc == 0
             close(y, ref.numpy(), TOL[dt] * 2, f"gemm tile {bm}x{bn} splits {sp}")
-    assert load().ga_gemm_nt(P(x), P(w), P(y), None, None, None, M, K + 8, N, 64, 64, 1, dtype_code(x), stream_ptr()) < 0
+    assert load().ga_gemm_nt(P(x), P(w), P(y), None, None, None, None, M, K + 8, N, 64, 64, 1, dtype_code(x), stream_ptr()) < 0
 
 
 # ------------------------------------------------------------------------------------- Linear layers with folded neighbours

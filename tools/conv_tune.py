@@ -53,7 +53,7 @@ def bind(path):
     lib = ctypes.CDLL(str(path))
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
     lib.ga_conv3x3_pack_weights.argtypes = [vp, vp, i32, i32, i64, i64, i64, i64, i32, i32, vp]
-    lib.ga_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 10 + [vp]
+    lib.ga_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, vp] + [i32] * 10 + [vp]
     return lib
 
 
@@ -70,10 +70,10 @@ def variant_times(lib, x, w, co, st, plans):
     y = torch.empty(B, co, ho, ho, device="cuda", dtype=x.dtype).contiguous(memory_format=torch.channels_last)
     out = {}
     for (bm, bn, sp) in plans:
-        ws = torch.empty(sp * B * ho * ho * co, device="cuda", dtype=torch.float32) if sp > 1 else None
+        ws, tk = ops.splitk_workspace(x.device, B * ho * ho, co, bm, bn, sp)
 
         def call():
-            rc = lib.ga_conv3x3_nhwc(P(x), P(wp), P(y), P(ws), None, None, B, h, h, ci, co, st, bm, bn, sp, 0, sp_())
+            rc = lib.ga_conv3x3_nhwc(P(x), P(wp), P(y), P(ws), P(tk), None, None, B, h, h, ci, co, st, bm, bn, sp, 0, sp_())
             assert rc == 0, rc
         out[(bm, bn, sp)] = replay_us(call, iters=10)
     return out
@@ -102,8 +102,9 @@ def main():
                     tiles = -(-B * ho * ho // bm) * -(-co // bn)
                     if tiles * sp > 4096 or (tiles * sp < 96 and sp < 16):
                         continue
-                    ws = sp * B * ho * ho * co if sp > 1 else 0
-                    plan = (bm, bn, sp, ws)
+                    if sp > 1 and sp * tiles * bm * bn > ops.LIN_SLAB_FLOATS:
+                        continue
+                    plan = (bm, bn, sp, 0)
                     res[(bm, bn, sp)] = replay_us(lambda: ops.conv3x3_nhwc(x, wp, co, st, None, None, plan=plan), iters=10)
             best = min(res, key=res.get)
             extra = ""

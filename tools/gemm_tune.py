@@ -48,16 +48,16 @@ def main():
                     tiles = -(-M // bm) * -(-N // bn)
                     if tiles * sp > 4096 or (tiles * sp < 64 and sp < 8):
                         continue
-                    ws = torch.empty(sp * M * N, device="cuda", dtype=torch.float32) if sp > 1 else None
+                    ws, tk = ops.splitk_workspace(x.device, M, N, bm, bn, sp)
 
                     def call():
-                        rc = lib.ga_gemm_nt(P(x), P(w), P(y), P(ws), P(bias), None, M, K, N, bm, bn, sp, dtype_code(x), stream_ptr())
+                        rc = lib.ga_gemm_nt(P(x), P(w), P(y), P(ws), P(tk), P(bias), None, M, K, N, bm, bn, sp, dtype_code(x), stream_ptr())
                         assert rc == 0, rc
                     res[(bm, bn, sp)] = replay_us(call, iters=10)
             best = min(res, key=res.get)
             bm, bn, sp = best
-            ws = torch.empty(sp * M * N, device="cuda", dtype=torch.float32) if sp > 1 else None
-            assert lib.ga_gemm_nt(P(x), P(w), P(y), P(ws), P(bias), None, M, K, N, bm, bn, sp, dtype_code(x), stream_ptr()) == 0
+            ws, tk = ops.splitk_workspace(x.device, M, N, bm, bn, sp)
+            assert lib.ga_gemm_nt(P(x), P(w), P(y), P(ws), P(tk), P(bias), None, M, K, N, bm, bn, sp, dtype_code(x), stream_ptr()) == 0
             err = float((y.float() - ref.float()).abs().max() / ref.float().abs().max())
             print(f"{M:>6} {K:>5} {N:>6} {t_lib:8.1f} {flop / t_lib / 1e6:6.0f} | {str(best):>14} {res[best]:8.1f} "
                   f"{flop / res[best] / 1e6:6.0f} {t_lib / res[best]:5.2f}  err {err:.1e}", flush=True)

@@ -1,10 +1,17 @@
 #!/usr/bin/env python3
-"""Per-shape time of the UNet's Linear layers / 1x1 convolutions at COLD weights: torch.nn.functional.linear (hipBLASLt)
-against ga_linear_fused for every (tile, split-K) plan.  In the pipeline a layer's weights are cold (1.7 GB of UNet weights
-cycle through the 256 MB Infinity Cache between two uses) while its input was just written: both contenders rotate over
-enough weight copies to exceed the cache.  hipGraph replay timing between two HIP events.
+"""Per-shape time of the UNet's Linear layers / 1x1 convolutions at COLD weights: the library form the round-2 build ran
+(torch.nn.functional.linear on hipBLASLt plus the separate LayerNorm / GEGLU / residual-add launches around it) against
+ga_linear_fused for every (tile, split-K, ring depth) plan.  In the pipeline a layer's weights are cold (1.7 GB of UNet
+weights cycle through the 256 MB Infinity Cache between two uses) while its input was just written: both contenders rotate
+over enough weight copies to exceed the cache.  hipGraph replay timing between two HIP events.
 
-  python tools/linear_tune.py [batches, default 1,3] [--write]     # --write: guided-attention_amd/linear_plans.json
+  python tools/linear_tune.py [batches, default 1,3] [--write] [--mode plain|fused|all]
+     plain : Y = X W^T + b                         vs F.linear                       (the 38 shapes per batch of round 2's table)
+     fused : the transformer block's real calls    vs the library + ga element-wise kernels:
+             ln    LayerNorm -> Linear                          (qkv, to_q)
+             res   Linear + bias + residual                     (to_out, FF out, proj_out)
+             geglu LayerNorm -> Linear -> GEGLU                 (FF in)
+  --write: guided-attention_amd/linear_plans.json  {"M,K,N,geglu": [bm, bn, splits, stages]}
 """
 import json
 import sys
@@ -16,6 +23,8 @@ import torch.nn.functional as F
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from guided_attention_amd import ops  # noqa: E402
 from gemm_tune import BASE  # noqa: E402
+
+TILES = ((128, 128, 3), (128, 128, 2), (128, 64, 4), (128, 64, 3), (64, 128, 4), (64, 128, 3), (64, 64, 4))
 
 
 def replay_us(fn, iters=20, reps=3):
@@ -44,52 +53,98 @@ def replay_us(fn, iters=20, reps=3):
     return best
 
 
+def candidates(M, K, n_out, geglu):
+    steps = K // 64
+    for bm, bn, st in TILES:
+        outc = bn // 2 if geglu else bn
+        tiles = -(-M // bm) * -(-n_out // outc)
+        for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+            if sp > 1 and steps // sp < 2:
+                continue
+            if (tiles * sp > 2048 and sp > 1) or (tiles * sp < 96 and sp < 16 and steps // (sp + 1) >= 2):
+                continue
+            if sp > 1 and sp * tiles * bm * bn > ops.LIN_SLAB_FLOATS:
+                continue
+            yield (bm, bn, sp, st)
+
+
+def cold(N, K, dev):
+    n_copies = max(2, min(64, -(-320 * 2 ** 20 // (N * K * 2))))
+    ws = [torch.randn(N, K, device=dev, dtype=torch.half) * K ** -0.5 for _ in range(n_copies)]
+    turn = [0]
+
+    def nxt():
+        turn[0] += 1
+        return ws[turn[0] % n_copies]
+    return ws, nxt
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     batches = [int(b) for b in (args[0] if args else "1,3").split(",")]
+    mode = sys.argv[sys.argv.index("--mode") + 1] if "--mode" in sys.argv else "all"
+    if "--mode" in sys.argv:
+        args = [a for a in args if a != mode]
+        batches = [int(b) for b in (args[0] if args else "1,3").split(",")]
     dev = torch.device("cuda")
     ops.prepare_device(dev)
-    table, plans, wins = {}, {}, 0
-    print(f"{'M':>6} {'K':>5} {'N':>6} {'lib us':>8} {'TF/s':>6} | {'best plan':>14} {'us':>8} {'TF/s':>6} {'x':>5}")
+    table, plans, wins, total = {}, {}, 0, 0
+
+    def report(tag, M, K, N, t_lib, res, flop, key):
+        nonlocal wins, total
+        best = min(res, key=res.get)
+        wins += res[best] <= t_lib
+        total += 1
+        print(f"{tag:>6} {M:>6} {K:>5} {N:>6} {t_lib:8.1f} {flop / t_lib / 1e6:6.0f} | {str(best):>18} {res[best]:8.1f} "
+              f"{flop / res[best] / 1e6:6.0f} {t_lib / res[best]:5.2f}", flush=True)
+        table[f"{tag},{M},{K},{N}"] = {"lib_us": round(t_lib, 1), "best": list(best), "best_us": round(res[best], 1),
+                                       "top": {str(k): round(v, 1) for k, v in sorted(res.items(), key=lambda kv: kv[1])[:4]}}
+        if key not in plans or tag != "plain":     # the fused forms are what the pipeline runs: they win the table entry
+            plans[key] = list(best)
+
+    print(f"{'form':>6} {'M':>6} {'K':>5} {'N':>6} {'lib us':>8} {'TF/s':>6} | {'best plan':>18} {'us':>8} {'TF/s':>6} {'x':>5}")
     for B in batches:
-        for tok, K, N in BASE:
-            M = B * tok
-            x = torch.randn(M, K, device=dev, dtype=torch.half)
-            n_copies = max(2, min(64, -(-320 * 2 ** 20 // (N * K * 2))))
-            ws = [torch.randn(N, K, device=dev, dtype=torch.half) * K ** -0.5 for _ in range(n_copies)]
-            bias = torch.randn(N, device=dev, dtype=torch.half)
-            turn = [0]
-
-            def nxt():
-                turn[0] += 1
-                return ws[turn[0] % n_copies]
-
-            flop = 2.0 * M * K * N
-            t_lib = replay_us(lambda: F.linear(x, nxt(), bias))
-            steps = K // 64
-            res = {}
-            for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64)):
-                for sp in (1, 2, 3, 4, 6, 8, 12, 16):
-                    if sp > 1 and steps // sp < 2:
-                        continue
-                    tiles = -(-M // bm) * -(-N // bn)
-                    if (tiles * sp > 2048 and sp > 1) or (tiles * sp < 96 and sp < 16 and steps // (sp + 1) >= 2):
-                        continue
-                    if sp > 1 and sp * tiles * bm * bn > ops.LIN_SLAB_FLOATS:
-                        continue
-                    plan = (bm, bn, sp)
-                    res[plan] = replay_us(lambda: ops.linear_fused(x, nxt(), bias, plan=plan), iters=20, reps=2)
-            best = min(res, key=res.get)
-            y = ops.linear_fused(x, ws[0], bias, plan=best)["y"]
-            ref = F.linear(x, ws[0], bias)
-            err = float((y.float() - ref.float()).abs().max() / ref.float().abs().max())
-            wins += res[best] <= t_lib
-            print(f"{M:>6} {K:>5} {N:>6} {t_lib:8.1f} {flop / t_lib / 1e6:6.0f} | {str(best):>14} {res[best]:8.1f} "
-                  f"{flop / res[best] / 1e6:6.0f} {t_lib / res[best]:5.2f}  err {err:.1e}", flush=True)
-            table[f"{M},{K},{N}"] = {"lib_us": round(t_lib, 1), "best": list(best), "best_us": round(res[best], 1), "err": err,
-                                     "all": {str(k): round(v, 1) for k, v in sorted(res.items(), key=lambda kv: kv[1])[:4]}}
-            plans[f"{M},{K},{N},0"] = list(best)
-    print(f"own kernel at least as fast as the library on {wins} of {len(table)} shapes (cold weights)")
+        if mode in ("plain", "all"):
+            for tok, K, N in BASE:
+                M = B * tok
+                x = torch.randn(M, K, device=dev, dtype=torch.half)
+                bias = torch.randn(N, device=dev, dtype=torch.half)
+                _, nxt = cold(N, K, dev)
+                t_lib = replay_us(lambda: F.linear(x, nxt(), bias))
+                res = {p: replay_us(lambda: ops.linear_fused(x, nxt(), bias, plan=p), reps=2) for p in candidates(M, K, N, False)}
+                report("plain", M, K, N, t_lib, res, 2.0 * M * K * N, f"{M},{K},{N},0")
+        if mode in ("fused", "all"):
+            for tok, C in ((4096, 320), (1024, 640), (256, 1280), (64, 1280)):
+                M = B * tok
+                x = torch.randn(M, C, device=dev, dtype=torch.half)
+                g, b_ = torch.ones(C, device=dev, dtype=torch.half), torch.zeros(C, device=dev, dtype=torch.half)
+                partials = torch.stack([x.float().sum(-1), (x.float() ** 2).sum(-1)], -1)[:, None, :].contiguous()
+                for N in (3 * C, C):            # LayerNorm -> qkv / to_q
+                    bias = torch.randn(N, device=dev, dtype=torch.half)
+                    _, nxt = cold(N, C, dev)
+                    cs, sh = torch.randn(N, device=dev), torch.randn(N, device=dev)
+                    t_lib = replay_us(lambda: F.linear(ops.layer_norm(x, g, b_, 1e-5), nxt(), bias))
+                    res = {p: replay_us(lambda: ops.linear_fused(x, nxt(), None, ln=(partials, cs, sh, 1e-5), plan=p), reps=2)
+                           for p in candidates(M, C, N, False)}
+                    report("ln", M, C, N, t_lib, res, 2.0 * M * C * N, f"{M},{C},{N},0")
+                for K in (C, 4 * C):            # Linear + bias + residual: to_out / proj_out, FF out
+                    xk = torch.randn(M, K, device=dev, dtype=torch.half)
+                    bias = torch.randn(C, device=dev, dtype=torch.half)
+                    r = torch.randn(M, C, device=dev, dtype=torch.half)
+                    _, nxt = cold(C, K, dev)
+                    t_lib = replay_us(lambda: F.linear(xk, nxt(), bias) + r)
+                    res = {p: replay_us(lambda: ops.linear_fused(xk, nxt(), bias, residual=r, want_row_partials=True, plan=p), reps=2)
+                           for p in candidates(M, K, C, False)}
+                    report("res", M, K, C, t_lib, res, 2.0 * M * K * C, f"{M},{K},{C},0")
+                N = 8 * C                       # LayerNorm -> FF in -> GEGLU
+                bias = torch.randn(N, device=dev, dtype=torch.half)
+                _, nxt = cold(N, C, dev)
+                cs, sh = torch.randn(N, device=dev), torch.randn(N, device=dev)
+                t_lib = replay_us(lambda: ops.geglu(F.linear(ops.layer_norm(x, g, b_, 1e-5), nxt(), bias)))
+                res = {p: replay_us(lambda: ops.linear_fused(x, nxt(), None, geglu=True, ln=(partials, cs, sh, 1e-5), plan=p), reps=2)
+                       for p in candidates(M, C, N // 2, True)}
+                report("geglu", M, C, N, t_lib, res, 2.0 * M * C * N, f"{M},{C},{N},1")
+    print(f"own kernel at least as fast as the library form on {wins} of {total} cases (cold weights)")
     print(json.dumps(table))
     if "--write" in sys.argv:
         path = Path(__file__).resolve().parent.parent / "guided-attention_amd" / "linear_plans.json"
