@@ -40,6 +40,14 @@ constexpr bool kAblNoExp = (GA_ABL & 1) != 0, kAblNoStage = (GA_ABL & 2) != 0, k
 
 // KT = rows of the swept tile (keys in fwd / dq, queries in dk_dv): 64, or 128 where the registers allow it
 // (fewer barriers and loop overheads per key: the 16-query forward ran 111 -> 91 us on the 4096-token layer).
+// A/B switch (tools/sa_variants.py): raise the wave's issue priority around its MFMA batches (s_setprio 1 ... 0), so that
+// the SIMD's other wave cannot slip vector work in between them.  Off in the product build unless the A/B says otherwise.
+#ifndef GA_SA_PRIO
+#define GA_SA_PRIO 0
+#endif
+#define GA_SA_PRIO_UP() do { if (GA_SA_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
+#define GA_SA_PRIO_DOWN() do { if (GA_SA_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+
 template <typename T, int KT>
 using TL = TileLds<T, KT>;
 
@@ -221,12 +229,14 @@ __device__ __forceinline__ void rows_times_cols(const T* img, const typename Tra
     // every fragment is already on its way: sweep the k-steps over batches of 4 row blocks, so that an MFMA never
     // waits for the one issued just before it (the two k-steps of a row block are a dependent chain)
     constexpr int GRP = NRB < 4 ? NRB : 4;
+    GA_SA_PRIO_UP();
 #pragma unroll
     for (int rb0 = 0; rb0 < NRB; rb0 += GRP)
 #pragma unroll
       for (int kc = 0; kc < NK; kc += 2)
 #pragma unroll
         for (int rb = rb0; rb < rb0 + GRP && rb < NRB; ++rb) step(rb, kc);
+    GA_SA_PRIO_DOWN();
   } else {
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
@@ -281,11 +291,13 @@ __device__ __forceinline__ void rowsT_times_frags(const T* img, const typename T
     const int st = (rb >> 1) & 1;
     if (rb + 2 < NRB) load(st ^ 1, rb + 2);
     __builtin_amdgcn_sched_barrier(0);  // keep the next stage's reads ahead of this stage's MFMAs
+    GA_SA_PRIO_UP();
 #pragma unroll
     for (int dt = 0; dt < NK; ++dt)
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb)
         out[dt][cb] = Traits<T>::mma16x2(a[st][dt][0], a[st][dt][1], f[rb][cb], f[rb + 1][cb], out[dt][cb]);
+    GA_SA_PRIO_DOWN();
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -310,6 +322,7 @@ struct ColFrags {
   }
   template <int CB>
   __device__ __forceinline__ void apply(const typename Traits<T>::frag (&f)[NRB][CB], f32x4 (&out)[NK][CB]) const {
+    GA_SA_PRIO_UP();
 #pragma unroll
     for (int rb = 0; rb < NRB; rb += 2)
 #pragma unroll
@@ -317,6 +330,7 @@ struct ColFrags {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
           out[dt][cb] = Traits<T>::mma16x2(a[rb >> 1][dt][0], a[rb >> 1][dt][1], f[rb][cb], f[rb + 1][cb], out[dt][cb]);
+    GA_SA_PRIO_DOWN();
   }
 };
 

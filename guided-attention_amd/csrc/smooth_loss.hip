@@ -32,6 +32,7 @@ struct LossArgs {
   int res, Kt, first, last, T;
   int ksize, smooth, strict;
   int stage_rows;   // pixel rows of A staged through LDS per pass of the softmax statistics (0: read from global memory)
+  int use_gcol;     // the guided tokens' columns of A are kept in LDS ([T][npix]); 0 (LDS budget): re-read from global memory
   float w_in, w_out3, w_c;
   double shrink;
   ga_token_t tok[kMaxTok];
@@ -100,7 +101,12 @@ __device__ __forceinline__ void row_stats(const LossArgs& a, const float* row, f
 // gcol[t][p] = A[p][column of guided token t]: taken while the row is at hand, so that the token loops never go back to
 // global memory (one dependent ~1-2 us load per token and phase otherwise: the launch is one workgroup, nothing hides it)
 __device__ __forceinline__ void gather_guided(const LossArgs& a, const float* row, int p, int npix, float* gcol) {
+  if (!a.use_gcol) return;
   for (int t = 0; t < a.T; ++t) gcol[t * npix + p] = row[a.first + a.tok[t].token - 1];
+}
+// A[p][column of guided token t]
+__device__ __forceinline__ float guided_value(const LossArgs& a, const float* gcol, int t, int p, int npix) {
+  return a.use_gcol ? gcol[(size_t)t * npix + p] : a.A[(size_t)p * a.Kt + a.first + a.tok[t].token - 1];
 }
 
 __device__ __forceinline__ void pixel_softmax_stats(const LossArgs& a, float* mx, float* sm, float* stage, float* gcol) {
@@ -204,14 +210,14 @@ __device__ __forceinline__ float strict_weights(const LossArgs& a, const ga_toke
 
 // Forward of one token into LDS: M (raw map), Pn (smoothed, normalised).  Returns the reductions.
 __device__ __forceinline__ TokenStats token_forward(const LossArgs& a, const ga_token_t& tk, const float* mx,
-                                                    const float* sm, const float* gcol_t, float* M, float* Pn, float* W,
-                                                    float* scratch) {
+                                                    const float* sm, const float* gcol, int t_idx, float* M, float* Pn,
+                                                    float* W, float* scratch) {
   const int res = a.res, npix = res * res;
   const bool strict = a.strict && tk.kind == GA_TOK_BOX;
   float at_most = 0.f;
   if (strict) at_most = strict_weights(a, tk, W, scratch);
-  // gcol_t[p] = A[p][first + token - 1]  (pipeline:228 "index - 1" into the [first:last) slice)
-  for (int p = threadIdx.x; p < npix; p += kThreads) M[p] = expf(gcol_t[p] * 100.0f - mx[p]) / sm[p];
+  // A[p][first + token - 1]  (pipeline:228 "index - 1" into the [first:last) slice)
+  for (int p = threadIdx.x; p < npix; p += kThreads) M[p] = expf(guided_value(a, gcol, t_idx, p, npix) * 100.0f - mx[p]) / sm[p];
   __syncthreads();
   const int pad = a.ksize >> 1;
   float v2[2] = {0.f, 0.f};
@@ -311,13 +317,13 @@ __device__ __forceinline__ void loss_forward(const LossArgs& a, float* lds, floa
   float* scratch = Pn + npix;  // 16 floats
   float* W = scratch + 16;     // [npix], strict mode only
   float* gcol = W + (a.strict ? npix : 0);             // [T][npix]
-  float* stage = align16(gcol + (size_t)a.T * npix);   // [stage_rows][Kt]
+  float* stage = align16(gcol + (a.use_gcol ? (size_t)a.T * npix : 0));   // [stage_rows][Kt]
   pixel_softmax_stats(a, mx, sm, stage, gcol);
   __syncthreads();
   float total = 0.f;
   for (int t = 0; t < a.T; ++t) {
     const ga_token_t& tk = a.tok[t];
-    const TokenStats st = token_forward(a, tk, mx, sm, gcol + (size_t)t * npix, M, Pn, W, scratch);
+    const TokenStats st = token_forward(a, tk, mx, sm, gcol, t, M, Pn, W, scratch);
     const TokenLoss tl = token_loss(a, tk, st);
     total += tk.weight * tl.item;
     if (threadIdx.x == 0) {
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
   float* dS = reinterpret_cast<float*>(colmap + ((a.Kt + 3) & ~3));  // [T][npix]
   float* W = dS + (size_t)a.T * npix;                                // [npix], strict mode only
   float* gcol = W + (a.strict ? npix : 0);                           // [T][npix]
-  float* stage = align16(gcol + (size_t)a.T * npix);                 // [stage_rows][Kt]
+  float* stage = align16(gcol + (a.use_gcol ? (size_t)a.T * npix : 0));   // [stage_rows][Kt]
 
   pixel_softmax_stats(a, mx, sm, stage, gcol);
   for (int c = threadIdx.x; c < a.Kt; c += kThreads) colmap[c] = -1;
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
   const float rm1 = (float)res - 1.0f;
   for (int t = 0; t < a.T; ++t) {
     const ga_token_t& tk = a.tok[t];
-    const TokenStats st = token_forward(a, tk, mx, sm, gcol + (size_t)t * npix, M, Pn, W, scratch);
+    const TokenStats st = token_forward(a, tk, mx, sm, gcol, t, M, Pn, W, scratch);
     const TokenLoss tl = token_loss(a, tk, st);
     if (threadIdx.x == 0) colmap[a.first + tk.token - 1] = t;
     const float sgc = tl.dc > 0.f ? 1.f : (tl.dc < 0.f ? -1.f : 0.f);
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
   // softmax backward: dA[p][c] = 100 * S[p][c] * (dS[p][c] - sum_k dS[p][k] S[p][k]) on the text slice
   for (int p = threadIdx.x; p < npix; p += kThreads) {
     float d = 0.f;
-    for (int t = 0; t < a.T; ++t) d += dS[(size_t)t * npix + p] * (expf(gcol[(size_t)t * npix + p] * 100.0f - mx[p]) / sm[p]);
+    for (int t = 0; t < a.T; ++t) d += dS[(size_t)t * npix + p] * (expf(guided_value(a, gcol, t, p, npix) * 100.0f - mx[p]) / sm[p]);
     dot[p] = d;
   }
   __syncthreads();
@@ -478,9 +484,9 @@ __global__ __launch_bounds__(kThreads) void smooth_loss_bwd_kernel(LossArgs a, c
   }
 }
 
-size_t fwd_lds(int npix, int T, int strict) { return sizeof(float) * ((4 + (strict ? 1 : 0) + (size_t)T) * (size_t)npix + 16); }
+size_t fwd_lds(int npix, int strict) { return sizeof(float) * ((4 + (strict ? 1 : 0)) * (size_t)npix + 16); }
 size_t bwd_lds(int npix, int Kt, int T, int strict) {
-  return sizeof(float) * ((6 + (strict ? 1 : 0)) * (size_t)npix + 16 + ((Kt + 3) & ~3) + 2 * (size_t)T * npix);
+  return sizeof(float) * ((6 + (strict ? 1 : 0)) * (size_t)npix + 16 + ((Kt + 3) & ~3) + (size_t)T * npix);
 }
 constexpr size_t kLdsBudget = 150 * 1024;
 // rows of A staged per pass: as many as fit beside the kernel's tables, at most one per thread, a multiple of 4
@@ -557,8 +563,10 @@ extern "C" int ga_smooth_loss_fwd(const float* A, int res, int Kt, int first, in
   LossArgs a;
   int rc = fill_args(a, A, res, Kt, first, last, tokens, T, hp);
   if (rc != GA_OK) return rc;
-  size_t lds = fwd_lds(res * res, T, a.strict);
+  size_t lds = fwd_lds(res * res, a.strict);
   if (lds > kLdsBudget) return GA_ERR_SHAPE;
+  a.use_gcol = lds + sizeof(float) * (size_t)T * res * res <= kLdsBudget / 2 ? 1 : 0;   // the columns first, the staging area with what is left
+  if (a.use_gcol) lds += sizeof(float) * (size_t)T * res * res;
   a.stage_rows = choose_stage_rows(lds, res * res, Kt, A);
   lds += sizeof(float) * (size_t)a.stage_rows * Kt + 16;
   if (set_dyn_lds(smooth_loss_fwd_kernel, lds) != GA_OK) return GA_ERR_LAUNCH;
@@ -588,6 +596,8 @@ extern "C" int ga_smooth_loss_bwd(const float* A, int res, int Kt, int first, in
   if (rc != GA_OK) return rc;
   size_t lds = bwd_lds(res * res, Kt, T, a.strict);
   if (lds > kLdsBudget) return GA_ERR_SHAPE;
+  a.use_gcol = lds + sizeof(float) * (size_t)T * res * res <= kLdsBudget / 2 ? 1 : 0;   // the columns first, the staging area with what is left
+  if (a.use_gcol) lds += sizeof(float) * (size_t)T * res * res;
   a.stage_rows = choose_stage_rows(lds, res * res, Kt, A);
   lds += sizeof(float) * (size_t)a.stage_rows * Kt + 16;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -623,8 +633,10 @@ extern "C" int ga_aggregate_loss_fwd(const void* const* maps, const int* heads, 
   LossArgs a;
   rc = fill_args(a, A, res, Kt, first, last, tokens, T, hp);
   if (rc != GA_OK) return rc;
-  size_t lds = fwd_lds(res * res, T, a.strict);
+  size_t lds = fwd_lds(res * res, a.strict);
   if (lds > kLdsBudget) return GA_ERR_SHAPE;
+  a.use_gcol = lds + sizeof(float) * (size_t)T * res * res <= kLdsBudget / 2 ? 1 : 0;   // the columns first, the staging area with what is left
+  if (a.use_gcol) lds += sizeof(float) * (size_t)T * res * res;
   a.stage_rows = choose_stage_rows(lds, res * res, Kt, A);
   lds += sizeof(float) * (size_t)a.stage_rows * Kt + 16;
   hipStream_t s = static_cast<hipStream_t>(stream);

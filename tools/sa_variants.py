@@ -21,10 +21,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", f"-I{
 
 # name -> (git revision of self_attn.hip or None for the working tree, extra -D flags)
 VARIANTS = {
-    "r1": ("1a2888f", []),                       # round-1 kernels
     "cur": (None, []),
+    "prio": (None, ["-DGA_SA_PRIO=1"]),              # s_setprio 1 around the MFMA batches
+    "noslp": (None, ["-fno-slp-vectorize"]),         # scalar f32 softmax arithmetic instead of the SLP-packed v_pk_* forms
+    "prio_noslp": (None, ["-DGA_SA_PRIO=1", "-fno-slp-vectorize"]),
     "nw2": (None, ["-DGA_FWD_NW=2"]),
-    "nw1": (None, ["-DGA_FWD_NW=1"]),
 }
 
 
