@@ -23,6 +23,34 @@ def supported(x, in_features, out_features):
             and x.stride(-1) == 1)
 
 
+def _transposed(weight):
+    """W^T (in_features, out_features) contiguous, cached per weight version: dX = dY W is then the SAME NT kernel with W^T as
+    its weight (the frozen UNet's Linear weights cost 0.7 GB twice — irrelevant beside 288 GB of HBM)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.dtype)
+    hit = _wt_cache.get(key)
+    if hit is None or hit[0]() is None:
+        with torch.no_grad():
+            wt = weight.t().contiguous()
+        if len(_wt_cache) > 2048:
+            for dead in [k for k, (ref, _) in _wt_cache.items() if ref() is None]:
+                del _wt_cache[dead]
+        import weakref
+        hit = _wt_cache[key] = (weakref.ref(weight), wt)
+    return hit[1]
+
+
+_wt_cache = {}
+
+
+def grad_input(gy, weight):
+    """dX = dY W for a frozen Linear (weight (N, K)): ga_linear_fused on the cached transpose where the kernel serves the
+    shape (N % 64 == 0: N is the depth of this product), the library GEMM otherwise."""
+    gy2 = gy if gy.stride(-1) == 1 else gy.contiguous()
+    if supported(gy2, weight.shape[0], weight.shape[1]) and weight.shape[1] % 8 == 0:
+        return ops.linear_fused(gy2, _transposed(weight), None)["y"]
+    return torch.matmul(gy, weight)
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b (+ residual) [, row partial sums of y].  Differentiable w.r.t. x and the residual."""
 
@@ -36,11 +64,14 @@ class _Linear(torch.autograd.Function):
         if partials is None:
             partials = x.new_empty(0)
         ctx.mark_non_differentiable(partials)
+        ctx.set_materialize_grads(False)     # no zero tensors for outputs nothing differentiates
         return out["y"], partials
 
     @staticmethod
     def backward(ctx, gy, _gp):
-        gx = torch.matmul(gy, ctx.weight) if ctx.needs_input_grad[0] else None
+        if gy is None:
+            return None, None, None, None, None
+        gx = grad_input(gy, ctx.weight) if ctx.needs_input_grad[0] else None
         return gx, None, None, (gy if ctx.has_res else None), None
 
 
@@ -72,7 +103,10 @@ def _folded(weight, bias, norm):
 
 
 class _LNLinear(torch.autograd.Function):
-    """y = [GEGLU](LayerNorm(x) W^T + b) with the statistics taken from `partials`.  Differentiable w.r.t. x."""
+    """(y, x) = ([GEGLU](LayerNorm(x) W^T + b), x) with the statistics taken from `partials`.  Differentiable w.r.t. x.
+    The second output is x itself: the caller hands THAT to x's other consumer (the residual input of the projection that
+    closes the sub-block), so that both gradients arrive here and the LayerNorm backward kernel adds them in its own pass
+    (`g_res` of ga_add_layer_norm_bwd) — autograd's accumulation would be one more launch per sub-block."""
 
     @staticmethod
     def forward(ctx, x, partials, norm, weight, bias, geglu):
@@ -83,19 +117,23 @@ class _LNLinear(torch.autograd.Function):
         if need:
             ctx.save_for_backward(x, out["ln_stats"], out["preact"] if geglu else None)
             ctx.norm, ctx.weight, ctx.geglu = norm, weight, geglu
-        return out["y"]
+        ctx.set_materialize_grads(False)
+        return out["y"], x.view_as(x)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_pass):
         x, stats, preact = ctx.saved_tensors
+        if gy is None:
+            return g_pass, None, None, None, None, None
         if ctx.geglu:
             gy = ops.geglu_backward(preact, gy)
-        g_ln = torch.matmul(gy, ctx.weight)                      # gradient at the LayerNorm's output (gamma applied inside)
-        gx = ops._ln_bwd(x.contiguous(), stats, ctx.norm.weight, g_ln, None)
+        g_ln = grad_input(gy, ctx.weight)                        # gradient at the LayerNorm's output (gamma applied inside)
+        gx = ops._ln_bwd(x.contiguous(), stats, ctx.norm.weight, g_ln, g_pass)
         return gx, None, None, None, None, None
 
 
 def ln_linear(x, partials, norm, weight, bias=None, geglu=False):
+    """-> (y, x): use the returned x for the residual connection (see _LNLinear)."""
     return _LNLinear.apply(x, partials, norm, weight, bias, geglu)
 
 

@@ -611,12 +611,15 @@ class AggregateSmoothLoss(torch.autograd.Function):
         ctx.save_for_backward(A)
         ctx.args = (res, first, last, plan, [m.shape for m in maps], maps[0].dtype)
         ctx.mark_non_differentiable(A, terms)
+        ctx.set_materialize_grads(False)
         return A, terms, loss
 
     @staticmethod
     def backward(ctx, _dA, _dterms, dloss):
         (A,) = ctx.saved_tensors
         res, first, last, plan, shapes, dtype = ctx.args
+        if dloss is None:
+            return (None,) * (4 + len(shapes))
         total = sum(s[0] for s in shapes)
         _, g = smooth_loss_bwd(A, res, first, last, plan, dloss, bcast_dtype=dtype, bcast_scale=1.0 / total)
         return (None, None, None, None) + tuple(g.unsqueeze(0).expand(s) for s in shapes)

@@ -229,7 +229,7 @@ class BasicTransformerBlock(nn.Module):
         x, xp = self.attn2(x, encoder_hidden_states=context,
                            folded={"partials": xp, "norm": self.norm2, "residual": x, "want_partials": True})
         proj, out = self.ff.net[0].proj, self.ff.net[2]
-        h = lin.ln_linear(x, xp, self.norm3, proj.weight, proj.bias, geglu=True)
+        h, x = lin.ln_linear(x, xp, self.norm3, proj.weight, proj.bias, geglu=True)
         return lin.linear(h, out.weight, out.bias, residual=x, want_partials=want_partials)
 
     def forward(self, x, context):

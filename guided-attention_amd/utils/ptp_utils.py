@@ -235,9 +235,11 @@ class AttendExciteCrossAttnProcessor:
         is_cross = encoder_hidden_states is not None
         store = self.attnstore
 
+        residual = [folded["residual"]] if folded is not None else None   # replaced by ln_linear's pass-through of the stream
+
         def finish(out):
             if folded is not None:
-                return fl.linear(out, attn.to_out[0].weight, attn.to_out[0].bias, residual=folded["residual"],
+                return fl.linear(out, attn.to_out[0].weight, attn.to_out[0].bias, residual=residual[0],
                                  want_partials=folded["want_partials"])
             return attn.to_out[1](attn.to_out[0](out))
 
@@ -248,7 +250,7 @@ class AttendExciteCrossAttnProcessor:
             if fused_ok and not (store is not None and store.wants_probs(False, n_pix)):
                 # self-attention without capture: one fused QKV GEMM, flash kernels on its column slices
                 if folded is not None:
-                    qkv = fl.ln_linear(hidden_states, folded["partials"], folded["norm"], fused_qkv_weight(attn))
+                    qkv, residual[0] = fl.ln_linear(hidden_states, folded["partials"], folded["norm"], fused_qkv_weight(attn))
                 else:
                     qkv = fused_qkv_projection(attn, hidden_states)
                 out = ops.SelfAttentionFusedQKV.apply(qkv, attn.heads, attn.scale)
@@ -261,7 +263,7 @@ class AttendExciteCrossAttnProcessor:
                 hidden_states = ops.layer_norm(hidden_states, norm.weight, norm.bias, norm.eps)
         context = encoder_hidden_states if is_cross else hidden_states
         if folded is not None and is_cross:
-            query = fl.ln_linear(hidden_states, folded["partials"], folded["norm"], attn.to_q.weight)
+            query, residual[0] = fl.ln_linear(hidden_states, folded["partials"], folded["norm"], attn.to_q.weight)
         else:
             query = attn.to_q(hidden_states)
         if is_cross and not context.requires_grad:

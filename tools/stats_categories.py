@@ -8,6 +8,7 @@ def cat(n):
     if "conv3x3_patch_kernel" in n: return "ga conv3x3 (patch variant)"
     if "conv3x3_kernel" in n: return "ga conv3x3 (per-tap variant)"
     if "conv_splitk" in n: return "ga conv split-K sum"
+    if "linear_kernel" in n: return "ga Linear (LayerNorm / GEGLU / residual folded in)"
     if "conv_pack" in n: return "ga conv weight pack"
     if n.startswith("Cijk") or n.startswith("Custom_Cijk"): return "hipBLASLt GEMM"
     if "igemm" in n or "ck16tensor" in n or "ck::" in n or "conv" in n.lower(): return "MIOpen/CK conv"
