@@ -410,9 +410,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
 constexpr int patch_pieces(int BM, bool wide = false) { return wide ? 13 : (BM >= 128 ? 9 : 7); }
 
 struct PatchGeom {
-  int nseg, srows;   // the tile = nseg segments of srows full rows each (nseg > 1: whole images, srows = H)
+  int nseg, srows;   // the tile = nseg segments; the patch of a segment holds srows + 2 image rows of W + 2 pixels
 };
 
+// Which tiles the patch kernel takes:
+//   (1) whole image rows:      BM = k W          -> one segment of k rows
+//   (2) whole small images:    BM = k H W        -> k segments of H rows
+//   (3) any run of BM consecutive pixels of ONE image (H W a multiple of BM): the run starts at column m0 mod W and wraps
+//       around the row ends; its patch holds every image row it touches — at most (W + BM - 2) / W + 1 of them, plus the
+//       halo.  This is what maps that are not whole rows of 128 or 64 pixels take: the 96 / 48 / 24-wide levels of the
+//       768^2 configuration (BASELINE config 4), which round 2 left on the per-tap kernel at 5.7 - 6.5 x the algorithmic
+//       bytes.  A 32-pixel fragment block that wraps a row end reads two patch rows (a few bank conflicts on those blocks).
 __host__ __device__ inline bool patch_geometry(int BM, int H, int W, PatchGeom& g, bool wide = false) {
   if (BM % W == 0 && (H * W) % BM == 0) {
     g.nseg = 1;
@@ -420,6 +428,9 @@ __host__ __device__ inline bool patch_geometry(int BM, int H, int W, PatchGeom& 
   } else if (BM % (H * W) == 0) {
     g.nseg = BM / (H * W);
     g.srows = H;
+  } else if ((H * W) % BM == 0) {
+    g.nseg = 1;
+    g.srows = (W + BM - 2) / W + 1;
   } else {
     return false;
   }
@@ -456,7 +467,10 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
 
   PatchGeom g;
   patch_geometry(BM, a.H, a.W, g, WIDE);
-  const int PW = a.W + 2, seg_px = g.srows * a.W, seg_rows = g.srows + 2;
+  // geometry (3) (a run that is not made of whole rows): one segment that starts in the middle of a row
+  const bool run = BM % a.W != 0 && BM % (a.H * a.W) != 0;
+  const int col0 = run ? (m0 % (a.H * a.W)) % a.W : 0;
+  const int PW = a.W + 2, seg_px = run ? BM : g.srows * a.W, seg_rows = g.srows + 2;
   const int npatch = g.nseg * seg_rows * PW;
 
   constexpr unsigned kOob = 0x80000000u;
@@ -533,7 +547,7 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
 #pragma unroll
   for (int i = 0; i < IM; ++i) {
     const int pm = wm * WM + i * 32 + lane_pixel(fr, a.lane_rot);
-    const int seg = pm / seg_px, rem = pm - seg * seg_px;
+    const int seg = pm / seg_px, rem = pm - seg * seg_px + col0;   // col0: the column the tile's first pixel sits in
     const int r = rem / a.W, c = rem - r * a.W;
     pix_base[i] = ((seg * seg_rows + r) * PW + c) * kLD + fh * 8;
   }
@@ -626,7 +640,7 @@ struct Plan {
 //              what makes a split pay at M = 256 (30 MB of slabs for 12 splits) and hurt at M = 49 152 (500 MB for 4: the
 //              first rule, a flat 1.5 % per split, chose 4 splits for SDXL's 128x128 level and doubled its time).
 // At most 16 splits, at least 3 k-steps per slice; 320 outputs prefer 64-wide tiles (no channel padding).
-Plan choose_plan(int M, int N, int steps) {
+Plan choose_plan(int M, int N, int steps, int H, int W, int stride) {
   const int cands[3][2] = {{128, 128}, {128, 64}, {64, 64}};
   const double rate[3] = {700.0, 650.0, 570.0};   // TFLOP/s of a well-filled launch per tile shape (profiles/r2_conv_tune.txt)
   const double flops = 2.0 * (double)M * (double)N * (double)steps * kKC;
@@ -636,11 +650,16 @@ Plan choose_plan(int M, int N, int steps) {
     const int bm = cands[ci][0], bn = cands[ci][1];
     const long long tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn, tiles = tm * tn;
     const double waste = (double)(tm * bm) * (double)(tn * bn) / ((double)M * (double)N);
+    // tiles the patch-in-LDS kernel cannot take fall to the per-tap kernel (9 x the A-side staging): about 0.7 of the rate
+    PatchGeom pg;
+    const bool patchable = stride == 1 && W >= 16 &&
+                           (patch_geometry(bm, H, W, pg) || ((bn <= 64 || bm == 128) && patch_geometry(bm, H, W, pg, true)));
+    const double tile_rate = rate[ci] * (patchable ? 1.0 : 0.7);
     const int max_s = steps / 3 < 16 ? (steps / 3 < 1 ? 1 : steps / 3) : 16;
     for (int s = 1; s <= max_s; ++s) {
       const double wgs = (double)tiles * s;
       const double fill = wgs <= 512.0 ? 480.0 / (wgs < 480.0 ? wgs : 480.0) : ((double)((long long)((wgs + 511) / 512)) * 512.0) / wgs;
-      const double compute_us = flops * waste * fill / (rate[ci] * 1e6);
+      const double compute_us = flops * waste * fill / (tile_rate * 1e6);
       const double split_us = s > 1 ? (double)s * (double)M * (double)N * 8.0 / 4.0e6 + 3.0 : 0.0;   // slabs out and back + the hand-off
       const double us = compute_us + split_us;
       if (us < best_us) {
@@ -680,10 +699,10 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, con
   // 8x8 maps stay on the per-tap kernel: the halo makes the patch 100 pixels for 64 and the depth splits only by chunks
   const bool geom_ok = a.pad == 1 && a.stride == 1 && a.W >= 16 && !force_v1();
   const bool patch = geom_ok && patch_geometry(BM, a.H, a.W, pg);
-  const bool patch_wide = geom_ok && !patch && BM == 128 && patch_geometry(BM, a.H, a.W, pg, true);
-  if (patch_wide) {   // a 128-pixel tile of one 128-wide row: the 13-piece instantiation
+  const bool patch_wide = geom_ok && !patch && (BN <= 64 || BM == 128) && patch_geometry(BM, a.H, a.W, pg, true);
+  if (patch_wide) {   // the 13-piece instantiation: one row of a 128-wide map, or a run of a 96- / 48-wide map (geometry 3)
     a.steps_per = (a.Cin / kKC + splits - 1) / splits;
-    if constexpr (BM == 128) {
+    if constexpr (BN <= 64 || BM == 128) {
       if (splits == 1)
         hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, false, true>), grid, dim3(kThreads), 0, s, X, Wp, Y,
                            (float*)nullptr, (unsigned*)nullptr, bias, residual, a);
@@ -750,7 +769,7 @@ extern "C" int ga_conv3x3_plan(int B, int H, int W, int Cin, int Cout, int strid
   if (B < 1 || H < 1 || W < 1 || Cin < kKC || Cin % kKC != 0 || Cout < 8 || Cout % 8 != 0 || (stride != 1 && stride != 2))
     return GA_ERR_SHAPE;
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-  const Plan p = choose_plan(B * Ho * Wo, Cout, 9 * Cin / kKC);
+  const Plan p = choose_plan(B * Ho * Wo, Cout, 9 * Cin / kKC, H, W, stride);
   *bm = p.bm;
   *bn = p.bn;
   *splits = p.splits;

@@ -781,6 +781,11 @@ CONV_SHAPES = [  # B, Cin, Cout, H, W, stride
     (3, 128, 64, 8, 8, 1), (2, 128, 64, 64, 64, 1), (1, 192, 128, 32, 32, 1), (3, 128, 192, 16, 16, 1),
     (2, 128, 64, 3, 128, 1), (1, 64, 128, 4, 128, 1),    # 128-wide maps (SDXL's top level): one row per tile, 13-piece patch
     (2, 64, 192, 64, 64, 1),   # activations outweigh the weights: the n-tile-fastest workgroup order inside an XCD's run
+    # BASELINE config 4 (768^2: 96 / 48 / 24-wide maps): tiles are runs of pixels that start mid-row and wrap around the row
+    # ends (patch geometry 3), at the configuration's real widths; plus small-channel cases of the same geometry incl. a batch
+    # whose images must not share a tile and a 40-wide map (runs of 64 pixels: 1.6 rows)
+    (1, 320, 320, 96, 96, 1), (1, 640, 640, 48, 48, 1), (3, 1280, 1280, 24, 24, 1),
+    (2, 64, 64, 24, 24, 1), (1, 64, 128, 48, 48, 1), (2, 128, 64, 32, 40, 1),
 ]
 
 
