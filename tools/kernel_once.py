@@ -4,6 +4,7 @@
   kernel_once.py cap_fwd|cap_bwd B H N D [dtype]      cross-attention capture (Kt = 77; fwd stores P)
   kernel_once.py gn_fwd|gn_bwd B C HW [dtype]         GroupNorm(+SiLU), 32 groups, channels-last
   kernel_once.py conv B Cin HW stride Cout [dtype]    3x3 implicit-GEMM convolution with bias + residual, the planner's tile
+  kernel_once.py lin M K N flags [dtype]              ga_linear_fused: flags = geglu | 2 LayerNorm fold | 4 residual
 Inputs are resident in HBM before the launches; 5 launches each."""
 import sys
 from pathlib import Path
@@ -61,6 +62,18 @@ elif kind == "conv":
     torch.cuda.synchronize()
     for _ in range(reps):
         ops.conv3x3_nhwc(x, wp, cout, stride, bias, res)
+elif kind == "lin":
+    M, K, N, flags = nums
+    x = torch.randn(M, K, device=dev, dtype=dt)
+    w = torch.randn(N, K, device=dev, dtype=dt) * K ** -0.5
+    bias = torch.randn(N, device=dev, dtype=dt)
+    n_out = N // 2 if flags & 1 else N
+    res = torch.randn(M, n_out, device=dev, dtype=dt) if flags & 4 else None
+    ln = (torch.rand(M, 5, 2, device=dev) * K, torch.randn(N, device=dev), torch.randn(N, device=dev), 1e-5) if flags & 2 else None
+    ops.prepare_device(torch.device(dev, torch.cuda.current_device()))
+    torch.cuda.synchronize()
+    for _ in range(reps):
+        ops.linear_fused(x, w, bias, residual=res, geglu=bool(flags & 1), ln=ln)
 else:
     raise SystemExit(f"unknown kernel kind {kind}")
 torch.cuda.synchronize()
