@@ -37,6 +37,7 @@ using namespace ga;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 #ifndef GA_CONV_PRIO
 #define GA_CONV_PRIO 0
@@ -608,6 +609,219 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
   conv_epilogue<T, BM, BN, OUT_F32>(acc, lds, Y, part, tickets, bias, residual, a, m0, n0, split);
 }
 
+// ---- the patch variant with the WEIGHTS going global -> LDS directly (buffer_load ... lds) ----------------------------------
+// In the kernel above a weight tile makes three hops — global -> 2 or 4 register quads per thread -> ds_write_b128 -> LDS —
+// with 3 to 9 register sets rotating to keep several k-steps in flight: 72 VGPRs for a 64-wide tile, an LDS write path that
+// tops out near 79 B/clk, and 5.6 of the 32.8 us of the batch-3 320 -> 320 launch (r2 ablation).  Here the weight tile
+// [BN][64] of a (chunk, tap) step is written by the DMA engine into a ring of NW slots (no staging registers, no ds_write):
+//   * an LDS-DMA wave-instruction writes 1 KiB contiguously (8 rows of 128 bytes): rows cannot be padded, so the slot is
+//     XOR-swizzled in 16-byte units — physical column = logical column ^ ((row >> 1) & 7), applied on the SOURCE address
+//     and on the fragment reads (a 32-row fragment's ds_read_b128 lane groups then cover all 64 banks);
+//   * PD = NW - 1 steps are in flight behind COUNTED s_waitcnt vmcnt(N) and raw s_barrier; the patch loads of the next chunk
+//     (ordinary loads to registers, issued at tap 0) sit in the same in-order counter: N is a compile-time constant per
+//     unrolled tap.  Past the last step the same step is loaded again into a slot nobody reads, so the counts stay static;
+//   * every LDS access inside the loop is inline asm: a C++ LDS load or store makes the compiler wait vmcnt(0) first (any
+//     pending LDS-DMA may alias it as far as its wait-count pass can tell) and the ring would drain at every step.
+// The patch staging (registers -> padded rows) and the epilogue are the kernel's above.
+__device__ __forceinline__ void conv_lds_read128(u32x4_t& dst, unsigned byte_address) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(byte_address) : "memory");
+#else
+  dst = u32x4_t{byte_address, 0u, 0u, 0u};
+#endif
+}
+__device__ __forceinline__ void conv_lds_write128(unsigned byte_address, u32x4_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_write_b128 %0, %1" ::"v"(byte_address), "v"(v) : "memory");
+#endif
+}
+template <int N>
+__device__ __forceinline__ void conv_wait_vmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+template <int N>
+__device__ __forceinline__ void conv_wait_lgkmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
+template <typename T, int BM, int BN, bool OUT_F32, bool WIDE = false>
+__global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_patch_dma_kernel(
+    const T* __restrict__ X, const T* __restrict__ Wp, T* __restrict__ Y, float* __restrict__ part,
+    unsigned* __restrict__ tickets, const T* __restrict__ bias, const T* __restrict__ residual, ConvArgs a) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int IM = WM / 32, JN = WN / 32;
+  constexpr int QP = kKC / 8;                 // 16-byte pieces per row
+  constexpr int RPP = kThreads / QP;          // rows staged per pass
+  constexpr int kPatchPieces = patch_pieces(BM, WIDE);
+  constexpr int kPatchRows = kPatchPieces * RPP;
+  constexpr int kPatch = kPatchRows * kLD;                 // elements of the patch buffer (padded rows)
+  constexpr int kSlot = BN * kKC;                          // elements of one weight ring slot (128-byte rows, swizzled)
+  constexpr int NW = BN <= 64 ? 4 : 2;                     // ring slots: 32 KB either way (two workgroups per CU)
+  constexpr int PD = NW - 1;                               // steps in flight
+  constexpr int IPW = BN / 32;                             // LDS-DMA wave-instructions per slot and wave
+  constexpr int kCtile = BM * (BN + 8);
+  constexpr int kLds = kPatch + NW * kSlot > kCtile ? kPatch + NW * kSlot : kCtile;
+  static_assert((kPatch * (int)sizeof(T)) % 256 == 0, "the ring starts on a bank-row boundary (the swizzle assumes it)");
+  __shared__ __attribute__((aligned(1024))) T lds[kLds];
+  T* ring = lds + kPatch;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int m0, n0, split;
+  tile_of_workgroup<BM, BN>(a, m0, n0, split);
+  const int cchunks = a.Cin / kKC;
+  const int c_begin = split * a.steps_per, c_end = min(cchunks, c_begin + a.steps_per);   // chunks of this split
+
+  PatchGeom g;
+  patch_geometry(BM, a.H, a.W, g, WIDE);
+  const bool run = BM % a.W != 0 && BM % (a.H * a.W) != 0;
+  const int col0 = run ? (m0 % (a.H * a.W)) % a.W : 0;
+  const int PW = a.W + 2, seg_px = run ? BM : g.srows * a.W, seg_rows = g.srows + 2;
+  const int npatch = g.nseg * seg_rows * PW;
+
+  constexpr unsigned kOob = 0x80000000u;
+  const int srow = tid / QP, sq = tid % QP;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wp), 0, a.w_bytes, 0x00020000);
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)lds);
+
+  // ---- patch staging (as above; the LDS stores are asm)
+  unsigned pa_off[kPatchPieces];
+#pragma unroll
+  for (int p = 0; p < kPatchPieces; ++p) {
+    const int q = srow + RPP * p;
+    const int seg = q / (seg_rows * PW), rem = q - seg * (seg_rows * PW);
+    const int pr = rem / PW, pc = rem - pr * PW;
+    const int mseg = m0 + seg * seg_px;
+    const int b = mseg / (a.H * a.W), y0 = (mseg - b * (a.H * a.W)) / a.W;
+    const int iy = y0 + pr - 1, ix = pc - 1;
+    const bool ok = q < npatch && mseg < a.M && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    pa_off[p] = ok ? (unsigned)((((b * a.H + iy) * a.W + ix) * a.Cin + 8 * sq) * (int)sizeof(T)) : kOob;
+  }
+  u32x4_t rp[kPatchPieces];
+  auto load_patch = [&](int chunk) {
+    const unsigned step = (unsigned)(chunk * kKC * (int)sizeof(T));
+#pragma unroll
+    for (int p = 0; p < kPatchPieces; ++p) rp[p] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, pa_off[p] + step, 0, 0);
+  };
+  const unsigned patch_st = lds0 + (unsigned)((srow * kLD + 8 * sq) * (int)sizeof(T));
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int p = 0; p < kPatchPieces; ++p) conv_lds_write128(patch_st + (unsigned)(RPP * p * kLD * (int)sizeof(T)), rp[p]);
+  };
+
+  // ---- weight DMA: instruction q of this wave fills rows 8 g .. 8 g + 7 of the slot, g = wave + 4 q; lane l lands at row
+  // 8 g + (l >> 3), physical 16-byte column l & 7, and therefore fetches logical column (l & 7) ^ swizzle(row)
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  unsigned w_off[IPW];
+#pragma unroll
+  for (int q = 0; q < IPW; ++q) {
+    const int row = 8 * (wave + 4 * q) + (lane >> 3);
+    const int col = (lane & 7) ^ ((row >> 1) & 7);
+    w_off[q] = (unsigned)((min(n0 + row, a.Cout - 1) * a.Cin + 8 * col) * (int)sizeof(T));   // rows past Cout repeat the last one (never stored)
+  }
+  auto issue_w = [&](int chunk, int tap, int slot) {
+    const unsigned step = (unsigned)((tap * a.Cout * a.Cin + chunk * kKC) * (int)sizeof(T));
+#pragma unroll
+    for (int q = 0; q < IPW; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(ring + slot * kSlot + (wave_u + 4 * q) * 8 * kKC),
+                                               16, (int)w_off[q], (int)step, 0, 0);
+  };
+
+  f32x16 acc[JN][IM];
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  // ---- fragment addresses (LDS byte addresses)
+  const int fr = lane & 31, fh = lane >> 5;
+  unsigned pix_adr[IM], b_adr[JN], b_sw[JN];
+#pragma unroll
+  for (int i = 0; i < IM; ++i) {
+    const int pm = wm * WM + i * 32 + lane_pixel(fr, a.lane_rot);
+    const int seg = pm / seg_px, rem = pm - seg * seg_px + col0;
+    const int r = rem / a.W, c = rem - r * a.W;
+    pix_adr[i] = lds0 + (unsigned)((((seg * seg_rows + r) * PW + c) * kLD + fh * 8) * (int)sizeof(T));
+  }
+#pragma unroll
+  for (int j = 0; j < JN; ++j) {
+    const int row = wn * WN + j * 32 + fr;
+    b_adr[j] = lds0 + (unsigned)((kPatch + row * kKC) * (int)sizeof(T));
+    b_sw[j] = (unsigned)(((row >> 1) & 7) ^ fh);
+  }
+  auto mma_tap = [&](int slot, int ky, int kx) {
+    const unsigned tap_off = (unsigned)((ky * PW + kx) * kLD * (int)sizeof(T));   // wave-uniform
+    const unsigned slot_off = (unsigned)(slot * kSlot * (int)sizeof(T));
+    u32x4_t fa[2][IM], fb[2][JN];
+    auto request = [&](int kk, int set) {
+#pragma unroll
+      for (int i = 0; i < IM; ++i) conv_lds_read128(fa[set][i], pix_adr[i] + tap_off + (unsigned)(kk * 16 * (int)sizeof(T)));
+#pragma unroll
+      for (int j = 0; j < JN; ++j) conv_lds_read128(fb[set][j], b_adr[j] + slot_off + 16u * ((2u * kk) ^ b_sw[j]));
+    };
+    request(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < kKC / 16; ++kk) {
+      if (kk + 1 < kKC / 16) {
+        request(kk + 1, (kk + 1) & 1);
+        conv_wait_lgkmcnt<IM + JN>();
+      } else {
+        conv_wait_lgkmcnt<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int i = 0; i < IM; ++i)
+          acc[j][i] = Mma32<T>::run(__builtin_bit_cast(uint4, fb[kk & 1][j]), __builtin_bit_cast(uint4, fa[kk & 1][i]), acc[j][i]);
+    }
+  };
+
+  if (c_begin < c_end) {
+    // prologue: patch of the first chunk (registers -> LDS), weights of its first PD steps into ring slots 0 .. PD - 1
+    load_patch(c_begin);
+#pragma unroll
+    for (int t = 0; t < PD; ++t) issue_w(c_begin, t, t);
+    store_patch();                 // the compiler waits for rp[] itself (its count includes the DMA instructions issued after)
+    conv_wait_lgkmcnt<0>();
+    int s = 0;                     // global step counter of this workgroup: ring slot = s % NW
+    for (int c = c_begin; c < c_end; ++c) {
+      const int cn = min(c + 1, c_end - 1);   // next chunk (clamped: loaded again and never used after the last one)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        // younger than step s's DMA at this point: the DMAs of steps s + 1 .. s + PD - 1, and the next chunk's patch loads
+        // when they were issued in between (at tap 0, behind that step's DMA): taps 1 .. PD
+        constexpr int kPatchInFlight = kPatchPieces;
+        if (t >= 1 && t <= PD) conv_wait_vmcnt<(PD - 1) * IPW + kPatchInFlight>();
+        else conv_wait_vmcnt<(PD - 1) * IPW>();
+        __builtin_amdgcn_s_barrier();   // step s's weights (and, at tap 0, the patch) are in LDS for everyone; step s - 1 is read
+        {  // refill the slot step s - 1 occupied with step s + PD
+          const int tt = t + PD;
+          if (tt < 9) issue_w(c, tt, (s + PD) % NW);
+          else issue_w(cn, tt - 9, (s + PD) % NW);
+        }
+        if (t == 0) load_patch(cn);
+        mma_tap(s % NW, t / 3, t % 3);
+        ++s;
+      }
+      // every wave is past tap 8 of this chunk after the barrier: the patch may be replaced
+      __builtin_amdgcn_s_barrier();
+      store_patch();
+      conv_wait_lgkmcnt<0>();
+    }
+  }
+  conv_wait_vmcnt<0>();
+  __syncthreads();
+  conv_epilogue<T, BM, BN, OUT_F32>(acc, lds, Y, part, tickets, bias, residual, a, m0, n0, split);
+}
+
 // pre-pack: W [Cout][Cin][3][3] in whatever strides the framework holds (element strides given) ->
 //   forward : Wp[t = ky*3+kx][n = cout][c = cin]          = W[cout][cin][ky][kx]
 //   backward: Wp[t = ky*3+kx][n = cin ][c = cout]         = W[cout][cin][2-ky][2-kx]   (dX = conv(dY, flipped, transposed))
@@ -671,6 +885,15 @@ Plan choose_plan(int M, int N, int steps, int H, int W, int stride) {
   return best;
 }
 
+// GA_CONV_DMA=0 in the environment keeps the register-staged weight path of the patch kernel (A/B runs)
+inline bool use_dma() {
+  static const bool v = [] {
+    const char* e = getenv("GA_CONV_DMA");
+    return e == nullptr || e[0] != '0';
+  }();
+  return v;
+}
+
 // GA_CONV_V1=1 in the environment keeps every shape on the per-tap staging kernel (A/B runs of tools/conv_tune.py)
 inline bool force_v1() {
   static const bool v = [] {
@@ -703,18 +926,35 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, con
   if (patch_wide) {   // the 13-piece instantiation: one row of a 128-wide map, or a run of a 96- / 48-wide map (geometry 3)
     a.steps_per = (a.Cin / kKC + splits - 1) / splits;
     if constexpr (BN <= 64 || BM == 128) {
-      if (splits == 1)
+      if (use_dma()) {
+        if (splits == 1)
+          hipLaunchKernelGGL((conv3x3_patch_dma_kernel<T, BM, BN, false, true>), grid, dim3(kThreads), 0, s, X, Wp, Y,
+                             (float*)nullptr, (unsigned*)nullptr, bias, residual, a);
+        else
+          hipLaunchKernelGGL((conv3x3_patch_dma_kernel<T, BM, BN, true, true>), grid, dim3(kThreads), 0, s, X, Wp, Y, ws,
+                             tickets, bias, residual, a);
+      } else if (splits == 1) {
         hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, false, true>), grid, dim3(kThreads), 0, s, X, Wp, Y,
                            (float*)nullptr, (unsigned*)nullptr, bias, residual, a);
-      else
+      } else {
         hipLaunchKernelGGL((conv3x3_patch_kernel<T, BM, BN, true, true>), grid, dim3(kThreads), 0, s, X, Wp, Y, ws, tickets,
                            bias, residual, a);
+      }
       return check_launch();
     }
   }
   if (patch) {
     a.steps_per = (a.Cin / kKC + splits - 1) / splits;   // this variant splits the depth by channel chunks
     a.lane_rot = a.W == 16 ? 2 : 0;
+  }
+  if (patch && use_dma()) {
+    if (splits == 1)
+      hipLaunchKernelGGL((conv3x3_patch_dma_kernel<T, BM, BN, false>), grid, dim3(kThreads), 0, s, X, Wp, Y, (float*)nullptr,
+                         (unsigned*)nullptr, bias, residual, a);
+    else
+      hipLaunchKernelGGL((conv3x3_patch_dma_kernel<T, BM, BN, true>), grid, dim3(kThreads), 0, s, X, Wp, Y, ws, tickets, bias,
+                         residual, a);
+    return check_launch();
   }
   if (splits == 1) {
     if (patch)
