@@ -649,7 +649,7 @@ __device__ __forceinline__ void conv_wait_lgkmcnt() {
 }
 
 template <typename T, int BM, int BN, bool OUT_F32, bool WIDE = false>
-__global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_patch_dma_kernel(
+__global__ __launch_bounds__(kThreads, WIDE ? 1 : 2) void conv3x3_patch_dma_kernel(
     const T* __restrict__ X, const T* __restrict__ Wp, T* __restrict__ Y, float* __restrict__ part,
     unsigned* __restrict__ tickets, const T* __restrict__ bias, const T* __restrict__ residual, ConvArgs a) {
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -759,28 +759,41 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
   auto mma_tap = [&](int slot, int ky, int kx) {
     const unsigned tap_off = (unsigned)((ky * PW + kx) * kLD * (int)sizeof(T));   // wave-uniform
     const unsigned slot_off = (unsigned)(slot * kSlot * (int)sizeof(T));
-    u32x4_t fa[2][IM], fb[2][JN];
+    // fragments of sub-step kk + 1 are requested before the MFMAs of kk (LDS returns in order: a counted lgkmcnt tells when
+    // kk's operands are in); the 128 x 128 tile has no registers for a second set under the two-workgroups-per-CU cap
+    constexpr bool kAhead = IM * JN <= 2;
+    constexpr int NSET = kAhead ? 2 : 1;
+    u32x4_t fa[NSET][IM], fb[NSET][JN];
     auto request = [&](int kk, int set) {
 #pragma unroll
       for (int i = 0; i < IM; ++i) conv_lds_read128(fa[set][i], pix_adr[i] + tap_off + (unsigned)(kk * 16 * (int)sizeof(T)));
 #pragma unroll
       for (int j = 0; j < JN; ++j) conv_lds_read128(fb[set][j], b_adr[j] + slot_off + 16u * ((2u * kk) ^ b_sw[j]));
     };
-    request(0, 0);
+    if constexpr (kAhead) request(0, 0);
 #pragma unroll
     for (int kk = 0; kk < kKC / 16; ++kk) {
-      if (kk + 1 < kKC / 16) {
-        request(kk + 1, (kk + 1) & 1);
-        conv_wait_lgkmcnt<IM + JN>();
+      constexpr int dummy = 0;
+      (void)dummy;
+      if constexpr (kAhead) {
+        if (kk + 1 < kKC / 16) {
+          request(kk + 1, (kk + 1) & 1);
+          conv_wait_lgkmcnt<IM + JN>();
+        } else {
+          conv_wait_lgkmcnt<0>();
+        }
       } else {
+        request(kk, 0);
         conv_wait_lgkmcnt<0>();
       }
       __builtin_amdgcn_sched_barrier(0);
+      const int set = kAhead ? (kk & 1) : 0;
 #pragma unroll
       for (int j = 0; j < JN; ++j)
 #pragma unroll
         for (int i = 0; i < IM; ++i)
-          acc[j][i] = Mma32<T>::run(__builtin_bit_cast(uint4, fb[kk & 1][j]), __builtin_bit_cast(uint4, fa[kk & 1][i]), acc[j][i]);
+          acc[j][i] = Mma32<T>::run(__builtin_bit_cast(uint4, fb[set][j]), __builtin_bit_cast(uint4, fa[set][i]), acc[j][i]);
+      if constexpr (!kAhead) __builtin_amdgcn_sched_barrier(0);   // the next sub-step's asm reads overwrite the fragment set
     }
   };
 

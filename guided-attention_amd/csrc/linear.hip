@@ -445,207 +445,6 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 64 * 1024 ? 2
   lin_epilogue<T, BM, BN, GEGLU, LN>(acc, lds, Y, a, p, m0, n0, nt, ln_m, ln_r);
 }
 
-// ---- token-stationary variant for SHORT depths (K <= 640: the 64x64 and 32x32 levels' q / qkv / FF-in projections) ----------
-// With K = 320 a tile of the kernel above is five k-steps: its time is the prologue's memory round trip, five half-hidden
-// ones and the epilogue — 13 x its MFMA time at batch 3 (12288 x 320 x 2560 with GEGLU: 57 us where the arithmetic needs 8),
-// and every one of the N / BN column tiles re-reads the same token rows from L2.  Here a workgroup keeps its BM token rows
-// for the WHOLE depth in LDS (BM x K x 2 bytes, loaded once by LDS-DMA) and walks a run of column tiles: the weight tiles
-// [BN][64] stream through a ring that never drains between tiles (the loads of the next tile's first k-steps are in flight
-// while this tile's epilogue runs), so after the first tile there is no prologue any more.  One workgroup per CU (the
-// token rows take 80 KB), grid = m tiles x column groups.
-template <typename T, int BM, int BN, int NSTAGE, bool GEGLU, bool LN>
-__global__ __launch_bounds__(kThreads, 1) void linear_stationary_kernel(const T* __restrict__ X, const T* __restrict__ W,
-                                                                        T* __restrict__ Y, LinArgs a, LinPtrs p) {
-  constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, JN = WN / 32;
-  constexpr int kSlot = BN * kBK;                            // elements per weight ring slot
-  constexpr int IPA = BM / 32, IPW = BN / 32;                // LDS-DMA wave-instructions per token chunk / weight slot and wave
-  constexpr int LDC = BN + 8;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];   // [token rows: KC x BM x 64][ring][output tile]
-  T* lds = reinterpret_cast<T*>(lds_raw);
-  const int KC = a.steps;                                    // 64-deep chunks of the depth
-  T* ring = lds + KC * BM * kBK;
-  T* Cs = ring + NSTAGE * kSlot;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
-  int mt, ng, unused;
-  lin_tile<BM, BN>(a, mt, ng, unused);                       // a.tn = column GROUPS here, a.splits = 1
-  const int m0 = mt * BM;
-  const int nt0 = ng * a.steps_per, nt1 = min(a.n_fastest /* total column tiles */, nt0 + a.steps_per);
-  const int total = (nt1 - nt0) * KC;                        // ring steps of this workgroup
-  constexpr int OUTC = GEGLU ? BN / 2 : BN;
-
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X), 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W), 0, a.w_bytes, 0x00020000);
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  // token rows, all chunks, once
-  {
-    unsigned voff[IPA];
-#pragma unroll
-    for (int q = 0; q < IPA; ++q) {
-      const int row = 8 * (wave + 4 * q) + (lane >> 3);
-      const int col = (lane & 7) ^ ((row >> 1) & 7);
-      voff[q] = (unsigned)((min(m0 + row, a.M - 1) * a.ldx + 8 * col) * (int)sizeof(T));
-    }
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-      for (int q = 0; q < IPA; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, GA_LDS_PTR(lds + c * BM * kBK + (wave_u + 4 * q) * 8 * kBK), 16,
-                                                 (int)voff[q], (int)(c * kBK * (int)sizeof(T)), 0, 0);
-  }
-  // weight slots: rows of the current column tile (GEGLU: BN/2 h rows then the BN/2 gate rows of the same columns)
-  int w_row[IPW], w_col[IPW];
-#pragma unroll
-  for (int q = 0; q < IPW; ++q) {
-    w_row[q] = 8 * (wave + 4 * q) + (lane >> 3);
-    w_col[q] = (lane & 7) ^ ((w_row[q] >> 1) & 7);
-  }
-  auto issue_w = [&](int g) {                                // ring step g = (column tile g / KC, chunk g % KC)
-    const int nt = nt0 + g / KC, ks = g - (g / KC) * KC, n0 = nt * OUTC;
-    T* slot = ring + (g % NSTAGE) * kSlot;
-#pragma unroll
-    for (int q = 0; q < IPW; ++q) {
-      int n;
-      if (GEGLU) n = w_row[q] < BN / 2 ? min(n0 + w_row[q], a.F - 1) : a.F + min(n0 + w_row[q] - BN / 2, a.F - 1);
-      else n = min(n0 + w_row[q], a.N - 1);
-      const unsigned off = (unsigned)((n * a.K + 8 * w_col[q]) * (int)sizeof(T));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, GA_LDS_PTR(slot + (wave_u + 4 * q) * 8 * kBK), 16, (int)off,
-                                               (int)(ks * kBK * (int)sizeof(T)), 0, 0);
-    }
-  };
-
-  unsigned a_adr[IM], a_sw[IM], b_adr[JN], b_sw[JN];
-  const unsigned lds0 = (unsigned)(uintptr_t)GA_LDS_PTR(lds), ring0 = (unsigned)(uintptr_t)GA_LDS_PTR(ring);
-#pragma unroll
-  for (int i = 0; i < IM; ++i) {
-    const int row = wm * WM + i * 32 + fr;
-    a_adr[i] = lds0 + row * (kBK * (int)sizeof(T));
-    a_sw[i] = (unsigned)(((row >> 1) & 7) ^ fh);
-  }
-#pragma unroll
-  for (int j = 0; j < JN; ++j) {
-    const int row = wn * WN + j * 32 + fr;
-    b_adr[j] = ring0 + row * (kBK * (int)sizeof(T));
-    b_sw[j] = (unsigned)(((row >> 1) & 7) ^ fh);
-  }
-
-  float ln_mean[IM], ln_rstd[IM];
-#pragma unroll
-  for (int i = 0; i < IM; ++i) ln_mean[i] = 0.f, ln_rstd[i] = 1.f;
-  if constexpr (LN) {
-#pragma unroll
-    for (int i = 0; i < IM; ++i) {
-      const int m = min(m0 + wm * WM + i * 32 + fr, a.M - 1);
-      float s1 = 0.f, s2 = 0.f;
-      for (int q = 0; q < a.ln_parts; ++q) {
-        const float2 v = *reinterpret_cast<const float2*>(p.ln_partials + ((size_t)m * a.ln_parts + q) * 2);
-        s1 += v.x;
-        s2 += v.y;
-      }
-      const float mean = s1 * a.ln_inv_k;
-      ln_mean[i] = mean;
-      ln_rstd[i] = rsqrtf(fmaxf(s2 * a.ln_inv_k - mean * mean, 0.f) + a.ln_eps);
-    }
-  }
-
-  f32x16 acc[JN][IM];
-#pragma unroll
-  for (int j = 0; j < JN; ++j)
-#pragma unroll
-    for (int i = 0; i < IM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-
-  constexpr int PRE = NSTAGE - 1;
-#pragma unroll
-  for (int g = 0; g < PRE; ++g)
-    if (g < total) issue_w(g);
-  int ks = 0, nt = nt0;
-  for (int g = 0; g < total; ++g) {
-    // the weight loads were issued behind the token rows: "step g's weights have landed" (in-order counter) covers them too
-    const int younger = min(total - 1 - g, PRE - 1);
-    if (younger >= 2) wait_vmcnt<2 * IPW>();
-    else if (younger == 1) wait_vmcnt<IPW>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (g + PRE < total) issue_w(g + PRE);
-    const unsigned a_off = (unsigned)(ks * BM * kBK * (int)sizeof(T)), b_off = (unsigned)((g % NSTAGE) * kSlot * (int)sizeof(T));
-    u32x4 fa[2][IM], fb[2][JN];
-    auto request = [&](int kk, int set) {
-#pragma unroll
-      for (int i = 0; i < IM; ++i) lds_read128(fa[set][i], a_adr[i] + a_off + 16u * ((2u * kk) ^ a_sw[i]));
-#pragma unroll
-      for (int j = 0; j < JN; ++j) lds_read128(fb[set][j], b_adr[j] + b_off + 16u * ((2u * kk) ^ b_sw[j]));
-    };
-    request(0, 0);
-#pragma unroll
-    for (int kk = 0; kk < kBK / 16; ++kk) {
-      if (kk + 1 < kBK / 16) {
-        request(kk + 1, (kk + 1) & 1);
-        wait_lgkmcnt<IM + JN>();
-      } else {
-        wait_lgkmcnt<0>();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < JN; ++j)
-#pragma unroll
-        for (int i = 0; i < IM; ++i)
-          acc[j][i] = Mma32L<T>::run(__builtin_bit_cast(uint4, fb[kk & 1][j]), __builtin_bit_cast(uint4, fa[kk & 1][i]), acc[j][i]);
-    }
-    if (++ks == KC) {           // the column tile is complete: out it goes (the ring keeps loading the next tile meanwhile)
-      lin_epilogue<T, BM, BN, GEGLU, LN>(acc, Cs, Y, a, p, m0, nt * OUTC, nt, ln_mean, ln_rstd);
-#pragma unroll
-      for (int j = 0; j < JN; ++j)
-#pragma unroll
-        for (int i = 0; i < IM; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-      ks = 0;
-      ++nt;
-      __syncthreads();          // the output tile is free again before the next epilogue writes it
-    }
-  }
-}
-
-template <typename T, int BM, int BN, int NSTAGE>
-int launch_stationary(const T* X, const T* W, T* Y, LinArgs a, const LinPtrs& p, int groups, hipStream_t s) {
-  const int outc = a.F ? BN / 2 : BN, n_out = a.F ? a.F : a.N;
-  const int tiles_n = (n_out + outc - 1) / outc;
-  a.tm = (a.M + BM - 1) / BM;
-  a.steps = a.K / kBK;
-  if (groups < 1) groups = 1;
-  if (groups > tiles_n) groups = tiles_n;
-  a.steps_per = (tiles_n + groups - 1) / groups;          // column tiles per workgroup
-  groups = (tiles_n + a.steps_per - 1) / a.steps_per;
-  a.splits = 1;
-  a.n_fastest = tiles_n;                                  // (field reused: total column tiles)
-  const size_t lds_bytes = sizeof(T) * ((size_t)a.steps * BM * kBK + (size_t)NSTAGE * BN * kBK + (size_t)BM * (BN + 8));
-  if (lds_bytes > kMaxLdsBytes) return GA_ERR_SHAPE;
-  const int tn_real = tiles_n;
-  LinArgs la = a;
-  la.tn = groups;                                         // lin_tile's n extent = column groups
-  const dim3 grid((unsigned)(la.tm * groups));
-  const bool ln = a.ln_parts > 0;
-  // lin_tile reads n_fastest as the ORDER flag: a run of m tiles per column group shares that group's weights in one L2
-#define GA_LIN_LAUNCH(G, L)                                                                                     \
-  do {                                                                                                          \
-    auto k = linear_stationary_kernel<T, BM, BN, NSTAGE, G, L>;                                                 \
-    if (set_dyn_lds(k, lds_bytes) != GA_OK) return GA_ERR_LAUNCH;                                               \
-    hipLaunchKernelGGL(k, grid, dim3(kThreads), lds_bytes, s, X, W, Y, la, p);                                  \
-  } while (0)
-  (void)tn_real;
-  if (a.F) {
-    if (ln) GA_LIN_LAUNCH(true, true);
-    else GA_LIN_LAUNCH(true, false);
-  } else {
-    if (ln) GA_LIN_LAUNCH(false, true);
-    else GA_LIN_LAUNCH(false, false);
-  }
-#undef GA_LIN_LAUNCH
-  return check_launch();
-}
-
 template <typename T, int BM, int BN, int NSTAGE>
 int launch_lin(const T* X, const T* W, T* Y, LinArgs a, const LinPtrs& p, hipStream_t s) {
   const int outc = a.F ? BN / 2 : BN, n_out = a.F ? a.F : a.N;
@@ -680,14 +479,6 @@ template <typename T>
 int lin_t(const void* X, const void* W, void* Y, const LinArgs& a, const LinPtrs& p, int bm, int bn, int stages, hipStream_t s) {
   const T* x = (const T*)X;
   const T* w = (const T*)W;
-  if (a.splits < 0) {   // token-stationary variant: -splits column groups per m tile; ring depth by what fits beside the rows
-    const int groups = -a.splits;
-    if (bm == 128 && bn == 128) return launch_stationary<T, 128, 128, 2>(x, w, (T*)Y, a, p, groups, s);
-    if (bm == 128 && bn == 64) return launch_stationary<T, 128, 64, 4>(x, w, (T*)Y, a, p, groups, s);
-    if (bm == 64 && bn == 128) return launch_stationary<T, 64, 128, 3>(x, w, (T*)Y, a, p, groups, s);
-    if (bm == 64 && bn == 64) return launch_stationary<T, 64, 64, 4>(x, w, (T*)Y, a, p, groups, s);
-    return GA_ERR_SHAPE;
-  }
   if (bm == 128 && bn == 128) {
     if (stages == 2) return launch_lin<T, 128, 128, 2>(x, w, (T*)Y, a, p, s);
     if (stages == 0 || stages == 3) return launch_lin<T, 128, 128, 3>(x, w, (T*)Y, a, p, s);
@@ -721,7 +512,7 @@ extern "C" int ga_linear_fused(const void* X, int64_t ldx, const void* W, void* 
                                int stages, int dtype, ga_stream_t stream) {
   if (!X || !W || !Y || !ep) return GA_ERR_NULL;
   if (M < 1 || K < kBK || K % kBK != 0 || N < 8 || N % 8 != 0 || ldx < K || ldx % 8 != 0 || ldy % 8 != 0) return GA_ERR_SHAPE;
-  if (splits == 0 || splits > 64 || splits < -1024 || K / kBK < splits || (splits > 1 && (!slabs || !tickets))) return GA_ERR_SHAPE;
+  if (splits < 1 || splits > 64 || K / kBK < splits || (splits > 1 && (!slabs || !tickets))) return GA_ERR_SHAPE;
   const int n_out = ep->geglu ? N / 2 : N;
   if (ep->geglu && (N % 16 != 0 || ep->residual)) return GA_ERR_SHAPE;
   if (ldy < n_out || (ep->residual && (ep->ld_res < n_out || ep->ld_res % 8 != 0))) return GA_ERR_SHAPE;

@@ -1225,8 +1225,6 @@ def linear_fused(x, weight, bias=None, residual=None, geglu=False, want_preact=F
         row_partials = torch.empty((M, parts, 2), dtype=torch.float32, device=x.device)
         ep.row_partials_out = row_partials.data_ptr()
     slabs = tickets = None
-    if splits < 0 and (K * bm + (4 if bn == 64 else 3 if bm == 64 else 2) * bn * 64 + bm * (bn + 8)) * 2 > 160 * 1024:
-        raise GaError(f"token-stationary plan {plan} does not fit in LDS for K={K}")
     if splits > 1:
         ws = linear_workspace(x.device)
         tiles = -(-M // bm) * parts

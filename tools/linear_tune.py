@@ -66,17 +66,6 @@ def candidates(M, K, n_out, geglu):
             if sp > 1 and sp * tiles * bm * bn > ops.LIN_SLAB_FLOATS:
                 continue
             yield (bm, bn, sp, st)
-    if K <= 640:      # token-stationary variant: the rows of an m tile stay in LDS, the workgroup walks a group of column tiles
-        for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64)):
-            ring = 4 if bn == 64 else 3 if bm == 64 else 2
-            if (K * bm + ring * bn * 64 + bm * (bn + 8)) * 2 > 160 * 1024:
-                continue
-            outc = bn // 2 if geglu else bn
-            tm, tn = -(-M // bm), -(-n_out // outc)
-            for groups in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 32, 40):
-                if groups > tn or tm * groups > 1024 or tm * groups < 64:
-                    continue
-                yield (bm, bn, -groups, 0)
 
 
 def cold(N, K, dev):
