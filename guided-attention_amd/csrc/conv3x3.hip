@@ -879,7 +879,7 @@ Plan choose_plan(int M, int N, int steps, int H, int W, int stride) {
     const double waste = (double)(tm * bm) * (double)(tn * bn) / ((double)M * (double)N);
     // tiles the patch-in-LDS kernel cannot take fall to the per-tap kernel (9 x the A-side staging): about 0.7 of the rate
     PatchGeom pg;
-    const bool patchable = stride == 1 && W >= 8 &&
+    const bool patchable = stride == 1 && W >= 16 &&
                            (patch_geometry(bm, H, W, pg) || ((bn <= 64 || bm == 128) && patch_geometry(bm, H, W, pg, true)));
     const double tile_rate = rate[ci] * (patchable ? 1.0 : 0.7);
     const int max_s = steps / 3 < 16 ? (steps / 3 < 1 ? 1 : steps / 3) : 16;
@@ -902,14 +902,6 @@ Plan choose_plan(int M, int N, int steps, int H, int W, int stride) {
 inline bool use_dma() {
   static const bool v = [] {
     const char* e = getenv("GA_CONV_DMA");
-    return e == nullptr || e[0] != '0';
-  }();
-  return v;
-}
-
-inline bool patch8() {
-  static const bool v = [] {
-    const char* e = getenv("GA_CONV_PATCH8");
     return e == nullptr || e[0] != '0';
   }();
   return v;
@@ -940,11 +932,9 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, con
   }
   dim3 grid((unsigned)(a.tm * a.tn * splits));
   PatchGeom pg;
-  // 8x8 maps: the register-staged patch kernel never took them (the halo makes the patch 100 pixels for 64 and the depth
-  // splits only by chunks); with the weights on the DMA ring the patch form wins there too — these launches are a 29.5 MB
-  // weight stream against 64 - 192 pixels — although a 32-pixel fragment block spans four 10-pixel patch rows (up to 3-way
-  // bank conflicts on the pixel reads; GA_CONV_PATCH8=0 keeps them on the per-tap kernel for A/B runs)
-  const bool geom_ok = a.pad == 1 && a.stride == 1 && (a.W >= 16 || (a.W >= 8 && use_dma() && patch8())) && !force_v1();
+  // 8x8 maps stay on the per-tap kernel: the halo makes the patch 100 pixels for 64 and the depth splits only by chunks (the
+  // DMA-ring patch form was measured there too: 15.4 vs 15.1 us at batch 1, 18.9 vs 18.9 at batch 3 — no gain, not kept)
+  const bool geom_ok = a.pad == 1 && a.stride == 1 && a.W >= 16 && !force_v1();
   const bool patch = geom_ok && patch_geometry(BM, a.H, a.W, pg);
   const bool patch_wide = geom_ok && !patch && (BN <= 64 || BM == 128) && patch_geometry(BM, a.H, a.W, pg, true);
   if (patch_wide) {   // the 13-piece instantiation: one row of a 128-wide map, or a run of a 96- / 48-wide map (geometry 3)

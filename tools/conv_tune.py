@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Per-shape time of the UNet's 3x3 convolutions: the library (MIOpen, benchmark mode, channels-last fp16) against
 ga_conv3x3_nhwc for every (tile, split-K) plan — forward; the stride-1 backward-to-input is the same kernel with
-Cin / Cout swapped, listed as its own shape.  hipGraph replay timing.  Prints a table and a JSON line."""
+Cin / Cout swapped, listed as its own shape.  hipGraph replay timing.  Prints a table and a JSON line.
+
+  conv_tune.py [batches, default 1,3] [cold] [--write] [variants [all]]
+     cold    : own-kernel launches rotate over enough packed-weight copies to exceed the 256 MB Infinity Cache — in the
+               pipeline a convolution's weights are cold (1.7 GB of UNet weights stream through between two uses) while its
+               input was just written; warm timings favour plans with too few bytes in flight per CU
+     --write : update guided-attention_amd/conv_plans.json {"M,Cin,Cout,stride": [bm, bn, splits]} with the best plans"""
 import json
 import sys
 from pathlib import Path
@@ -80,7 +86,7 @@ def variant_times(lib, x, w, co, st, plans):
 
 
 def main():
-    batches = [int(b) for b in (sys.argv[1] if len(sys.argv) > 1 else "1,3").split(",")]
+    batches = [int(b) for b in (sys.argv[1] if len(sys.argv) > 1 and sys.argv[1][0].isdigit() else "1,3").split(",")]
     vdir = Path(__file__).resolve().parent / "micro" / "sa_variants"
     variants = {p.stem[3:]: bind(p) for p in sorted(vdir.glob("libconv_*.so"))} if "variants" in sys.argv else {}
     table = {}
@@ -93,6 +99,13 @@ def main():
             flop = 2.0 * B * ho * ho * co * ci * 9
             t_lib = replay_us(lambda: F.conv2d(x, w, None, stride=st, padding=1))
             wp = ops.conv3x3_packed_weights(w, False)
+            n_copies = max(1, min(48, -(-320 * 2 ** 20 // (9 * co * ci * 2)))) if "cold" in sys.argv else 1
+            wps = [wp] + [wp.clone() for _ in range(n_copies - 1)]
+            turn = [0]
+
+            def nxt():
+                turn[0] += 1
+                return wps[turn[0] % n_copies]
             steps = 9 * ci // 64
             res = {}
             for bm, bn in ((128, 128), (128, 64), (64, 64)):
@@ -105,7 +118,7 @@ def main():
                     if sp > 1 and sp * tiles * bm * bn > ops.LIN_SLAB_FLOATS:
                         continue
                     plan = (bm, bn, sp, 0)
-                    res[(bm, bn, sp)] = replay_us(lambda: ops.conv3x3_nhwc(x, wp, co, st, None, None, plan=plan), iters=10)
+                    res[(bm, bn, sp)] = replay_us(lambda: ops.conv3x3_nhwc(x, nxt(), co, st, None, None, plan=plan), iters=max(10, min(n_copies, 40)))
             best = min(res, key=res.get)
             extra = ""
             for vname, vlib in variants.items():
@@ -119,6 +132,14 @@ def main():
             table[f"{B},{ci},{co},{h},{st}"] = {"lib_us": round(t_lib, 1), "best": list(best), "best_us": round(res[best], 1),
                                                 "all": {f"{k[0]}x{k[1]}x{k[2]}": round(v, 1) for k, v in res.items()}}
     print(json.dumps(table))
+    if "--write" in sys.argv:
+        path = Path(__file__).resolve().parent.parent / "guided-attention_amd" / "conv_plans.json"
+        plans = json.loads(path.read_text()) if path.exists() else {}
+        for key, row in table.items():
+            B, ci, co, h, st = (int(v) for v in key.split(","))
+            ho = (h - 1) // st + 1
+            plans[f"{B * ho * ho},{ci},{co},{st}"] = row["best"]
+        path.write_text(json.dumps(plans, indent=0, sort_keys=True))
 
 
 if __name__ == "__main__":
