@@ -66,7 +66,7 @@ PROTOTYPES = {
     "ga_cfg_ddim_step": [_vp, _vp, _f, _vp, _f, _f, _vp, _vp, _i64, _i, _vp],
     "ga_self_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ga_self_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
-    "ga_group_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ga_group_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ga_group_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ga_geglu_fwd": [_vp, _vp, _i64, _i, _i, _vp],
     "ga_geglu_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],

@@ -13,8 +13,6 @@
 // Backward recomputes the normalised value and the SiLU derivative, reduces (sum dyhat, sum dyhat*yhat) the same
 // way and writes dx; gamma/beta gradients are not produced (the UNet weights are frozen on this path).
 // HBM-bound: forward moves 2 reads + 1 write of the tensor (the second read hits L2/MALL at these sizes).
-#include <cstdlib>
-
 #include "attn_common.h"
 
 using namespace ga;
@@ -114,9 +112,7 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict_
 // workgroup also stores the results (the forward's (mean, rstd) that the backward reads).
 constexpr int kMaxStatsNB = 128;
 
-// SC1: the partials were written by OTHER workgroups of this launch (write-through stores): every load of them bypasses this
-// CU's L1 (8-byte agent-scope relaxed atomic loads = global_load_dwordx2 sc1).
-template <bool FWD, bool SC1 = false>
+template <bool FWD>
 __device__ __forceinline__ void fold_partials(const float* __restrict__ partial, int b, int NB, int G, float inv_n,
                                               float eps, float2* res, float* keep) {
   const float2* pp = reinterpret_cast<const float2*>(partial) + (size_t)b * NB * G;
@@ -126,17 +122,7 @@ __device__ __forceinline__ void fold_partials(const float* __restrict__ partial,
 #pragma unroll
     for (int i = 0; i < kMaxStatsNB / 8; ++i) {
       const int nb = part + 8 * i;
-      if (g < G && nb < NB) {
-        if constexpr (SC1) {
-          const unsigned long long raw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(pp + (size_t)nb * G + g),
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          v[i] = float2{__uint_as_float((unsigned)raw), __uint_as_float((unsigned)(raw >> 32))};
-        } else {
-          v[i] = pp[(size_t)nb * G + g];
-        }
-      } else {
-        v[i] = float2{0.f, 0.f};
-      }
+      v[i] = (g < G && nb < NB) ? pp[(size_t)nb * G + g] : float2{0.f, 0.f};
     }
     float sa = 0.f, sc = 0.f;
 #pragma unroll
@@ -513,139 +499,6 @@ __global__ __launch_bounds__(kThreads) void gn_wide_apply_kernel(const T* __rest
 #pragma unroll
     for (int u = 0; u < kU; ++u)
       if (pn + u * m.RP < p1) v[u] = xb[(size_t)(pn + u * m.RP) * m.VP];
-  }
-}
-
-// ---- ONE launch for the wide forward: statistics and apply of the two kernels above with the pixel block kept in
-// registers across a hand-made rendezvous of the image's workgroups.  Round 2's GroupNorm was two dependent launches that
-// each read the tensor (1.59 x the algorithmic bytes, 4.5 + 6 ... 9 us); here a workgroup loads its block once, publishes
-// its per-group partial sums write-through (8-byte agent-scope stores), drains, and one lane adds 1 to the image's ARRIVE
-// counter and polls it (relaxed sc1 loads, s_sleep between polls, bounded) until all NB blocks of the image are in; the
-// partials are then folded with sc1 loads — in the same fixed order as before, so every workgroup derives the same (mean,
-// rstd) bits — and the block is normalised from its registers.  A DEPART counter tells the last workgroup out to return
-// both words to zero (every workgroup has passed its poll by then), so launches need no memset between them.
-// Residency: the grid is NB x B <= 3 x 128 workgroups of 256 threads and ~100 VGPRs — at least four such workgroups fit on
-// each of the 256 CUs, so all of them are resident whatever the dispatch order (the rendezvous never waits for a workgroup
-// that cannot start).  Taken only when a workgroup's block fits one batch of kUF loads per lane; otherwise the two launches.
-constexpr int kUF = 16;
-constexpr unsigned kGnSpinLimit = 1u << 22;   // ~4 s of polling: far beyond any legitimate wait; then go on (wrong output) rather than hang
-
-template <typename T, bool ACT>
-__global__ __launch_bounds__(kThreads) void gn_wide_fused_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
-                                                                 const T* __restrict__ gamma, const T* __restrict__ beta,
-                                                                 T* __restrict__ y, float* __restrict__ partial,
-                                                                 unsigned* __restrict__ counters, float inv_n, float eps,
-                                                                 float* __restrict__ stats, int HW, int C, int G, int PB) {
-  __shared__ float4 lds4[kThreads];
-  __shared__ float2 res[64];
-  const WideMap m(C, G);
-  const int b = blockIdx.y, nb = blockIdx.x, NB = gridDim.x, p0 = nb * PB, p1 = min(HW, p0 + PB);
-  const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
-  Vec8<T>* yb = reinterpret_cast<Vec8<T>*>(y + (size_t)b * HW * C) + m.vec;
-  Vec8<T> v[kUF];
-  float cb[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) cb[j] = 0.f;
-  const int p = p0 + m.pr;
-  float c0[8], c1[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) c0[j] = c1[j] = 0.f;
-  if (m.active) {
-#pragma unroll
-    for (int u = 0; u < kUF; ++u)
-      if (p + u * m.RP < p1) v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
-    if (cbias != nullptr) {
-      const Vec8<T> bv = reinterpret_cast<const Vec8<T>*>(cbias + (size_t)b * C)[m.vec];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) cb[j] = Traits<T>::to_f32(bv.v[j]);
-    }
-#pragma unroll
-    for (int u = 0; u < kUF; ++u)
-      if (p + u * m.RP < p1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float a = Traits<T>::to_f32(v[u].v[j]) + cb[j];
-          c0[j] += a;
-          c1[j] += a * a;
-        }
-      }
-  }
-  // per-group partial sums of this block -> partial[b][nb][G] as 8-byte write-through stores
-  {
-    float4 r = {0.f, 0.f, 0.f, 0.f};
-    if (m.active) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (j < m.split) {
-          r.x += c0[j];
-          r.y += c1[j];
-        } else {
-          r.z += c0[j];
-          r.w += c1[j];
-        }
-      }
-    }
-    lds4[threadIdx.x] = r;
-    __syncthreads();
-    const int cg = C / G;
-    unsigned long long* out = reinterpret_cast<unsigned long long*>(partial + ((size_t)b * NB + nb) * G * 2);
-    for (int g = threadIdx.x; g < G; g += kThreads) {
-      const int vlo = (g * cg) >> 3, vhi = ((g + 1) * cg - 1) >> 3;
-      float a = 0.f, bb = 0.f;
-      for (int vv = vlo; vv <= vhi; ++vv) {
-        const bool first = (vv * 8) / cg == g;
-        for (int pr = 0; pr < m.RP; ++pr) {
-          const float4 e = lds4[pr * m.VP + vv];
-          a += first ? e.x : e.z;
-          bb += first ? e.y : e.w;
-        }
-      }
-      __hip_atomic_store(out + g, ((unsigned long long)__float_as_uint(bb) << 32) | __float_as_uint(a), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
-  __syncthreads();
-  unsigned* arrive = counters + 2 * b;
-  unsigned* depart = arrive + 1;
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)NB && ++spins < kGnSpinLimit)
-      __builtin_amdgcn_s_sleep(2);
-  }
-  __syncthreads();
-  fold_partials<true, true>(partial, b, NB, G, inv_n, eps, res, nb == 0 ? stats : nullptr);
-  if (m.active) {
-    const float* mr = reinterpret_cast<const float*>(res);
-    float sc[8], sh[8];
-    const Vec8<T> gm = reinterpret_cast<const Vec8<T>*>(gamma)[m.vec], bt = reinterpret_cast<const Vec8<T>*>(beta)[m.vec];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int g = j < m.split ? m.gA : m.gA + 1;
-      sc[j] = Traits<T>::to_f32(gm.v[j]) * mr[2 * g + 1];
-      sh[j] = Traits<T>::to_f32(bt.v[j]) - (mr[2 * g] - cb[j]) * sc[j];  // (x + cb - mean) * scale + beta
-    }
-#pragma unroll
-    for (int u = 0; u < kUF; ++u)
-      if (p + u * m.RP < p1) {
-        Vec8<T> o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float z = Traits<T>::to_f32(v[u].v[j]) * sc[j] + sh[j];
-          if (ACT) z *= sigmoidf_(z);
-          o.v[j] = Traits<T>::from_f32(z);
-        }
-        yb[(size_t)(p + u * m.RP) * m.VP] = o;
-      }
-  }
-  // last one out returns the image's two counter words to zero (everyone has passed the poll above by then)
-  if (threadIdx.x == 0) {
-    const unsigned d = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d == (unsigned)NB - 1) {
-      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
 }
 
@@ -1038,14 +891,6 @@ int launch_bwd_t(const void* x, const void* cbias, const void* dy, const void* g
   }
 
 // wide path: geometry and launches
-constexpr int kMaxFusedImages = 32;   // counter words of the one-launch forward: 2 per image (ga_hip.h)
-inline bool gn_fused_enabled() {      // GA_GN_FUSED=0: always the two-launch form (A/B runs)
-  static const bool v = [] {
-    const char* e = getenv("GA_GN_FUSED");
-    return e == nullptr || e[0] != '0';
-  }();
-  return v;
-}
 inline bool wide_ok(int C, int G, size_t elem) { return elem == 2 && C % 8 == 0 && C / G >= 8 && C <= 8 * kThreads; }
 
 struct WideGeom {
@@ -1062,22 +907,9 @@ struct WideGeom {
 
 template <typename T>
 int wide_fwd(const void* x, const void* cbias, const void* gamma, const void* beta, void* y, float* stats, float* ws,
-             unsigned* counters, int B, int HW, int C, int G, float eps, int act, hipStream_t s) {
+             int B, int HW, int C, int G, float eps, int act, hipStream_t s) {
   const WideGeom g(HW, C);
   const float inv_n = 1.0f / ((float)HW * (float)(C / G));
-  {  // one launch when a workgroup's block fits one batch of loads (it stays in registers across the rendezvous)
-    const int RP = kThreads / (C / 8);
-    const int PB = g.PBs;
-    if (counters != nullptr && PB <= kUF * RP && g.NB <= kMaxStatsNB && B <= kMaxFusedImages && gn_fused_enabled()) {
-      if (act)
-        hipLaunchKernelGGL((gn_wide_fused_kernel<T, true>), dim3(g.NB, B), dim3(kThreads), 0, s, (const T*)x, (const T*)cbias,
-                           (const T*)gamma, (const T*)beta, (T*)y, ws, counters, inv_n, eps, stats, HW, C, G, PB);
-      else
-        hipLaunchKernelGGL((gn_wide_fused_kernel<T, false>), dim3(g.NB, B), dim3(kThreads), 0, s, (const T*)x, (const T*)cbias,
-                           (const T*)gamma, (const T*)beta, (T*)y, ws, counters, inv_n, eps, stats, HW, C, G, PB);
-      return check_launch();
-    }
-  }
   hipLaunchKernelGGL(gn_wide_stats_kernel<T>, dim3(g.NB, B), dim3(kThreads), 0, s, (const T*)x, (const T*)cbias, ws, HW,
                      C, G, g.PBs);
   if (act)
@@ -1114,10 +946,10 @@ int wide_bwd(const void* x, const void* cbias, const void* dy, const void* gamma
 }
 
 template <typename T>
-int fwd_dtype(const void* x, const void* cbias, const void* gamma, const void* beta, void* y, float* stats, float* ws,
-              unsigned* counters, int B, int HW, int C, int G, float eps, int act, const Geom& g, hipStream_t s) {
+int fwd_dtype(const void* x, const void* cbias, const void* gamma, const void* beta, void* y, float* stats, float* ws, int B,
+              int HW, int C, int G, float eps, int act, const Geom& g, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
-    if (wide_ok(C, G, sizeof(T))) return wide_fwd<T>(x, cbias, gamma, beta, y, stats, ws, counters, B, HW, C, G, eps, act, s);
+    if (wide_ok(C, G, sizeof(T))) return wide_fwd<T>(x, cbias, gamma, beta, y, stats, ws, B, HW, C, G, eps, act, s);
   }
   if (act) {
     GA_GN_NPT(launch_fwd_t, T, true, x, cbias, gamma, beta, y, stats, ws, B, HW, C, G, eps, g, s)
@@ -1140,8 +972,8 @@ int bwd_dtype(const void* x, const void* cbias, const void* dy, const void* gamm
 }  // namespace
 
 extern "C" int ga_group_norm_fwd(const void* x, const void* chan_bias, const void* gamma, const void* beta, void* y,
-                                 float* stats, float* workspace, unsigned* counters, int B, int HW, int C, int G, float eps,
-                                 int act_silu, int dtype, ga_stream_t stream) {
+                                 float* stats, float* workspace, int B, int HW, int C, int G, float eps, int act_silu,
+                                 int dtype, ga_stream_t stream) {
   if (!x || !gamma || !beta || !y || !stats || !workspace) return GA_ERR_NULL;
   Geom g;
   int rc = geometry(B, HW, C, G, g);
@@ -1156,9 +988,9 @@ extern "C" int ga_group_norm_fwd(const void* x, const void* chan_bias, const voi
     }
   }
   switch (dtype) {
-    case GA_F16: return fwd_dtype<_Float16>(x, chan_bias, gamma, beta, y, stats, workspace, counters, B, HW, C, G, eps, act_silu, g, s);
-    case GA_BF16: return fwd_dtype<bf16_t>(x, chan_bias, gamma, beta, y, stats, workspace, counters, B, HW, C, G, eps, act_silu, g, s);
-    case GA_F32: return fwd_dtype<float>(x, chan_bias, gamma, beta, y, stats, workspace, counters, B, HW, C, G, eps, act_silu, g, s);
+    case GA_F16: return fwd_dtype<_Float16>(x, chan_bias, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
+    case GA_BF16: return fwd_dtype<bf16_t>(x, chan_bias, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
+    case GA_F32: return fwd_dtype<float>(x, chan_bias, gamma, beta, y, stats, workspace, B, HW, C, G, eps, act_silu, g, s);
     default: return GA_ERR_DTYPE;
   }
 }

@@ -188,12 +188,11 @@ def replay_launch_us(key, iters=100):
         stats = torch.empty(B, groups, 2, device=dev, dtype=torch.float32)
         ws = torch.empty(B * 257 * groups * 2, device=dev, dtype=torch.float32)
         code = dtype_code(x)
-        cnt = gn_counters(dev)
-        check(lib.ga_group_norm_fwd(_ptr(x), None, _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(ws), _ptr(cnt), B, HW, C, groups,
+        check(lib.ga_group_norm_fwd(_ptr(x), None, _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(ws), B, HW, C, groups,
                                     1e-5, int(flag), code, stream_ptr()), "replay gn")
         if kind == "group_norm_fwd":
             def fn():
-                check(lib.ga_group_norm_fwd(_ptr(x), None, _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(ws), _ptr(cnt), B, HW, C,
+                check(lib.ga_group_norm_fwd(_ptr(x), None, _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(ws), B, HW, C,
                                             groups, 1e-5, int(flag), code, stream_ptr()), "replay gn fwd")
         else:
             def fn():
@@ -693,8 +692,8 @@ class GroupNormAct(torch.autograd.Function):
         ws = torch.empty((B * 257 * groups * 2,), dtype=torch.float32, device=x.device)
         _count(("group_norm_fwd", B, groups, H * W, 0, C, bool(act), str(x.dtype)))
         check(load().ga_group_norm_fwd(_ptr(x), _ptr(chan_bias), _ptr(weight), _ptr(bias), _ptr(y), _ptr(stats), _ptr(ws),
-                                       _ptr(gn_counters(x.device) if B <= 32 else None), B, H * W, C, groups, float(eps),
-                                       int(bool(act)), dtype_code(x), stream_ptr()), "ga_group_norm_fwd")
+                                       B, H * W, C, groups, float(eps), int(bool(act)), dtype_code(x), stream_ptr()),
+              "ga_group_norm_fwd")
         ctx.save_for_backward(x, weight, bias, stats, chan_bias)
         ctx.meta = (groups, bool(act))
         return y
@@ -1118,19 +1117,6 @@ def splitk_workspace(device, M, N, bm, bn, splits):
     return ws["slabs"], ws["tickets"]
 
 
-_gn_cnt = {}
-
-
-def gn_counters(device):
-    """The arrive / depart words of the one-launch GroupNorm forward (2 per image, zero between launches)."""
-    t = _gn_cnt.get(device.index)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise GaError("the GroupNorm counters must exist before a hipGraph capture (call ops.prepare_device first)")
-        t = _gn_cnt[device.index] = torch.zeros(64, dtype=torch.int32, device=device)
-    return t
-
-
 def prepare_device(device):
     """Allocate the persistent per-device scratch of the kernels (split-K slabs, arrival tickets) — once, before any
     hipGraph capture, so that captured launches and eager launches share the same, never-moving buffers."""
@@ -1140,7 +1126,6 @@ def prepare_device(device):
             device = torch.device("cuda", torch.cuda.current_device())
         linear_workspace(device)
         _ticket(device)
-        gn_counters(device)
 
 
 def _measured_linear_plans():

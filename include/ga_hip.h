@@ -217,14 +217,10 @@ int ga_self_attn_bwd(const void* Q, const void* K, const void* V, const void* O,
  *   C <= 2560.  chan_bias (optional, [B][C] T): the layer normalises x + chan_bias[b][c] — the ResnetBlock's
  *   time-embedding term folded into the norm instead of a separate broadcast-add pass; it receives no gradient.
  *   gamma/beta gradients are not produced (weights are frozen on this path).
- *   counters (forward, optional): 2 * B 32-bit words (B <= 32), ZERO on entry, left zero — with them the large-level forward
- *   is ONE launch: a workgroup keeps its pixel block in registers, publishes its partial sums, the image's workgroups
- *   rendezvous on counters[2 b] (bounded poll) and normalise from registers; NULL keeps the two launches.  Launches sharing
- *   the words must be stream-ordered.
  */
 #define GA_GN_WORKSPACE_FLOATS(B, G) ((B) * 257 * (G) * 2)
 int ga_group_norm_fwd(const void* x, const void* chan_bias, const void* gamma, const void* beta, void* y, float* stats,
-                      float* workspace, unsigned* counters, int B, int HW, int C, int G, float eps, int act_silu, int dtype,
+                      float* workspace, int B, int HW, int C, int G, float eps, int act_silu, int dtype,
                       ga_stream_t stream);
 int ga_group_norm_bwd(const void* x, const void* chan_bias, const void* dy, const void* gamma, const void* beta,
                       const float* stats, void* dx, float* workspace, int B, int HW, int C, int G, int act_silu,

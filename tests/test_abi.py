@@ -106,7 +106,7 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.ga_add_layer_norm_fwd(None, None, None, None, None, None, None, 4, 16, 1e-5, 0, None) == -1
     assert lib.ga_add_layer_norm_bwd(None, None, None, None, None, None, 4, 16, 0, None) == -1
     assert lib.ga_self_attn_fwd(None, None, None, None, None, 1, 8, 64, 40, 0, 0.1, 0, None) == -1
-    assert lib.ga_group_norm_fwd(None, None, None, None, None, None, None, None, 1, 64, 320, 32, 1e-5, 1, 0, None) == -1
+    assert lib.ga_group_norm_fwd(None, None, None, None, None, None, None, 1, 64, 320, 32, 1e-5, 1, 0, None) == -1
     # shape / dtype / alignment errors are told apart (host-side checks on fake, never dereferenced pointers)
     p = ctypes.c_void_p(4096)
     assert lib.ga_geglu_fwd(p, p, 4, 12, 0, None) == -2          # F = 12 fp16 is not a whole 16-byte vector
