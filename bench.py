@@ -56,6 +56,8 @@ def parse(argv=None):
     ap.add_argument("--two-pass-steps", type=int, default=1,
                     help="after the timed region, also time this many images with the two-pass form of the loss-only "
                          "steps and report it beside the headline (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the per-shape micro-replays behind `roofline` (profiling runs: nothing but images in the trace)")
     ap.add_argument("--launch-timeout", type=float, default=3300.0,
                     help="self-launched ranks (--gpus N run directly) are terminated after this many seconds")
     ap.add_argument("--launch-check", action="store_true",
@@ -528,7 +530,7 @@ def main(argv=None):
         pipe.batch_loss_only_guidance = True
     if rank == 0:
         n_images = args.steps * world
-        roof = roofline_entry(census, ops, args.model)
+        roof = None if args.no_roofline else roofline_entry(census, ops, args.model)
         flops_per_fwd = {"sd15": 0.803e12, "sd21": 2.149e12}.get(args.model)
         names = {"sd21": ("guided images/sec (50-step SD-2.1 768^2)", "SD-2.1 UNet 768^2 (latent 96^2)"),
                  "sdxl": ("guided images/sec (50-step SDXL-base 1024^2)", "SDXL-base UNet 1024^2 (latent 128^2)"),
