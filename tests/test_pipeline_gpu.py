@@ -139,6 +139,8 @@ def test_half_precision_pipeline_vs_oracle(dt, tol):
     out, _ = run_product(pipe, meta, embeds, lat0, noise, thr)
     assert out.unet_calls["fwd_b1_grad"] == s.calls["fwd_b1_grad"] and out.unet_calls["bwd"] == s.calls["bwd"]
     err = np.abs(out.latents.float().cpu().numpy() - ref).max() / np.abs(ref).max()
+    rms = float(np.sqrt(np.mean((out.latents.float().cpu().numpy() - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
+    print(f"[measured] half-precision pipeline {dt}: latents max-rel {err:.3e} rms-rel {rms:.3e}")
     assert err < tol, err
 
 
@@ -441,7 +443,10 @@ def test_sdxl_layout_one_guidance_step(dt, tol_maps, tol_grad):
     assert np.abs(A.detach().cpu().numpy() - A_ref.detach().numpy()).max() < tol_maps * A_ref.max().item()
     np.testing.assert_allclose(loss.item(), float(r["loss"]), rtol=1e-4 if dt == "f32" else 3e-2)
     err = (g_hip.float().cpu() - g_ref).abs().max().item() / g_ref.abs().max().item()
-    assert err < tol_grad, err
+    cos = float((g_hip.float().cpu() * g_ref).sum() / (g_hip.float().cpu().norm() * g_ref.norm()))
+    print(f"[measured] sdxl layout {dt}: maps {np.abs(A.detach().cpu().numpy() - A_ref.detach().numpy()).max() / A_ref.max().item():.3e} "
+          f"loss {abs(loss.item() - float(r['loss'])) / abs(float(r['loss'])):.3e} grad max-rel {err:.3e} cosine {cos:.5f}")
+    assert err < tol_grad and cos > (0.9999 if dt == "f32" else 0.97), (err, cos)
 
 
 def test_paint_with_words_pipeline_vs_oracle():
