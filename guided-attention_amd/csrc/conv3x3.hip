@@ -648,8 +648,12 @@ __device__ __forceinline__ void conv_wait_lgkmcnt() {
 #endif
 }
 
-template <typename T, int BM, int BN, bool OUT_F32, bool WIDE = false>
-__global__ __launch_bounds__(kThreads, WIDE ? 1 : 2) void conv3x3_patch_dma_kernel(
+// DEEP: twice the ring (64 KB of weight slots, one workgroup per CU) for the WEIGHT-BOUND launches — the 16 x 16 and 8 x 8
+// levels, where a launch is a 15 - 59 MB weight stream against <= 1024 pixels.  A plan there puts about one workgroup on each CU;
+// with the 32 KB ring that is 24 KB of weights in flight per CU, and the stream ran at 1.3 - 1.8 TB/s (bytes in flight / memory
+// latency under load, not the MFMAs, set the time: 29.5 MB took 16.8 - 22.4 us cold).
+template <typename T, int BM, int BN, bool OUT_F32, bool WIDE = false, bool DEEP = false>
+__global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_dma_kernel(
     const T* __restrict__ X, const T* __restrict__ Wp, T* __restrict__ Y, float* __restrict__ part,
     unsigned* __restrict__ tickets, const T* __restrict__ bias, const T* __restrict__ residual, ConvArgs a) {
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(kThreads, WIDE ? 1 : 2) void conv3x3_patch_dma_kern
   constexpr int kPatchRows = kPatchPieces * RPP;
   constexpr int kPatch = kPatchRows * kLD;                 // elements of the patch buffer (padded rows)
   constexpr int kSlot = BN * kKC;                          // elements of one weight ring slot (128-byte rows, swizzled)
-  constexpr int NW = BN <= 64 ? 4 : 2;                     // ring slots: 32 KB either way (two workgroups per CU)
+  constexpr int NW = (BN <= 64 ? 4 : 2) * (DEEP ? 2 : 1);  // ring slots: 32 KB (two workgroups per CU), DEEP: 64 KB
   constexpr int PD = NW - 1;                               // steps in flight
   constexpr int IPW = BN / 32;                             // LDS-DMA wave-instructions per slot and wave
   constexpr int kCtile = BM * (BN + 8);
@@ -879,7 +883,7 @@ Plan choose_plan(int M, int N, int steps, int H, int W, int stride) {
     const double waste = (double)(tm * bm) * (double)(tn * bn) / ((double)M * (double)N);
     // tiles the patch-in-LDS kernel cannot take fall to the per-tap kernel (9 x the A-side staging): about 0.7 of the rate
     PatchGeom pg;
-    const bool patchable = stride == 1 && W >= 16 &&
+    const bool patchable = stride == 1 && W >= 8 &&
                            (patch_geometry(bm, H, W, pg) || ((bn <= 64 || bm == 128) && patch_geometry(bm, H, W, pg, true)));
     const double tile_rate = rate[ci] * (patchable ? 1.0 : 0.7);
     const int max_s = steps / 3 < 16 ? (steps / 3 < 1 ? 1 : steps / 3) : 16;
@@ -902,6 +906,15 @@ Plan choose_plan(int M, int N, int steps, int H, int W, int stride) {
 inline bool use_dma() {
   static const bool v = [] {
     const char* e = getenv("GA_CONV_DMA");
+    return e == nullptr || e[0] != '0';
+  }();
+  return v;
+}
+
+// GA_CONV_DEEP=0: never the 64 KB weight ring (A/B runs)
+inline bool deep_ring() {
+  static const bool v = [] {
+    const char* e = getenv("GA_CONV_DEEP");
     return e == nullptr || e[0] != '0';
   }();
   return v;
@@ -932,9 +945,10 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, con
   }
   dim3 grid((unsigned)(a.tm * a.tn * splits));
   PatchGeom pg;
-  // 8x8 maps stay on the per-tap kernel: the halo makes the patch 100 pixels for 64 and the depth splits only by chunks (the
-  // DMA-ring patch form was measured there too: 15.4 vs 15.1 us at batch 1, 18.9 vs 18.9 at batch 3 — no gain, not kept)
-  const bool geom_ok = a.pad == 1 && a.stride == 1 && a.W >= 16 && !force_v1();
+  // 8x8 maps: the register-staged patch kernel never took them (the halo makes the patch 100 pixels for 64, the depth splits
+  // only by chunks), and the 32 KB DMA ring measured the same as the per-tap kernel (15.4 vs 15.1 us): these launches are a
+  // 29.5 - 59 MB weight stream — what they need is bytes in flight, i.e. the DEEP ring below
+  const bool geom_ok = a.pad == 1 && a.stride == 1 && (a.W >= 16 || (a.W >= 8 && use_dma() && deep_ring())) && !force_v1();
   const bool patch = geom_ok && patch_geometry(BM, a.H, a.W, pg);
   const bool patch_wide = geom_ok && !patch && (BN <= 64 || BM == 128) && patch_geometry(BM, a.H, a.W, pg, true);
   if (patch_wide) {   // the 13-piece instantiation: one row of a 128-wide map, or a run of a 96- / 48-wide map (geometry 3)
@@ -962,12 +976,22 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, con
     a.lane_rot = a.W == 16 ? 2 : 0;
   }
   if (patch && use_dma()) {
-    if (splits == 1)
+    // weight-bound launch (few pixels against tens of MB of weights) with about one workgroup per CU: the deep ring
+    const bool deep = a.M <= 1024 && (long long)a.tm * a.tn * splits <= 384 && deep_ring();
+    if (deep) {
+      if (splits == 1)
+        hipLaunchKernelGGL((conv3x3_patch_dma_kernel<T, BM, BN, false, false, true>), grid, dim3(kThreads), 0, s, X, Wp, Y,
+                           (float*)nullptr, (unsigned*)nullptr, bias, residual, a);
+      else
+        hipLaunchKernelGGL((conv3x3_patch_dma_kernel<T, BM, BN, true, false, true>), grid, dim3(kThreads), 0, s, X, Wp, Y, ws,
+                           tickets, bias, residual, a);
+    } else if (splits == 1) {
       hipLaunchKernelGGL((conv3x3_patch_dma_kernel<T, BM, BN, false>), grid, dim3(kThreads), 0, s, X, Wp, Y, (float*)nullptr,
                          (unsigned*)nullptr, bias, residual, a);
-    else
+    } else {
       hipLaunchKernelGGL((conv3x3_patch_dma_kernel<T, BM, BN, true>), grid, dim3(kThreads), 0, s, X, Wp, Y, ws, tickets, bias,
                          residual, a);
+    }
     return check_launch();
   }
   if (splits == 1) {

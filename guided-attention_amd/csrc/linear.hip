@@ -241,7 +241,7 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
 
 // GEGLU: BN columns of the tile = BN/2 h features followed by the BN/2 gate features of the same output columns
 template <typename T, int BM, int BN, int NSTAGE, bool GEGLU, bool LN>
-__global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 64 * 1024 ? 2 : 1) void linear_kernel(
+__global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 80 * 1024 ? 2 : 1) void linear_kernel(
     const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ Y, LinArgs a, LinPtrs p) {
   constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, JN = WN / 32;
   constexpr int kStage = (BM + BN) * kBK;                  // elements per ring slot
@@ -344,7 +344,8 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 64 * 1024 ? 2
   for (int it = 0; it < nsteps; ++it) {
     // my loads of step `it` have landed when at most the younger steps' instructions are outstanding
     const int younger = min(nsteps - 1 - it, PRE - 1);
-    if (younger >= 2) wait_vmcnt<2 * IPS>();
+    if (younger >= 3) wait_vmcnt<3 * IPS>();
+    else if (younger == 2) wait_vmcnt<2 * IPS>();
     else if (younger == 1) wait_vmcnt<IPS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's part of step `it` is in LDS; everyone is done reading step it - 1
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 64 * 1024 ? 2
           acc[j][i] = Mma32L<T>::run(__builtin_bit_cast(uint4, fb[kk & 1][j]), __builtin_bit_cast(uint4, fa[kk & 1][i]), acc[j][i]);
     }
   }
-  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "the counted waits above cover up to three k-steps in flight");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 5, "the counted waits above cover up to four k-steps in flight");
   wait_lgkmcnt<0>();
   __builtin_amdgcn_s_barrier();   // every wave's fragment reads are done: the ring memory is free for the epilogue
 
@@ -488,6 +489,7 @@ int lin_t(const void* X, const void* W, void* Y, const LinArgs& a, const LinPtrs
     if (stages == 0 || stages == 4)
       return tall ? launch_lin<T, 128, 64, 4>(x, w, (T*)Y, a, p, s) : launch_lin<T, 64, 128, 4>(x, w, (T*)Y, a, p, s);
   } else if (bm == 64 && bn == 64) {
+    if (stages == 5) return launch_lin<T, 64, 64, 5>(x, w, (T*)Y, a, p, s);   // K = 320: the whole depth in flight, 2 x 80 KB per CU
     if (stages == 0 || stages == 4) return launch_lin<T, 64, 64, 4>(x, w, (T*)Y, a, p, s);
   }
   return GA_ERR_SHAPE;

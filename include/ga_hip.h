@@ -303,7 +303,7 @@ int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspace, unsigned
  * (bitwise reproducible) and runs the epilogue — one launch.  ga_linear_workspace gives the sizes: `slabs` f32
  * [slab_floats], `tickets` [tiles] 32-bit words that are ZERO on entry (the kernel leaves them zero); launches that
  * share them must be stream-ordered.  `stages` = k-steps of the LDS ring (0: the tile's default; 128x128: 2 or 3,
- * 128x64 / 64x128: 3 or 4, 64x64: 4): shallow rings fit two workgroups per CU.  K % 64 == 0, N % 8 == 0, 16-bit dtypes. */
+ * 128x64 / 64x128: 3 or 4, 64x64: 4 or 5): shallow rings fit two workgroups per CU.  K % 64 == 0, N % 8 == 0, 16-bit dtypes. */
 typedef struct {
   const void* bias;
   const void* residual;

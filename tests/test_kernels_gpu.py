@@ -887,11 +887,11 @@ def test_linear_fused(ops, shape, dt):
     ref_plain = xd @ wd.T + bd
     tol = TOL[dt] * 2
     steps = K // 64
-    for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64)):
+    for bm, bn, stages in ((128, 128, 0), (128, 128, 2), (128, 64, 0), (128, 64, 3), (64, 128, 0), (64, 64, 0), (64, 64, 5)):
         for splits in (1, 2, 5):
             if steps // splits < 1:
                 continue
-            plan = (bm, bn, splits)
+            plan = (bm, bn, splits, stages)
             y = ops.linear_fused(x, w, bias, plan=plan)["y"]
             close(y, ref_plain.numpy(), tol, f"bias {plan}")
             y = ops.linear_fused(x, w, bias, residual=res, plan=plan)["y"]

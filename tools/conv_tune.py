@@ -3,7 +3,7 @@
 ga_conv3x3_nhwc for every (tile, split-K) plan — forward; the stride-1 backward-to-input is the same kernel with
 Cin / Cout swapped, listed as its own shape.  hipGraph replay timing.  Prints a table and a JSON line.
 
-  conv_tune.py [batches, default 1,3] [cold] [--write] [variants [all]]
+  conv_tune.py [batches, default 1,3] [cold] [small] [--write] [variants [all]]
      cold    : own-kernel launches rotate over enough packed-weight copies to exceed the 256 MB Infinity Cache — in the
                pipeline a convolution's weights are cold (1.7 GB of UNet weights stream through between two uses) while its
                input was just written; warm timings favour plans with too few bytes in flight per CU
@@ -30,6 +30,8 @@ BASE_ALL = [  # (Cin, Cout, H, stride)
 
 # "variants" runs compare extra builds on a few representative shapes only
 BASE = BASE_ALL if "variants" not in sys.argv or "all" in sys.argv else [(320, 320, 64, 1), (640, 640, 32, 1), (1280, 1280, 16, 1), (1280, 1280, 8, 1)]
+if "small" in sys.argv:        # the weight-bound levels only (16 x 16 and 8 x 8 maps)
+    BASE = [b for b in BASE_ALL if b[2] <= 16]
 
 
 def replay_us(fn, iters=20):

@@ -24,7 +24,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from guided_attention_amd import ops  # noqa: E402
 from gemm_tune import BASE  # noqa: E402
 
-TILES = ((128, 128, 3), (128, 128, 2), (128, 64, 4), (128, 64, 3), (64, 128, 4), (64, 128, 3), (64, 64, 4))
+TILES = ((128, 128, 3), (128, 128, 2), (128, 64, 4), (128, 64, 3), (64, 128, 4), (64, 128, 3), (64, 64, 4), (64, 64, 5))
 
 
 def replay_us(fn, iters=20, reps=3):
