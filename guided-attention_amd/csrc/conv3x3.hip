@@ -152,6 +152,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T
                                                  split * per_slice, 16);   // aux 16 = sc1: write-through
         }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int i = 0; i < IM; ++i) keep_live(acc[j][i]);   // the stored registers stay untouched until the stores are done
     __syncthreads();
     int* flag = reinterpret_cast<int*>(lds);
     if (tid == 0) {

@@ -140,4 +140,17 @@ inline int check_launch() {
   return e == hipSuccess ? GA_OK : GA_ERR_LAUNCH;
 }
 
+// Holds `v` in its registers up to this point of the instruction stream.  Used after the sc1 (write-through) buffer stores
+// of the split-K slabs: the compiler re-used a stored accumulator register for the NEXT store's address in the instruction
+// right behind `buffer_store_dwordx4 ... sc1` (it knows no hazard there when the store has an SGPR offset), and on the MI355X
+// lanes 12-15 of each 16-lane row then stored the new value now and then (about one tile in a few hundred launches:
+// linear_kernel<128, 64, 3>, round 3).  With the accumulators live until the `s_waitcnt vmcnt(0)` behind the stores nothing
+// can overwrite them early; tools/store_hazard_scan.py looks for the instruction pair in the built library.
+template <typename V>
+__device__ __forceinline__ void keep_live(const V& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::"v"(v));
+#endif
+}
+
 }  // namespace ga

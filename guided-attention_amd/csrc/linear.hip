@@ -403,6 +403,10 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 80 * 1024 ? 2
           __builtin_amdgcn_raw_buffer_store_b128(v, srsrc, tbase + q * (kThreads * 16u), split * per_slice, 16);   // sc1
         }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int i = 0; i < IM; ++i) keep_live(acc[j][i]);   // the stored registers stay untouched until the stores are done
     __syncthreads();
     int* flag = reinterpret_cast<int*>(lds);
     if (tid == 0) {

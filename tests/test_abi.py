@@ -146,3 +146,15 @@ def test_product_refuses_cpu_tensors():
         ops.latent_axpy(torch.zeros(4), torch.zeros(4), 1.0)
     with pytest.raises(ops.GaError):
         ops.aggregate_maps([torch.zeros(2, 4, 4)])
+
+
+def test_no_write_through_store_has_its_data_overwritten_behind_it(lib):
+    """The split-K slab stores (buffer_store_dwordx4 ... sc1) must not be followed within two instructions by a VALU write to
+    the registers they store: on the MI355X that pair stored the new value from a few lanes now and then (round 3,
+    linear_kernel<128, 64, 3>; csrc/ga_common.h keep_live is the fix).  Reads the built library's ISA — no GPU needed."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    from store_hazard_scan import write_through_offenders
+    from guided_attention_amd import _lib
+    bad = write_through_offenders(str(_lib.LIB_PATH), window=2)
+    assert not bad, "\n".join(f"{f}: {s_} ; {w}" for f, s_, w in bad[:10])

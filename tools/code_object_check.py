@@ -36,6 +36,18 @@ def _device_elfs(fatbin):
         pos = cur
 
 
+def extract_code_objects(lib_path, out_dir):
+    """Writes every device ELF of the library to out_dir/co<i>.elf and returns the paths (for llvm-objdump and friends)."""
+    fat = Path(out_dir) / "fat.bin"
+    subprocess.run([str(LLVM / "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", str(lib_path), str(fat)], check=True)
+    paths = []
+    for i, (_ident, elf) in enumerate(_device_elfs(fat.read_bytes())):
+        p = Path(out_dir) / f"co{i}.elf"
+        p.write_bytes(elf)
+        paths.append(p)
+    return paths
+
+
 def kernels(lib_path):
     """[{name, private_segment_fixed_size, vgpr_spill_count, ...}] for every kernel of every device code object."""
     lib_path = Path(lib_path)
