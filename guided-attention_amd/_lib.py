@@ -71,6 +71,7 @@ PROTOTYPES = {
     "ga_geglu_fwd": [_vp, _vp, _i64, _i, _i, _vp],
     "ga_geglu_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "ga_bias_residual_add": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "ga_conv3x3_packed_elems": [_i, _i],
     "ga_conv3x3_pack_weights": [_vp, _vp, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp],
     "ga_conv3x3_plan": [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i),
                         ctypes.POINTER(ctypes.c_longlong)],
@@ -99,7 +100,7 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name == "ga_strerror" else
-                          ctypes.c_longlong if name == "ga_splitk_workspace_floats" else ctypes.c_int)
+                          ctypes.c_longlong if name in ("ga_splitk_workspace_floats", "ga_conv3x3_packed_elems") else ctypes.c_int)
         _lib = lib
     return _lib
 

@@ -83,7 +83,20 @@ struct ConvArgs {
   int lane_rot;     // patch kernel on 16-wide maps: lanes 16..31 of a 32-pixel block take their row's pixels rotated by 2
                     // (see lane_pixel); 0 everywhere else
   unsigned x_bytes, w_bytes;   // sizes of X and Wp (buffer descriptors: loads beyond them return zeros); < 2 GiB
+  // Weight addressing, in elements: (tap t, row n, channel chunk c) starts at t * w_tap + (n / 64) * w_blk + (n % 64) * w_row
+  // + c * w_chunk.  The 3x3 pack is BLOCKED — [tap][n / 64][c][n % 64][64 channels]: the 64 rows x 128 bytes a workgroup
+  // fetches per k-step are ONE contiguous 8 KB run (w_row = 64, w_chunk = 4096).  In the row-major [N][K] layout the plain
+  // GEMM entry point reads (the framework's own Linear weights; w_row = K, w_chunk = 64) the same fetch is 64 pieces of 128
+  // bytes 2 K bytes apart, and the cold weight streams of the 1280-channel levels ran at 1.3 - 1.8 TB/s on it.
+  int w_tap, w_blk, w_row, w_chunk;
 };
+
+__device__ __forceinline__ unsigned w_row_bytes(const ConvArgs& a, int n, int piece) {   // (row n, 16-byte piece) of chunk 0, tap 0
+  return (unsigned)(((n >> 6) * a.w_blk + (n & 63) * a.w_row + 8 * piece) * 2);
+}
+__device__ __forceinline__ unsigned w_step_bytes(const ConvArgs& a, int tap, int chunk) {
+  return (unsigned)((tap * a.w_tap + chunk * a.w_chunk) * 2);
+}
 
 // Which pixel of its 32-pixel block an MFMA lane (0..31) owns.  Identity, except in the patch kernel on 16-wide maps: a
 // block is two image rows there, lanes 16..31 read the patch 18 (not 16) rows further, and the bank of a 144-byte row
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
 #pragma unroll
   for (int p = 0; p < PB; ++p) {
     const int n = n0 + srow + RPP * p;
-    b_off[p] = n < a.Cout ? (unsigned)((n * a.Cin + 8 * sq) * (int)sizeof(T)) : kOob;
+    b_off[p] = n < a.Cout ? w_row_bytes(a, n, sq) : kOob;
   }
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X), 0, a.x_bytes, 0x00020000);
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
   auto load_step = [&](uint4 (&ra)[PA], uint4 (&rb)[PB]) {
     if ((GA_CONV_ABL & 1) && in_loop) return;
     const int a_step = ((ld_ky * a.W + ld_kx) * a.Cin + ld_c * kKC) * (int)sizeof(T);                  // wave-uniform
-    const unsigned b_step = (unsigned)((ld_tap * a.Cout * a.Cin + ld_c * kKC) * (int)sizeof(T));        // kOob + it stays >= 2 GiB
+    const unsigned b_step = w_step_bytes(a, ld_tap, ld_c);        // kOob + it stays >= 2 GiB
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
       const bool in = (unsigned)(a_iy[p] + ld_ky) < (unsigned)a.H && (unsigned)(a_ix[p] + ld_kx) < (unsigned)a.W;
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
 #pragma unroll
   for (int p = 0; p < PB; ++p) {
     const int n = n0 + srow + RPP * p;
-    b_off[p] = n < a.Cout ? (unsigned)((n * a.Cin + 8 * sq) * (int)sizeof(T)) : kOob;
+    b_off[p] = n < a.Cout ? w_row_bytes(a, n, sq) : kOob;
   }
   // Weight register sets: NS sets in rotation, NS | 9 so that every index is static in the unrolled chunk body; PD of
   // them in flight (prefetch distance in steps).  A 64-wide weight tile is 2 registers-quads per set: nine sets, six
@@ -525,7 +538,7 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
   constexpr int NS = BN <= 64 ? 9 : 3, PD = BN <= 64 ? 6 : 3;
   uint4 rb[NS][PB];
   auto load_w = [&](int chunk, int tap, uint4 (&r)[PB]) {
-    const unsigned step = (unsigned)((tap * a.Cout * a.Cin + chunk * kKC) * (int)sizeof(T));
+    const unsigned step = w_step_bytes(a, tap, chunk);
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
       const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[p] + step, 0, 0);
@@ -730,10 +743,10 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
   for (int q = 0; q < IPW; ++q) {
     const int row = 8 * (wave + 4 * q) + (lane >> 3);
     const int col = (lane & 7) ^ ((row >> 1) & 7);
-    w_off[q] = (unsigned)((min(n0 + row, a.Cout - 1) * a.Cin + 8 * col) * (int)sizeof(T));   // rows past Cout repeat the last one (never stored)
+    w_off[q] = w_row_bytes(a, min(n0 + row, a.Cout - 1), col);   // rows past Cout repeat the last one (never stored)
   }
   auto issue_w = [&](int chunk, int tap, int slot) {
-    const unsigned step = (unsigned)((tap * a.Cout * a.Cin + chunk * kKC) * (int)sizeof(T));
+    const unsigned step = w_step_bytes(a, tap, chunk);
 #pragma unroll
     for (int q = 0; q < IPW; ++q)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(ring + slot * kSlot + (wave_u + 4 * q) * 8 * kKC),
@@ -844,23 +857,28 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
 }
 
 // pre-pack: W [Cout][Cin][3][3] in whatever strides the framework holds (element strides given) ->
-//   forward : Wp[t = ky*3+kx][n = cout][c = cin]          = W[cout][cin][ky][kx]
-//   backward: Wp[t = ky*3+kx][n = cin ][c = cout]         = W[cout][cin][2-ky][2-kx]   (dX = conv(dY, flipped, transposed))
+//   Wp[t = ky*3+kx][nb = n / 64][cb = c / 64][r = n % 64][k = c % 64]   (N rounded up to 64 rows, the extra rows zero)
+//   forward : n = cout, c = cin : W[cout][cin][ky][kx]
+//   backward: n = cin, c = cout : W[cout][cin][2-ky][2-kx]   (dX = conv(dY, flipped, transposed))
 template <typename T>
 __global__ __launch_bounds__(kThreads) void conv_pack_kernel(const T* __restrict__ W, T* __restrict__ Wp, int Cout, int Cin,
                                                              long long s_o, long long s_i, long long s_y, long long s_x,
                                                              int transpose) {
   const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
-  const long long total = 9LL * Cout * Cin;
-  if (idx >= total) return;
   const int N = transpose ? Cin : Cout, C = transpose ? Cout : Cin;
-  const int c = (int)(idx % C);
-  const int n = (int)((idx / C) % N);
-  const int t = (int)(idx / ((long long)C * N));
+  const int NB = (N + 63) / 64, CB = C / kKC;
+  const long long total = 9LL * NB * 64 * C;
+  if (idx >= total) return;
+  const int k = (int)(idx & 63), r = (int)((idx >> 6) & 63);
+  const long long blk = idx >> 12;
+  const int cb = (int)(blk % CB);
+  const int nb = (int)((blk / CB) % NB);
+  const int t = (int)(blk / ((long long)CB * NB));
+  const int n = nb * 64 + r, c = cb * kKC + k;
   const int ky = t / 3, kx = t - 3 * ky;
   const int co = transpose ? c : n, ci = transpose ? n : c;
   const int sy = transpose ? 2 - ky : ky, sx = transpose ? 2 - kx : kx;
-  Wp[idx] = W[co * s_o + ci * s_i + sy * s_y + sx * s_x];
+  Wp[idx] = n < N ? W[co * s_o + ci * s_i + sy * s_y + sx * s_x] : Traits<T>::from_f32(0.f);
 }
 
 struct Plan {
@@ -1059,13 +1077,15 @@ extern "C" int ga_conv3x3_plan(int B, int H, int W, int Cin, int Cout, int strid
   return GA_OK;
 }
 
+extern "C" long long ga_conv3x3_packed_elems(int N, int C) { return 9LL * ((N + 63) / 64) * 64 * C; }
+
 extern "C" int ga_conv3x3_pack_weights(const void* W, void* Wp, int Cout, int Cin, int64_t stride_o, int64_t stride_i,
                                        int64_t stride_y, int64_t stride_x, int transpose_flip, int dtype,
                                        ga_stream_t stream) {
   if (!W || !Wp) return GA_ERR_NULL;
-  if (Cout < 1 || Cin < 1) return GA_ERR_SHAPE;
+  if (Cout < 1 || Cin < 1 || (transpose_flip ? Cout : Cin) % kKC != 0) return GA_ERR_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const long long total = 9LL * Cout * Cin;
+  const long long total = ga_conv3x3_packed_elems(transpose_flip ? Cin : Cout, transpose_flip ? Cout : Cin);
   dim3 grid((unsigned)((total + kThreads - 1) / kThreads));
   switch (dtype) {
     case GA_F16:
@@ -1096,10 +1116,11 @@ extern "C" int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* wo
   a.Wo = (W - 1) / stride + 1;
   a.M = B * a.Ho * a.Wo;
   a.pad = 1;
-  const long long xb = (long long)B * H * W * Cin * 2, wb = 9LL * Cin * Cout * 2;
+  const long long xb = (long long)B * H * W * Cin * 2, wb = ga_conv3x3_packed_elems(Cout, Cin) * 2;
   if (xb >= (1LL << 31) || wb >= (1LL << 31) || (long long)a.M * Cout >= (1LL << 31)) return GA_ERR_SHAPE;   // 32-bit byte offsets
   a.x_bytes = (unsigned)xb;
   a.w_bytes = (unsigned)wb;
+  a.w_tap = (int)(wb / 18); a.w_blk = 64 * Cin; a.w_row = 64; a.w_chunk = 64 * kKC;   // the blocked pack
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case GA_F16: return conv_t<_Float16>(X, Wp, Y, workspace, tickets, bias, residual, a, bm, bn, splits, s);
@@ -1125,6 +1146,7 @@ extern "C" int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspac
   a.pad = 0;
   a.x_bytes = (unsigned)xb;
   a.w_bytes = (unsigned)wb;
+  a.w_tap = 0; a.w_blk = 64 * K; a.w_row = K; a.w_chunk = kKC;   // row-major [N][K]
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case GA_F16: return conv_t<_Float16>(X, W, Y, workspace, tickets, bias, residual, a, bm, bn, splits, s);

@@ -909,7 +909,8 @@ def conv3x3_plan(B, H, W, Cin, Cout, stride):
 
 
 def conv3x3_packed_weights(weight, transpose_flip):
-    """[9][N][C] pack of a (Cout, Cin, 3, 3) weight (any strides), cached per (storage, version)."""
+    """Blocked [9][N / 64][C / 64][64][64] pack (csrc/conv3x3.hip) of a (Cout, Cin, 3, 3) weight (any strides), cached per
+    (storage, version)."""
     key = (weight.data_ptr(), weight._version, weight.dtype, bool(transpose_flip), tuple(weight.stride()), tuple(weight.shape))
     entry = _conv_pack_cache.get(key)
     # the entry is only good for the tensor object it was made from: a freed weight's address can be handed to another
@@ -919,7 +920,7 @@ def conv3x3_packed_weights(weight, transpose_flip):
         require_cuda(weight)
         Cout, Cin = weight.shape[0], weight.shape[1]
         N, C = (Cin, Cout) if transpose_flip else (Cout, Cin)
-        hit = torch.empty((9, N, C), dtype=weight.dtype, device=weight.device)
+        hit = torch.empty(int(load().ga_conv3x3_packed_elems(N, C)), dtype=weight.dtype, device=weight.device)
         so, si, sy, sx = weight.stride()
         check(load().ga_conv3x3_pack_weights(_ptr(weight), _ptr(hit), Cout, Cin, so, si, sy, sx, int(bool(transpose_flip)),
                                              dtype_code(weight), stream_ptr()), "ga_conv3x3_pack_weights")

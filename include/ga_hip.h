@@ -246,10 +246,13 @@ int ga_bias_residual_add(const void* y, const void* bias, const void* residual, 
  * (diffusers 0.12.1 ResnetBlock2D / Upsample2D / Downsample2D convolutions, run by the reference inside
  * pipeline_guided_attention.py:583-743 through cuDNN).  16-bit types; Cin % 64 == 0 (one k-step = 64 channels of one
  * tap), Cout % 8 == 0; anything else returns GA_ERR_SHAPE.
- *   ga_conv3x3_pack_weights : W [Cout][Cin][3][3] with the given ELEMENT strides -> Wp [9][N][C] (tap-major, depth
- *                             contiguous).  transpose_flip = 0: N = Cout, C = Cin (forward).  transpose_flip = 1:
- *                             N = Cin, C = Cout, taps mirrored — with it the same kernel computes the backward to the
- *                             input of a stride-1 convolution from the upstream gradient.  Once per weight version.
+ *   ga_conv3x3_pack_weights : W [Cout][Cin][3][3] with the given ELEMENT strides -> the blocked pack
+ *                             Wp [9][ceil(N / 64)][C / 64][64][64] (tap, 64-row block, 64-channel chunk, row, channel;
+ *                             rows past N are zero): what a workgroup fetches per k-step is one contiguous 8 KB run.
+ *                             Wp holds ga_conv3x3_packed_elems(N, C) elements.  transpose_flip = 0: N = Cout, C = Cin
+ *                             (forward).  transpose_flip = 1: N = Cin, C = Cout, taps mirrored — with it the same kernel
+ *                             computes the backward to the input of a stride-1 convolution from the upstream gradient.
+ *                             C % 64 == 0.  Once per weight version.
  *   ga_conv3x3_plan         : tile (bm x bn) and split-K factor for a shape, and the f32 workspace it needs
  *                             (ga_splitk_workspace_floats(B * Ho * Wo, Cout, bm, bn, splits); 0 when splits == 1).
  *                             Pure host function.
@@ -261,6 +264,7 @@ int ga_bias_residual_add(const void* y, const void* bias, const void* residual, 
  *                             leaves them zero.  Launches sharing workspace / tickets must be stream-ordered.
  */
 long long ga_splitk_workspace_floats(int64_t M, int N, int bm, int bn, int splits);
+long long ga_conv3x3_packed_elems(int N, int C);
 int ga_conv3x3_pack_weights(const void* W, void* Wp, int Cout, int Cin, int64_t stride_o, int64_t stride_i,
                             int64_t stride_y, int64_t stride_x, int transpose_flip, int dtype, ga_stream_t stream);
 int ga_conv3x3_plan(int B, int H, int W, int Cin, int Cout, int stride, int* bm, int* bn, int* splits,

@@ -70,7 +70,7 @@ def variant_times(lib, x, w, co, st, plans):
     import ctypes
     B, ci, h, _ = x.shape
     ho = (h - 1) // st + 1
-    wp = torch.empty(9, co, ci, device="cuda", dtype=x.dtype)
+    wp = torch.empty(9 * (-(-co // 64) * 64) * ci, device="cuda", dtype=x.dtype)      # the blocked pack (include/ga_hip.h)
     sp_ = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
     so, si, sy, sx = w.stride()
