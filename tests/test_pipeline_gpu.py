@@ -122,10 +122,16 @@ def test_variants_are_result_identical(variant):
     assert err < 2e-4, err
 
 
-@pytest.mark.parametrize("dt,tol", [("f16", 6e-2), ("bf16", 2.5e-1)])
+@pytest.mark.parametrize("dt,tol", [("f16", 1.5e-2), ("bf16", 1.0e-1)])
 def test_half_precision_pipeline_vs_oracle(dt, tol):
     """The fast dtypes against the fp32 CPU oracle, case without threshold-driven branching near the limit
-    (thresholds chosen so both sides take the same branches).  Stated tolerance: max |dlatent| / max |latent|."""
+    (thresholds chosen so both sides take the same branches).  Stated tolerance: max |dlatent| / max |latent|.
+    Measured on the MI355X (round 3, `pytest -s`, the [measured] line below): f16 5.7e-3 (rms 5.3e-3), bf16 4.8e-2 (rms 4.1e-2)
+    after 4 denoising steps with 3 guidance updates — the bounds are 2 - 2.6x the measurement (round 2 carried 6e-2 / 2.5e-1).
+    Error budget: one UNet evaluation differs from fp32 by about 2^-11 (f16) / 2^-8 (bf16) per stored activation, ~3e-3 / 2e-2
+    at the noise prediction after ~60 layers with f32 accumulation inside every kernel; the guidance update multiplies the latent
+    gradient's error (a few %, in bf16) by scale_factor * sqrt(scale_range) and the DDIM recursion carries it on: the
+    differences are common-mode (rms ~ max), not isolated spikes."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     meta = dict(G9[2], steps=4)
@@ -390,7 +396,9 @@ def test_strict_mode_pipeline_vs_oracle():
     assert err < 5e-3, err
 
 
-@pytest.mark.parametrize("dt,tol_maps,tol_grad", [("f32", 1e-4, 3e-3), ("bf16", 4e-2, 3.5e-1)])
+# measured on the MI355X (round 3, the [measured] line): f32 maps 6.8e-7, grad 4.4e-6, cosine 1.00000; bf16 maps 1.4e-2,
+# loss 6.6e-5, grad max-rel 4.2e-2, cosine 0.99918 — the bf16 bounds are 2 - 2.4x that (round 2 carried 4e-2 / 3.5e-1 / 0.97)
+@pytest.mark.parametrize("dt,tol_maps,tol_grad", [("f32", 1e-5, 5e-5), ("bf16", 3e-2, 1e-1)])
 def test_sdxl_layout_one_guidance_step(dt, tol_maps, tol_grad):
     """BASELINE config 5 layout (no reference oracle exists: diffusers 0.12.1 predates SDXL): 3 levels, no attention on
     the top level, 2 / 3 transformer blocks per attention below (SDXL: 2 / 10), per-level head counts, linear
@@ -441,12 +449,12 @@ def test_sdxl_layout_one_guidance_step(dt, tol_maps, tol_grad):
     terms, loss = ops.SmoothLoss.apply(A.reshape(res * res, 77), res, 1, 76, plan)
     (g_hip,) = torch.autograd.grad(loss, [lat_g])
     assert np.abs(A.detach().cpu().numpy() - A_ref.detach().numpy()).max() < tol_maps * A_ref.max().item()
-    np.testing.assert_allclose(loss.item(), float(r["loss"]), rtol=1e-4 if dt == "f32" else 3e-2)
+    np.testing.assert_allclose(loss.item(), float(r["loss"]), rtol=1e-5 if dt == "f32" else 2e-3)
     err = (g_hip.float().cpu() - g_ref).abs().max().item() / g_ref.abs().max().item()
     cos = float((g_hip.float().cpu() * g_ref).sum() / (g_hip.float().cpu().norm() * g_ref.norm()))
     print(f"[measured] sdxl layout {dt}: maps {np.abs(A.detach().cpu().numpy() - A_ref.detach().numpy()).max() / A_ref.max().item():.3e} "
           f"loss {abs(loss.item() - float(r['loss'])) / abs(float(r['loss'])):.3e} grad max-rel {err:.3e} cosine {cos:.5f}")
-    assert err < tol_grad and cos > (0.9999 if dt == "f32" else 0.97), (err, cos)
+    assert err < tol_grad and cos > (0.99999 if dt == "f32" else 0.997), (err, cos)
 
 
 def test_paint_with_words_pipeline_vs_oracle():
