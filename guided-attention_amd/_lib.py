@@ -67,7 +67,7 @@ PROTOTYPES = {
     "ga_self_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ga_self_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ga_group_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
-    "ga_group_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ga_group_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ga_geglu_fwd": [_vp, _vp, _i64, _i, _i, _vp],
     "ga_geglu_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "ga_bias_residual_add": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
@@ -77,6 +77,7 @@ PROTOTYPES = {
                         ctypes.POINTER(ctypes.c_longlong)],
     "ga_splitk_workspace_floats": [_i64, _i, _i, _i, _i],
     "ga_conv3x3_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ga_conv3x3_up2x_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ga_gemm_nt": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
     "ga_linear_workspace": [_i64, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(_i)],
     "ga_linear_fused": [_vp, _i64, _vp, _vp, _i64, ctypes.POINTER(ga_linear_epilogue_t), _vp, _vp, _i64, _i, _i, _i, _i, _i,

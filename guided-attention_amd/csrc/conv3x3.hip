@@ -89,6 +89,9 @@ struct ConvArgs {
   // GEMM entry point reads (the framework's own Linear weights; w_row = K, w_chunk = 64) the same fetch is 64 pieces of 128
   // bytes 2 K bytes apart, and the cold weight streams of the 1280-channel levels ran at 1.3 - 1.8 TB/s on it.
   int w_tap, w_blk, w_row, w_chunk;
+  int up;           // 1: X is [B][H/2][W/2][Cin] and the convolution runs on its nearest-neighbour 2x up-sampling (H, W are the
+                    // up-sampled sizes): only the patch gather of conv3x3_patch_dma_kernel changes — pixel (iy, ix) of the
+                    // patch is read from (iy >> 1, ix >> 1) — and the [B][H][W][Cin] intermediate is never written
 };
 
 __device__ __forceinline__ unsigned w_row_bytes(const ConvArgs& a, int n, int piece) {   // (row n, 16-byte piece) of chunk 0, tap 0
@@ -721,7 +724,8 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
     const int b = mseg / (a.H * a.W), y0 = (mseg - b * (a.H * a.W)) / a.W;
     const int iy = y0 + pr - 1, ix = pc - 1;
     const bool ok = q < npatch && mseg < a.M && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-    pa_off[p] = ok ? (unsigned)((((b * a.H + iy) * a.W + ix) * a.Cin + 8 * sq) * (int)sizeof(T)) : kOob;
+    const int pix = a.up ? (b * (a.H >> 1) + (iy >> 1)) * (a.W >> 1) + (ix >> 1) : (b * a.H + iy) * a.W + ix;
+    pa_off[p] = ok ? (unsigned)((pix * a.Cin + 8 * sq) * (int)sizeof(T)) : kOob;
   }
   u32x4_t rp[kPatchPieces];
   auto load_patch = [&](int chunk) {
@@ -973,6 +977,7 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, con
   const bool geom_ok = a.pad == 1 && a.stride == 1 && (a.W >= 16 || (a.W >= 8 && use_dma() && deep_ring())) && !force_v1();
   const bool patch = geom_ok && patch_geometry(BM, a.H, a.W, pg);
   const bool patch_wide = geom_ok && !patch && (BN <= 64 || BM == 128) && patch_geometry(BM, a.H, a.W, pg, true);
+  if (a.up && !((patch || patch_wide) && use_dma())) return GA_ERR_SHAPE;   // only the patch-DMA kernel gathers from the half-size map
   if (patch_wide) {   // the 13-piece instantiation: one row of a 128-wide map, or a run of a 96- / 48-wide map (geometry 3)
     a.steps_per = (a.Cin / kKC + splits - 1) / splits;
     if constexpr (BN <= 64 || BM == 128) {
@@ -1121,6 +1126,33 @@ extern "C" int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* wo
   a.x_bytes = (unsigned)xb;
   a.w_bytes = (unsigned)wb;
   a.w_tap = (int)(wb / 18); a.w_blk = 64 * Cin; a.w_row = 64; a.w_chunk = 64 * kKC;   // the blocked pack
+  a.up = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case GA_F16: return conv_t<_Float16>(X, Wp, Y, workspace, tickets, bias, residual, a, bm, bn, splits, s);
+    case GA_BF16: return conv_t<bf16_t>(X, Wp, Y, workspace, tickets, bias, residual, a, bm, bn, splits, s);
+    default: return GA_ERR_DTYPE;
+  }
+}
+
+extern "C" int ga_conv3x3_up2x_nhwc(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets,
+                                    const void* bias, const void* residual, int B, int H, int W, int Cin, int Cout, int bm,
+                                    int bn, int splits, int dtype, ga_stream_t stream) {
+  if (!X || !Wp || !Y) return GA_ERR_NULL;
+  if (B < 1 || H < 1 || W < 1 || Cin < kKC || Cin % kKC != 0 || Cout < 8 || Cout % 8 != 0) return GA_ERR_SHAPE;
+  if (splits < 1 || splits > 64 || (splits > 1 && (!workspace || !tickets))) return GA_ERR_SHAPE;
+  if (!al16(X) || !al16(Wp) || !al16(Y) || (bias && !al16(bias)) || (residual && !al16(residual))) return GA_ERR_ALIGN;
+  ConvArgs a;
+  a.B = B; a.H = 2 * H; a.W = 2 * W; a.Cin = Cin; a.Cout = Cout; a.stride = 1;
+  a.Ho = a.H; a.Wo = a.W;
+  a.M = B * a.Ho * a.Wo;
+  a.pad = 1;
+  const long long xb = (long long)B * H * W * Cin * 2, wb = ga_conv3x3_packed_elems(Cout, Cin) * 2;
+  if (xb >= (1LL << 31) || wb >= (1LL << 31) || (long long)a.M * Cout >= (1LL << 31)) return GA_ERR_SHAPE;
+  a.x_bytes = (unsigned)xb;
+  a.w_bytes = (unsigned)wb;
+  a.w_tap = (int)(wb / 18); a.w_blk = 64 * Cin; a.w_row = 64; a.w_chunk = 64 * kKC;
+  a.up = 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case GA_F16: return conv_t<_Float16>(X, Wp, Y, workspace, tickets, bias, residual, a, bm, bn, splits, s);
@@ -1147,6 +1179,7 @@ extern "C" int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspac
   a.x_bytes = (unsigned)xb;
   a.w_bytes = (unsigned)wb;
   a.w_tap = 0; a.w_blk = 64 * K; a.w_row = K; a.w_chunk = kKC;   // row-major [N][K]
+  a.up = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case GA_F16: return conv_t<_Float16>(X, W, Y, workspace, tickets, bias, residual, a, bm, bn, splits, s);

@@ -291,7 +291,8 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
                                                                 const T* __restrict__ beta,
                                                                 const float* __restrict__ stats,
                                                                 const float* __restrict__ partial, int NB, float inv_n,
-                                                                T* __restrict__ dx, int HW, int C, int G, int PB) {
+                                                                const T* __restrict__ gres, T* __restrict__ dx, int HW,
+                                                                int C, int G, int PB) {
   __shared__ float2 res[64];
   const int b = blockIdx.y, CP = C / W, cpg = (C / G) / W;
   fold_partials<false>(partial, b, NB, G, inv_n, 0.f, res, nullptr);
@@ -319,17 +320,19 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
   const Item<T, W>* xb = reinterpret_cast<const Item<T, W>*>(x) + (size_t)b * HW * CP;
   const Item<T, W>* db = reinterpret_cast<const Item<T, W>*>(dy) + (size_t)b * HW * CP;
   Item<T, W>* ob = reinterpret_cast<Item<T, W>*>(dx) + (size_t)b * HW * CP;
+  const Item<T, W>* rb = reinterpret_cast<const Item<T, W>*>(gres) + (size_t)b * HW * CP;   // gradient of x's other consumer
 #pragma unroll
   for (int k = 0; k < NPT; ++k) {
     const int cp = threadIdx.x + k * kThreads;
     if (cp >= CP) continue;
     for (int p = p0; p < p1; p += kU) {
-      Item<T, W> v[kU], d[kU];
+      Item<T, W> v[kU], d[kU], gr[kU];
 #pragma unroll
       for (int u = 0; u < kU; ++u)
         if (p + u < p1) {
           v[u] = xb[(size_t)(p + u) * CP + cp];
           d[u] = db[(size_t)(p + u) * CP + cp];
+          if (gres != nullptr) gr[u] = rb[(size_t)(p + u) * CP + cp];
         }
 #pragma unroll
       for (int u = 0; u < kU; ++u)
@@ -339,7 +342,8 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(const T* __restr
           for (int j = 0; j < W; ++j) {
             const float yh = (Traits<T>::to_f32(v[u].v[j]) + cbk[k][j] - mu[k]) * rs[k];
             const float dh = dyhat_of<ACT>(yh, Traits<T>::to_f32(d[u].v[j]), g0[k][j], b0[k][j]);
-            o.v[j] = Traits<T>::from_f32(rs[k] * (dh - a1[k] - yh * a2[k]));
+            const float add = gres != nullptr ? Traits<T>::to_f32(gr[u].v[j]) : 0.f;
+            o.v[j] = Traits<T>::from_f32(rs[k] * (dh - a1[k] - yh * a2[k]) + add);
           }
           ob[(size_t)(p + u) * CP + cp] = o;
         }
@@ -573,15 +577,16 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
                                                                      const T* __restrict__ beta,
                                                                      const float* __restrict__ stats,
                                                                      const float* __restrict__ partial, int NB,
-                                                                     float inv_n, T* __restrict__ dx, int HW, int C,
-                                                                     int G, int PB) {
+                                                                     float inv_n, const T* __restrict__ gres,
+                                                                     T* __restrict__ dx, int HW, int C, int G, int PB) {
   __shared__ float2 res[64];
   const WideMap m(C, G);
   const int b = blockIdx.y, p0 = blockIdx.x * PB, p1 = min(HW, p0 + PB);
   const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
   const Vec8<T>* db = reinterpret_cast<const Vec8<T>*>(dy + (size_t)b * HW * C) + m.vec;
   Vec8<T>* ob = reinterpret_cast<Vec8<T>*>(dx + (size_t)b * HW * C) + m.vec;
-  Vec8<T> v[kU], d[kU];   // first batch in flight under the fold of the partial sums (as in the forward)
+  const Vec8<T>* rb = reinterpret_cast<const Vec8<T>*>(gres + (size_t)b * HW * C) + m.vec;   // gradient of x's other consumer
+  Vec8<T> v[kU], d[kU], gr[kU];   // first batch in flight under the fold of the partial sums (as in the forward)
   int p = p0 + m.pr;
   if (m.active) {
 #pragma unroll
@@ -589,6 +594,7 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
       if (p + u * m.RP < p1) {
         v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
         d[u] = db[(size_t)(p + u * m.RP) * m.VP];
+        if (gres != nullptr) gr[u] = rb[(size_t)(p + u * m.RP) * m.VP];
       }
   }
   fold_partials<false>(partial, b, NB, G, inv_n, 0.f, res, nullptr);
@@ -611,7 +617,8 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
         for (int j = 0; j < 8; ++j) {
           const float yh = (Traits<T>::to_f32(v[u].v[j]) + k.cb[j] - k.mu[j]) * k.rs[j];
           const float dh = dyhat_of<ACT>(yh, Traits<T>::to_f32(d[u].v[j]), k.gm[j], k.bt[j]);
-          o.v[j] = Traits<T>::from_f32(k.rs[j] * (dh - a1[j] - yh * a2[j]));
+          const float add = gres != nullptr ? Traits<T>::to_f32(gr[u].v[j]) : 0.f;
+          o.v[j] = Traits<T>::from_f32(k.rs[j] * (dh - a1[j] - yh * a2[j]) + add);
         }
         ob[(size_t)(p + u * m.RP) * m.VP] = o;
       }
@@ -621,6 +628,7 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
       if (pn + u * m.RP < p1) {
         v[u] = xb[(size_t)(pn + u * m.RP) * m.VP];
         d[u] = db[(size_t)(pn + u * m.RP) * m.VP];
+        if (gres != nullptr) gr[u] = rb[(size_t)(pn + u * m.RP) * m.VP];
       }
   }
 }
@@ -630,6 +638,9 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
 // The group's slab (HW pixels x C/G channels, <= 20 480 elements) is read once into LDS while the sums are taken,
 // reduced in-block, then normalised from LDS: a single ~4 us latency chain instead of three launches.
 constexpr int kSmallMaxElems = 20480;
+// pixels per thread at most: ceil(HW / floor(NT / hp)) <= 2 HW hp / NT + 1, with HW hp <= 10240 at NT = 1024 and < 2048 at
+// NT = 256 (small_wide): 21 and 17
+constexpr int kSmallIters = 24;
 
 template <int NT>
 __device__ __forceinline__ void block_sum2(float& a, float& c, float* red) {
@@ -715,8 +726,9 @@ template <typename T, bool ACT, int NT>
 __global__ __launch_bounds__(NT) void gn_small_bwd_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
                                                           const T* __restrict__ dy, const T* __restrict__ gamma,
                                                           const T* __restrict__ beta,
-                                                          const float* __restrict__ stats, T* __restrict__ dx,
-                                                          int HW, int C, int G) {
+                                                          const float* __restrict__ stats,
+                                                          const T* __restrict__ gres, T* __restrict__ dx, int HW, int C,
+                                                          int G) {
   extern __shared__ __attribute__((aligned(16))) char smem_small[];
   float* red = reinterpret_cast<float*>(smem_small);
   float2* dh = reinterpret_cast<float2*>(red + 32);  // [HW][Cg/2] dL/dyhat
@@ -751,19 +763,32 @@ __global__ __launch_bounds__(NT) void gn_small_bwd_kernel(const T* __restrict__ 
       s1 += d0 * y0 + d1 * y1;
     }
   }
+  // the skip connection's gradient: all of this thread's loads in flight across the block reduction
+  Item<T, 2> gr[kSmallIters];
+  if (active && gres != nullptr) {
+#pragma unroll
+    for (int k = 0; k < kSmallIters; ++k) {
+      const int p = p0 + k * rows;
+      if (p < HW) gr[k] = *reinterpret_cast<const Item<T, 2>*>(gres + base + (size_t)p * C);
+    }
+  }
   block_sum2<NT>(s0, s1, red);
   if (!active) return;
   const float inv_n = 1.0f / ((float)HW * (float)Cg);
   const float m1 = s0 * inv_n, m2 = s1 * inv_n;
-#pragma unroll 4
-  for (int p = p0; p < HW; p += rows) {
+#pragma unroll
+  for (int k = 0; k < kSmallIters; ++k) {
+    const int p = p0 + k * rows;
+    if (p >= HW) break;
     const float2 a = dh[p * hp + j];
     const Item<T, 2> v = xs[p * hp + j];
     const float y0 = (Traits<T>::to_f32(v.v[0]) + cb0) * rstd;
     const float y1 = (Traits<T>::to_f32(v.v[1]) + cb1) * rstd;
+    const float r0 = gres != nullptr ? Traits<T>::to_f32(gr[k].v[0]) : 0.f;
+    const float r1 = gres != nullptr ? Traits<T>::to_f32(gr[k].v[1]) : 0.f;
     Item<T, 2> o;
-    o.v[0] = Traits<T>::from_f32(rstd * (a.x - m1 - y0 * m2));
-    o.v[1] = Traits<T>::from_f32(rstd * (a.y - m1 - y1 * m2));
+    o.v[0] = Traits<T>::from_f32(rstd * (a.x - m1 - y0 * m2) + r0);
+    o.v[1] = Traits<T>::from_f32(rstd * (a.y - m1 - y1 * m2) + r1);
     *reinterpret_cast<Item<T, 2>*>(dx + base + (size_t)p * C) = o;
   }
 }
@@ -795,24 +820,24 @@ int small_fwd(const void* x, const void* cb, const void* gamma, const void* beta
 
 template <typename T, bool ACT, int NT>
 int small_bwd_launch(const void* x, const void* cb, const void* dy, const void* gamma, const void* beta,
-                     const float* stats, void* dx, int B, int HW, int C, int G, hipStream_t s) {
+                     const float* stats, const void* gres, void* dx, int B, int HW, int C, int G, hipStream_t s) {
   const size_t lds = kSmallHeader + (sizeof(float) + sizeof(T)) * (size_t)HW * (C / G);
   auto k = gn_small_bwd_kernel<T, ACT, NT>;
   const int rc = set_dyn_lds(k, lds);
   if (rc != GA_OK) return rc;
   hipLaunchKernelGGL(k, dim3(G, B), dim3(NT), lds, s, (const T*)x, (const T*)cb, (const T*)dy, (const T*)gamma,
-                     (const T*)beta, stats, (T*)dx, HW, C, G);
+                     (const T*)beta, stats, (const T*)gres, (T*)dx, HW, C, G);
   return check_launch();
 }
 
 template <typename T>
 int small_bwd(const void* x, const void* cb, const void* dy, const void* gamma, const void* beta, const float* stats,
-              void* dx, int B, int HW, int C, int G, int act, hipStream_t s) {
+              const void* gres, void* dx, int B, int HW, int C, int G, int act, hipStream_t s) {
   if (small_wide(HW, C, G))
-    return act ? small_bwd_launch<T, true, 1024>(x, cb, dy, gamma, beta, stats, dx, B, HW, C, G, s)
-               : small_bwd_launch<T, false, 1024>(x, cb, dy, gamma, beta, stats, dx, B, HW, C, G, s);
-  return act ? small_bwd_launch<T, true, 256>(x, cb, dy, gamma, beta, stats, dx, B, HW, C, G, s)
-             : small_bwd_launch<T, false, 256>(x, cb, dy, gamma, beta, stats, dx, B, HW, C, G, s);
+    return act ? small_bwd_launch<T, true, 1024>(x, cb, dy, gamma, beta, stats, gres, dx, B, HW, C, G, s)
+               : small_bwd_launch<T, false, 1024>(x, cb, dy, gamma, beta, stats, gres, dx, B, HW, C, G, s);
+  return act ? small_bwd_launch<T, true, 256>(x, cb, dy, gamma, beta, stats, gres, dx, B, HW, C, G, s)
+             : small_bwd_launch<T, false, 256>(x, cb, dy, gamma, beta, stats, gres, dx, B, HW, C, G, s);
 }
 
 bool small_path(int HW, int C, int G, size_t slab_bytes_per_elem) {
@@ -857,13 +882,14 @@ int launch_fwd_t(const void* x, const void* cbias, const void* gamma, const void
 
 template <typename T, bool ACT, int NPT, int W>
 int launch_bwd_t(const void* x, const void* cbias, const void* dy, const void* gamma, const void* beta,
-                 const float* stats, void* dx, float* ws, int B, int HW, int C, int G, const Geom& g, hipStream_t s) {
+                 const float* stats, const void* gres, void* dx, float* ws, int B, int HW, int C, int G, const Geom& g,
+                 hipStream_t s) {
   const float inv_n = 1.0f / ((float)HW * (float)(C / G));
   hipLaunchKernelGGL((gn_bwd_stats_kernel<T, ACT, NPT, W>), dim3(g.NB, B), dim3(kThreads), g.lds, s, (const T*)x,
                      (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, ws, HW, C, G, g.PBs);
   hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT, NPT, W>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
                      (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, (const float*)ws, g.NB, inv_n,
-                     (T*)dx, HW, C, G, g.PBa);
+                     (const T*)gres, (T*)dx, HW, C, G, g.PBa);
   return check_launch();
 }
 
@@ -925,7 +951,7 @@ int wide_fwd(const void* x, const void* cbias, const void* gamma, const void* be
 
 template <typename T>
 int wide_bwd(const void* x, const void* cbias, const void* dy, const void* gamma, const void* beta, const float* stats,
-             void* dx, float* ws, int B, int HW, int C, int G, int act, hipStream_t s) {
+             const void* gres, void* dx, float* ws, int B, int HW, int C, int G, int act, hipStream_t s) {
   const WideGeom g(HW, C);
   const float inv_n = 1.0f / ((float)HW * (float)(C / G));
   if (act)
@@ -937,11 +963,11 @@ int wide_bwd(const void* x, const void* cbias, const void* dy, const void* gamma
   if (act)
     hipLaunchKernelGGL((gn_wide_bwd_apply_kernel<T, true>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
                        (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, (const float*)ws, g.NB,
-                       inv_n, (T*)dx, HW, C, G, g.PBa);
+                       inv_n, (const T*)gres, (T*)dx, HW, C, G, g.PBa);
   else
     hipLaunchKernelGGL((gn_wide_bwd_apply_kernel<T, false>), dim3(g.NBa, B), dim3(kThreads), 0, s, (const T*)x,
                        (const T*)cbias, (const T*)dy, (const T*)gamma, (const T*)beta, stats, (const float*)ws, g.NB,
-                       inv_n, (T*)dx, HW, C, G, g.PBa);
+                       inv_n, (const T*)gres, (T*)dx, HW, C, G, g.PBa);
   return check_launch();
 }
 
@@ -959,14 +985,14 @@ int fwd_dtype(const void* x, const void* cbias, const void* gamma, const void* b
 
 template <typename T>
 int bwd_dtype(const void* x, const void* cbias, const void* dy, const void* gamma, const void* beta, const float* stats,
-              void* dx, float* ws, int B, int HW, int C, int G, int act, const Geom& g, hipStream_t s) {
+              const void* gres, void* dx, float* ws, int B, int HW, int C, int G, int act, const Geom& g, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
-    if (wide_ok(C, G, sizeof(T))) return wide_bwd<T>(x, cbias, dy, gamma, beta, stats, dx, ws, B, HW, C, G, act, s);
+    if (wide_ok(C, G, sizeof(T))) return wide_bwd<T>(x, cbias, dy, gamma, beta, stats, gres, dx, ws, B, HW, C, G, act, s);
   }
   if (act) {
-    GA_GN_NPT(launch_bwd_t, T, true, x, cbias, dy, gamma, beta, stats, dx, ws, B, HW, C, G, g, s)
+    GA_GN_NPT(launch_bwd_t, T, true, x, cbias, dy, gamma, beta, stats, gres, dx, ws, B, HW, C, G, g, s)
   }
-  GA_GN_NPT(launch_bwd_t, T, false, x, cbias, dy, gamma, beta, stats, dx, ws, B, HW, C, G, g, s)
+  GA_GN_NPT(launch_bwd_t, T, false, x, cbias, dy, gamma, beta, stats, gres, dx, ws, B, HW, C, G, g, s)
 }
 
 }  // namespace
@@ -996,8 +1022,8 @@ extern "C" int ga_group_norm_fwd(const void* x, const void* chan_bias, const voi
 }
 
 extern "C" int ga_group_norm_bwd(const void* x, const void* chan_bias, const void* dy, const void* gamma,
-                                 const void* beta, const float* stats, void* dx, float* workspace, int B, int HW, int C,
-                                 int G, int act_silu, int dtype, ga_stream_t stream) {
+                                 const void* beta, const float* stats, const void* g_res, void* dx, float* workspace, int B,
+                                 int HW, int C, int G, int act_silu, int dtype, ga_stream_t stream) {
   if (!x || !dy || !gamma || !beta || !stats || !dx || !workspace) return GA_ERR_NULL;
   Geom g;
   int rc = geometry(B, HW, C, G, g);
@@ -1005,16 +1031,16 @@ extern "C" int ga_group_norm_bwd(const void* x, const void* chan_bias, const voi
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (small_path(HW, C, G, sizeof(float) + elem_bytes(dtype))) {
     switch (dtype) {
-      case GA_F16: return small_bwd<_Float16>(x, chan_bias, dy, gamma, beta, stats, dx, B, HW, C, G, act_silu, s);
-      case GA_BF16: return small_bwd<bf16_t>(x, chan_bias, dy, gamma, beta, stats, dx, B, HW, C, G, act_silu, s);
-      case GA_F32: return small_bwd<float>(x, chan_bias, dy, gamma, beta, stats, dx, B, HW, C, G, act_silu, s);
+      case GA_F16: return small_bwd<_Float16>(x, chan_bias, dy, gamma, beta, stats, g_res, dx, B, HW, C, G, act_silu, s);
+      case GA_BF16: return small_bwd<bf16_t>(x, chan_bias, dy, gamma, beta, stats, g_res, dx, B, HW, C, G, act_silu, s);
+      case GA_F32: return small_bwd<float>(x, chan_bias, dy, gamma, beta, stats, g_res, dx, B, HW, C, G, act_silu, s);
       default: return GA_ERR_DTYPE;
     }
   }
   switch (dtype) {
-    case GA_F16: return bwd_dtype<_Float16>(x, chan_bias, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
-    case GA_BF16: return bwd_dtype<bf16_t>(x, chan_bias, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
-    case GA_F32: return bwd_dtype<float>(x, chan_bias, dy, gamma, beta, stats, dx, workspace, B, HW, C, G, act_silu, g, s);
+    case GA_F16: return bwd_dtype<_Float16>(x, chan_bias, dy, gamma, beta, stats, g_res, dx, workspace, B, HW, C, G, act_silu, g, s);
+    case GA_BF16: return bwd_dtype<bf16_t>(x, chan_bias, dy, gamma, beta, stats, g_res, dx, workspace, B, HW, C, G, act_silu, g, s);
+    case GA_F32: return bwd_dtype<float>(x, chan_bias, dy, gamma, beta, stats, g_res, dx, workspace, B, HW, C, G, act_silu, g, s);
     default: return GA_ERR_DTYPE;
   }
 }

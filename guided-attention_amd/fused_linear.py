@@ -11,6 +11,8 @@ Weights are frozen on this path (only the latents are differentiated, pipeline_g
 produces dX only — dX = dY W by the library GEMM, then the existing LayerNorm / GEGLU backward kernels.
 The gamma-scaled weights, their column sums and the beta / bias shifts are built once per (weight, norm) pair and
 re-built when a version counter moves."""
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -34,8 +36,11 @@ def _transposed(weight):
         if len(_wt_cache) > 2048:
             for dead in [k for k, (ref, _) in _wt_cache.items() if ref() is None]:
                 del _wt_cache[dead]
-        import weakref
-        hit = _wt_cache[key] = (weakref.ref(weight), wt)
+        # the entry lives as long as the tensor that OWNS the storage: a 1x1 convolution's weight arrives here as a fresh
+        # (out, in) view of the parameter on every call — tied to that view, the entry was dead by the next call and every
+        # guidance backward transposed 27 weight matrices again (round 3: 14 strided-copy launches per backward pass)
+        owner = weight._base if weight._base is not None else weight
+        hit = _wt_cache[key] = (weakref.ref(owner), wt)
     return hit[1]
 
 

@@ -196,7 +196,7 @@ def replay_launch_us(key, iters=100):
                                             groups, 1e-5, int(flag), code, stream_ptr()), "replay gn fwd")
         else:
             def fn():
-                check(lib.ga_group_norm_bwd(_ptr(x), None, _ptr(dy), _ptr(w), _ptr(b_), _ptr(stats), _ptr(y), _ptr(ws), B,
+                check(lib.ga_group_norm_bwd(_ptr(x), None, _ptr(dy), _ptr(w), _ptr(b_), _ptr(stats), None, _ptr(y), _ptr(ws), B,
                                             HW, C, groups, int(flag), code, stream_ptr()), "replay gn bwd")
     elif kind in ("attn_capture_fwd", "attn_capture_bwd", "self_attn_fwd", "self_attn_bwd"):
         q = torch.randn(B, N, H * D, device=dev, dtype=dtype)
@@ -672,10 +672,13 @@ def _nhwc(x):
 
 class GroupNormAct(torch.autograd.Function):
     """y = [silu](group_norm(x [+ chan_bias[:, :, None, None]])) on channels-last (B, C, H, W) tensors;
-    differentiable w.r.t. x only (chan_bias is the time-embedding term: it carries no gradient on this path)."""
+    differentiable w.r.t. x only (chan_bias is the time-embedding term: it carries no gradient on this path).
+    with_alias: returns (y, x) — the caller hands that second output to x's OTHER consumer (the block's skip connection),
+    so that both gradients arrive in this node and ga_group_norm_bwd adds them in its own pass (`g_res`); autograd's
+    accumulation would be one more launch per block (23 per guidance backward of the SD-1.x UNet)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, act, chan_bias):
+    def forward(ctx, x, weight, bias, groups, eps, act, chan_bias, with_alias=False):
         require_cuda(x, weight, bias, chan_bias)
         if x.dim() != 4:
             raise GaError("GroupNormAct expects a (B, C, H, W) tensor")
@@ -696,27 +699,36 @@ class GroupNormAct(torch.autograd.Function):
               "ga_group_norm_fwd")
         ctx.save_for_backward(x, weight, bias, stats, chan_bias)
         ctx.meta = (groups, bool(act))
+        if with_alias:
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_alias=None):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise GaError("GroupNorm weight gradients are not part of the guided-attention path (frozen UNet)")
+        if dy is None:           # only the alias was differentiated
+            return g_alias, None, None, None, None, None, None, None
         x, weight, bias, stats, chan_bias = ctx.saved_tensors
         groups, act = ctx.meta
         B, C, H, W = x.shape
         dy = _nhwc(dy)
+        if g_alias is not None:
+            g_alias = _nhwc(g_alias)
         dx = torch.empty_like(x, memory_format=torch.channels_last)
         ws = torch.empty((B * 257 * groups * 2,), dtype=torch.float32, device=x.device)
         _count(("group_norm_bwd", B, groups, H * W, 0, C, bool(act), str(x.dtype)))
-        check(load().ga_group_norm_bwd(_ptr(x), _ptr(chan_bias), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(stats), _ptr(dx),
-                                       _ptr(ws), B, H * W, C, groups, int(act), dtype_code(x), stream_ptr()),
+        check(load().ga_group_norm_bwd(_ptr(x), _ptr(chan_bias), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(stats),
+                                       _ptr(g_alias), _ptr(dx), _ptr(ws), B, H * W, C, groups, int(act), dtype_code(x),
+                                       stream_ptr()),
               "ga_group_norm_bwd")
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
-def group_norm_act(x, weight, bias, groups, eps, act, chan_bias=None):
-    return GroupNormAct.apply(x, weight, bias, groups, eps, act, chan_bias)
+def group_norm_act(x, weight, bias, groups, eps, act, chan_bias=None, with_alias=False):
+    """-> y, or (y, x) with with_alias (use that x for the skip connection: see GroupNormAct)."""
+    return GroupNormAct.apply(x, weight, bias, groups, eps, act, chan_bias, with_alias)
 
 
 # --------------------------------------------------------------------------------------- feed-forward / residual epilogues
@@ -958,6 +970,61 @@ def conv3x3_nhwc(x, wp, cout, stride=1, bias=None, residual=None, plan=None):
     return y
 
 
+GA_ERR_SHAPE = -2   # include/ga_hip.h
+_no_fused_upsample = set()   # (B, H, W, Cin, Cout, dtype) the patch kernel does not serve: the caller up-samples itself
+
+
+def conv3x3_up2x_nhwc(x, wp, cout, bias=None, plan=None):
+    """conv3x3(nearest-neighbour 2x up-sampling of x) without the up-sampled tensor (ga_conv3x3_up2x_nhwc), or None when the
+    shape is not served by the patch kernel."""
+    require_cuda(x, wp, bias)
+    x = _nhwc(x)
+    B, Cin, H, W = x.shape
+    key = (B, H, W, Cin, cout, x.dtype)
+    if key in _no_fused_upsample:
+        return None
+    bm, bn, splits = (plan or conv3x3_plan(B, 2 * H, 2 * W, Cin, cout, 1))[:3]
+    y = torch.empty((B, cout, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    ws, tickets = splitk_workspace(x.device, B * 4 * H * W, cout, bm, bn, splits)
+    rc = load().ga_conv3x3_up2x_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(tickets), _ptr(bias), None, B, H, W, Cin,
+                                     cout, bm, bn, splits, dtype_code(x), stream_ptr())
+    if rc == GA_ERR_SHAPE:
+        _no_fused_upsample.add(key)
+        return None
+    check(rc, "ga_conv3x3_up2x_nhwc")
+    _count(("conv3x3", B, Cin, 4 * H * W, 1, cout, bias is not None, str(x.dtype)))
+    return y
+
+
+class UpsampleConv3x3(torch.autograd.Function):
+    """y = conv2d(interpolate(x, scale_factor=2, mode="nearest"), weight, padding=1) + bias (diffusers 0.12.1 Upsample2D)
+    in one launch; backward: the stride-1 backward-to-input kernel, then the 2x2 sums of the up-sampling's adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
+            raise GaError("convolution weight gradients are not part of the guided-attention path (frozen UNet)")
+        y = conv3x3_up2x_nhwc(x, conv3x3_packed_weights(weight, False), weight.shape[0], bias)
+        if y is None:
+            up = torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest")
+            y = conv3x3_nhwc(up, conv3x3_packed_weights(weight, False), weight.shape[0], 1, bias)
+        ctx.weight, ctx.in_shape = weight, tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        g_up = conv3x3_nhwc(_nhwc(gy), conv3x3_packed_weights(ctx.weight, True), ctx.weight.shape[1], 1)
+        B, C, H, W = ctx.in_shape
+        gx = torch.ops.aten.upsample_nearest2d_backward(g_up, [2 * H, 2 * W], [B, C, H, W], 2.0, 2.0)
+        return gx, None, None
+
+
+def upsample_conv3x3(x, weight, bias=None):
+    return UpsampleConv3x3.apply(x, weight, bias)
+
+
 class Conv3x3(torch.autograd.Function):
     """y = conv2d(x, weight, bias=None, padding=1, stride) (+ bias + residual) on channels-last 16-bit activations.
     Differentiable w.r.t. x (stride 1: the same kernel on the flipped / transposed pack) and the residual; the weights
@@ -977,6 +1044,9 @@ class Conv3x3(torch.autograd.Function):
     def backward(ctx, gy):
         weight, stride = ctx.weight, ctx.stride
         gx = None
+        # ONE dense copy when the gradient is a strided view (a channel slice of a concatenation's gradient): the kernel below
+        # and the skip connection's consumer (ga_group_norm_bwd's g_res) both read it
+        gy = _nhwc(gy)
         if ctx.needs_input_grad[0]:
             if stride == 1:
                 gx = conv3x3_nhwc(gy, conv3x3_packed_weights(weight, True), weight.shape[1], 1)
@@ -990,6 +1060,7 @@ def conv3x3(x, weight, bias=None, residual=None, stride=1):
 
 
 conv3x3.supported = conv3x3_supported
+conv3x3.upsample = upsample_conv3x3
 
 
 # --------------------------------------------------------------------------------------- tiled self-attention

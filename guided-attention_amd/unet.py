@@ -9,6 +9,7 @@ Every attention layer dispatches to an *attention processor* with the reference'
 The default processor is the HIP one (no CPU fallback).
 """
 import math
+import os
 from dataclasses import dataclass, field
 from types import SimpleNamespace
 from typing import Optional, Tuple, Union
@@ -127,6 +128,11 @@ class Attention(nn.Module):
         return proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask)
 
 
+# A/B switches for measurements (tools/unet_bench.py): GA_FUSE_UPSAMPLE=0 / GA_GN_ALIAS=0 restore the separate launches
+_FUSE_UPSAMPLE = os.environ.get("GA_FUSE_UPSAMPLE", "1") != "0"
+_GN_ALIAS = os.environ.get("GA_GN_ALIAS", "1") != "0"
+
+
 class GroupNormAct(nn.GroupNorm):
     """GroupNorm with an optional fused SiLU.  Same parameters / state_dict keys as nn.GroupNorm.  `impl` is a
     callable (x, weight, bias, groups, eps, act) -> y installed by the GPU pipeline (the channels-last HIP
@@ -137,14 +143,22 @@ class GroupNormAct(nn.GroupNorm):
         self.act = act
         self.impl = None
 
-    def forward(self, x, chan_bias=None):
-        """chan_bias (B, C), optional: normalise x + chan_bias[:, :, None, None] (folded into the kernels)."""
+    def forward(self, x, chan_bias=None, with_alias=False):
+        """chan_bias (B, C), optional: normalise x + chan_bias[:, :, None, None] (folded into the kernels).
+        with_alias: -> (y, x) where the returned x is what the block's skip connection must consume: with the HIP
+        kernels and a differentiated input it is an alias produced by the norm's autograd node, so the skip connection's
+        gradient is added inside the norm's backward kernel (ops.GroupNormAct); otherwise x itself."""
         if self.impl is not None:
-            return self.impl(x, self.weight, self.bias, self.num_groups, self.eps, self.act, chan_bias)
+            if with_alias and _GN_ALIAS and x.requires_grad and torch.is_grad_enabled():
+                return self.impl(x, self.weight, self.bias, self.num_groups, self.eps, self.act, chan_bias, True)
+            y = self.impl(x, self.weight, self.bias, self.num_groups, self.eps, self.act, chan_bias)
+            return (y, x) if with_alias else y
+        x_in = x
         if chan_bias is not None:
             x = x + chan_bias[:, :, None, None]
         y = super().forward(x)
-        return F.silu(y) if self.act else y
+        y = F.silu(y) if self.act else y
+        return (y, x_in) if with_alias else y
 
 
 def conv3x3(x, conv, impl, residual=None, with_bias=True):
@@ -267,8 +281,8 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, context):
         b, c, h, w = x.shape
-        res = x
-        x = nchw_to_tokens(self.norm(x))
+        x, res = self.norm(x, with_alias=True)   # res: the skip connection's view of the input (see GroupNormAct.forward)
+        x = nchw_to_tokens(x)
         blocks = self.transformer_blocks
         lin = blocks[0].lin_impl
         if lin is not None and x.is_contiguous() and lin.supported(x, c, blocks[0].norm1.normalized_shape[0]) and \
@@ -305,7 +319,8 @@ class ResnetBlock2D(nn.Module):
         block's time_emb_proj(temb_act) already evaluated (all blocks in one GEMM)."""
         # norm1 / norm2 carry the SiLU.  conv1's bias rides on the time projection (one add instead of two): the
         # UNet's batched projection already contains it; the stand-alone path adds it here
-        h = conv3x3(self.norm1(x), self.conv1, self.conv_impl, with_bias=False)
+        h, x = self.norm1(x, with_alias=True)   # x: the skip connection's view of the input (see GroupNormAct.forward)
+        h = conv3x3(h, self.conv1, self.conv_impl, with_bias=False)
         if isinstance(temb_act, dict):
             tproj = temb_act[id(self)]
         else:
@@ -347,6 +362,10 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(channels, channels, 3, padding=1)
 
     def forward(self, x, output_size=None):
+        impl = self.conv_impl
+        if output_size is None and impl is not None and getattr(impl, "upsample", None) is not None and _FUSE_UPSAMPLE and \
+                impl.supported(x, self.conv.weight, 1):
+            return impl.upsample(x, self.conv.weight, self.conv.bias)   # the up-sampling happens in the patch gather
         if output_size is None:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         else:

@@ -217,14 +217,16 @@ int ga_self_attn_bwd(const void* Q, const void* K, const void* V, const void* O,
  *   C <= 2560.  chan_bias (optional, [B][C] T): the layer normalises x + chan_bias[b][c] — the ResnetBlock's
  *   time-embedding term folded into the norm instead of a separate broadcast-add pass; it receives no gradient.
  *   gamma/beta gradients are not produced (weights are frozen on this path).
+ *   g_res (optional, like dx): the gradient that reaches x through its OTHER consumer (the block's skip connection);
+ *   dx = group-norm backward + g_res in the same pass instead of a separate accumulation launch.
  */
 #define GA_GN_WORKSPACE_FLOATS(B, G) ((B) * 257 * (G) * 2)
 int ga_group_norm_fwd(const void* x, const void* chan_bias, const void* gamma, const void* beta, void* y, float* stats,
                       float* workspace, int B, int HW, int C, int G, float eps, int act_silu, int dtype,
                       ga_stream_t stream);
 int ga_group_norm_bwd(const void* x, const void* chan_bias, const void* dy, const void* gamma, const void* beta,
-                      const float* stats, void* dx, float* workspace, int B, int HW, int C, int G, int act_silu,
-                      int dtype, ga_stream_t stream);
+                      const float* stats, const void* g_res, void* dx, float* workspace, int B, int HW, int C, int G,
+                      int act_silu, int dtype, ga_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * UNet host helpers: element-wise epilogues of the transformer feed-forward and the ResnetBlock (diffusers 0.12.1
@@ -262,6 +264,11 @@ int ga_bias_residual_add(const void* y, const void* bias, const void* residual, 
  *                             that arrives last sums them in slice order (bitwise reproducible) and writes Y — ONE
  *                             launch.  `tickets`: ceil(M / bm) * ceil(Cout / bn) 32-bit words, ZERO on entry; the kernel
  *                             leaves them zero.  Launches sharing workspace / tickets must be stream-ordered.
+ *   ga_conv3x3_up2x_nhwc    : Y [B][2H][2W][Cout] = conv(nearest-neighbour 2x up-sampling of X [B][H][W][Cin], Wp), stride 1
+ *                             (diffusers 0.12.1 Upsample2D.forward: F.interpolate(scale_factor=2, mode="nearest") + conv):
+ *                             the patch gather reads pixel (y >> 1, x >> 1); the up-sampled map is never written.  Plan as
+ *                             for a [B][2H][2W] input.  GA_ERR_SHAPE when the shape is not served by the patch kernel (the
+ *                             caller up-samples itself and calls ga_conv3x3_nhwc).
  */
 long long ga_splitk_workspace_floats(int64_t M, int N, int bm, int bn, int splits);
 long long ga_conv3x3_packed_elems(int N, int C);
@@ -272,6 +279,9 @@ int ga_conv3x3_plan(int B, int H, int W, int Cin, int Cout, int stride, int* bm,
 int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets, const void* bias,
                     const void* residual, int B, int H, int W, int Cin, int Cout, int stride, int bm, int bn, int splits,
                     int dtype, ga_stream_t stream);
+int ga_conv3x3_up2x_nhwc(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets, const void* bias,
+                         const void* residual, int B, int H, int W, int Cin, int Cout, int bm, int bn, int splits, int dtype,
+                         ga_stream_t stream);
 
 /* Linear layers / 1x1 convolutions of the UNet (diffusers 0.12.1 CrossAttention.to_q/to_k/to_v/to_out, FeedForward,
  * Transformer2DModel.proj_in/proj_out, ResnetBlock2D.conv_shortcut — called from pipeline_guided_attention.py:647-738

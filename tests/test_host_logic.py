@@ -310,3 +310,23 @@ def test_kv_cache_pins_survive_eviction():
     for ctx in others:
         ptp_utils.cached_context_projections(attn, ctx + 1)
     assert len(attn.__dict__["_kv_cache"]) == ptp_utils.KV_CACHE_ENTRIES
+
+
+def test_transposed_weight_cache_outlives_the_view_it_was_asked_with():
+    """fused_linear._transposed: the cached W^T of a 1x1 convolution's weight must survive the (out, in) VIEW it was
+    requested with (a fresh view per call) and die with the parameter: tied to the view, every guidance backward
+    transposed the 27 projection / shortcut weights again (round 3)."""
+    import gc
+    import torch
+    from guided_attention_amd import fused_linear
+    conv = torch.nn.Conv2d(8, 16, 1)
+    t1 = fused_linear._transposed(fused_linear.conv1x1_weight(conv))
+    gc.collect()
+    t2 = fused_linear._transposed(fused_linear.conv1x1_weight(conv))
+    assert t1 is t2 and torch.equal(t1, conv.weight.reshape(16, 8).t())
+    with torch.no_grad():
+        conv.weight.add_(1.0)                       # a new version: re-built
+    t3 = fused_linear._transposed(fused_linear.conv1x1_weight(conv))
+    assert t3 is not t1 and torch.equal(t3, conv.weight.reshape(16, 8).t())
+    lin = torch.nn.Linear(8, 16)
+    assert fused_linear._transposed(lin.weight) is fused_linear._transposed(lin.weight)

@@ -591,6 +591,50 @@ def test_group_norm_act(ops, shape, act, dt):
     yr2.backward(g.double().cpu())
     close(y3, yr2.detach().numpy(), TOL[dt] * 2, "y with channel bias")
     close(xb.grad, xr2.grad.numpy(), TOL[dt] * 3, "dx with channel bias")
+    # with_alias: the second output is x for the block's skip connection; its gradient is added inside the backward kernel
+    g2 = dev(hashrand.normalish(shape, 12) * 0.8, DT[dt]).contiguous(memory_format=torch.channels_last)
+    xc = x.clone().requires_grad_(True)
+    y4, x_alias = ops.group_norm_act(xc, w, b, 32, 1e-5, act, cb, True)
+    assert torch.equal(y4, y3.detach()) and torch.equal(x_alias.detach(), x)
+    torch.autograd.backward([y4, x_alias], [g, g2])
+    close(xc.grad, xr2.grad.numpy() + g2.double().cpu().numpy(), TOL[dt] * 3, "dx + skip-connection gradient")
+    xd = x.clone().requires_grad_(True)
+    _, only_alias = ops.group_norm_act(xd, w, b, 32, 1e-5, act, cb, True)
+    only_alias.backward(g2)                                    # the norm's own output unused: the alias gradient passes through
+    assert torch.equal(xd.grad, g2)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 128, 64, 8, 8), (2, 64, 128, 16, 16), (1, 192, 64, 32, 32), (3, 64, 64, 4, 4), (1, 64, 64, 12, 20),
+                                   (2, 64, 64, 2, 2)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_upsample_conv3x3_in_one_launch(ops, shape, dt):
+    """ga_conv3x3_up2x_nhwc (diffusers Upsample2D: nearest 2x + conv3x3 + bias, the up-sampled map never written) and its
+    autograd wrapper against interpolate + conv2d in fp64 on the CPU, forward and backward to the input.  Shapes the patch
+    kernel does not serve (4x4 -> 8x8 maps here are served, 6-wide ones would not) take the two-launch fallback inside the
+    wrapper: same result either way."""
+    B, Cin, Cout, H, W = shape
+    ops._no_fused_upsample.clear()
+    x = dev(hashrand.normalish((B, Cin, H, W), 71 + Cin), DT[dt]).contiguous(memory_format=torch.channels_last)
+    w = dev(hashrand.normalish((Cout, Cin, 3, 3), 72 + Cout) * (1.0 / math.sqrt(9 * Cin)), DT[dt])
+    bias = dev(hashrand.normalish((Cout,), 73) * 0.3, DT[dt])
+    gy = dev(hashrand.normalish((B, Cout, 2 * H, 2 * W), 74), DT[dt]).contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(True)
+    y = ops.upsample_conv3x3(xa, w, bias)
+    y.backward(gy)
+    xr = x.double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(torch.nn.functional.interpolate(xr, scale_factor=2.0, mode="nearest"), w.double().cpu(),
+                                    bias.double().cpu(), padding=1)
+    yr.backward(gy.double().cpu())
+    close(y, yr.detach().numpy(), TOL[dt] * 2, "y")
+    close(xa.grad, xr.grad.numpy(), TOL[dt] * 3, "dx")
+    # the one-launch form itself, bit-identical to the two-launch form on the same kernel where it is served
+    wp = ops.conv3x3_packed_weights(w, False)
+    fused = ops.conv3x3_up2x_nhwc(x, wp, Cout, bias)
+    if fused is not None:
+        up = torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest")
+        assert torch.equal(fused, ops.conv3x3_nhwc(up, wp, Cout, 1, bias))
+    assert (fused is not None) == (min(2 * H, 2 * W) >= 8), "which shapes the patch kernel serves changed: update this test"
 
 
 # ------------------------------------------------------------------------------------- GEGLU, bias + residual
