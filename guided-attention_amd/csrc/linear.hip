@@ -122,16 +122,36 @@ __device__ __forceinline__ void wait_lgkmcnt() {
 #endif
 }
 
-// gelu(g) = g/2 (1 + erf(g / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, three orders below the
-// 16-bit output's resolution): one v_rcp, one v_exp and six FMAs.  erff() costs several times that, and with five k-steps
-// of MFMAs per tile the GEGLU epilogue — 32 gelu per thread and tile — took longer than the tile's matrix work (the
-// 12288 x 320 x 2560 call: 58 us with erff).
-__device__ __forceinline__ float gelu_erf(float g) {
-  const float x = fabsf(g) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * x);
-  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-  const float erf_abs = 1.0f - poly * __expf(-x * x);
-  return 0.5f * g * (1.0f + copysignf(erf_abs, g));
+// gelu(g) = g/2 (1 + erf(g / sqrt 2)); erff() made the epilogue longer than the tile's matrix work (the 12288 x 320 x 2560
+// call: 58 us with erff).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Two gelu at a time on the packed-f32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth per issue):
+// erf(x) = x P(x^2) / Q(x^2) on [-4, 4] (the rational approximation XLA / Eigen use for f32: |err| <= 4.5e-7, constant beyond
+// |x| = 4 where 1 - |erf| < 2e-8), one v_rcp per element and no v_exp.  The first form here — Abramowitz-Stegun 7.1.26: one v_rcp,
+// one v_exp and scalar FMAs per element — cost about 84 issue cycles per element and wave against about 45 for this one; with
+// five k-steps of MFMAs per tile the GEGLU epilogue (32 gelu per thread and tile) is as long as the tile's matrix work.
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 g) {
+  const f32x2 lim = {4.0f, 4.0f};
+  f32x2 x = g * 0.70710678118654752f;
+  x = __builtin_elementwise_min(__builtin_elementwise_max(x, -lim), lim);
+  const f32x2 x2 = x * x;
+  auto c = [](float v) { return f32x2{v, v}; };
+  f32x2 p = c(-2.72614225801306e-10f);
+  p = __builtin_elementwise_fma(p, x2, c(2.77068142495902e-08f));
+  p = __builtin_elementwise_fma(p, x2, c(-2.10102402082508e-06f));
+  p = __builtin_elementwise_fma(p, x2, c(-5.69250639462346e-05f));
+  p = __builtin_elementwise_fma(p, x2, c(-7.34990630326855e-04f));
+  p = __builtin_elementwise_fma(p, x2, c(-2.95459980854025e-03f));
+  p = __builtin_elementwise_fma(p, x2, c(-1.60960333262415e-02f));
+  f32x2 q = c(-1.45660718464996e-05f);
+  q = __builtin_elementwise_fma(q, x2, c(-2.13374055278905e-04f));
+  q = __builtin_elementwise_fma(q, x2, c(-1.68282697438203e-03f));
+  q = __builtin_elementwise_fma(q, x2, c(-7.37332916720468e-03f));
+  q = __builtin_elementwise_fma(q, x2, c(-1.42647390514189e-02f));
+  const f32x2 rq = {__frcp_rn(q.x), __frcp_rn(q.y)};
+  const f32x2 erf = x * p * rq;
+  const f32x2 hg = g * 0.5f;
+  return __builtin_elementwise_fma(hg, erf, hg);
 }
 
 // Epilogue of both kernels: bias / LayerNorm algebra in registers, the tile through LDS (`Cs`, BM x (BN + 8) elements that no
@@ -209,7 +229,11 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
       const uint4 gv = *reinterpret_cast<const uint4*>(Cs + r * LDC + BN / 2 + cv);
       const T* ge = reinterpret_cast<const T*>(&gv);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) e[k] = Traits<T>::from_f32(Traits<T>::to_f32(e[k]) * gelu_erf(Traits<T>::to_f32(ge[k])));
+      for (int k = 0; k < 8; k += 2) {
+        const f32x2 gl = gelu_erf2(f32x2{Traits<T>::to_f32(ge[k]), Traits<T>::to_f32(ge[k + 1])});
+        e[k] = Traits<T>::from_f32(Traits<T>::to_f32(e[k]) * gl.x);
+        e[k + 1] = Traits<T>::from_f32(Traits<T>::to_f32(e[k + 1]) * gl.y);
+      }
     } else if (residual != nullptr && ok) {
       const uint4 rv = *reinterpret_cast<const uint4*>(residual + (size_t)m * a.ld_res + n);
       const T* re = reinterpret_cast<const T*>(&rv);
