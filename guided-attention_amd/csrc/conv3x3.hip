@@ -977,11 +977,17 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, con
   const bool geom_ok = a.pad == 1 && a.stride == 1 && (a.W >= 16 || (a.W >= 8 && use_dma() && deep_ring())) && !force_v1();
   const bool patch = geom_ok && patch_geometry(BM, a.H, a.W, pg);
   const bool patch_wide = geom_ok && !patch && (BN <= 64 || BM == 128) && patch_geometry(BM, a.H, a.W, pg, true);
-  if (a.up && !((patch || patch_wide) && use_dma())) return GA_ERR_SHAPE;   // only the patch-DMA kernel gathers from the half-size map
+  // Tiles that are RUNS of pixels (start mid-row, wrap around the row ends: the 96 / 48 / 24-wide maps of the 768^2
+  // configuration) stay on the register-staged patch kernel: the DMA-ring form measured 6 - 20 % slower on the 48-wide level
+  // and up to 17 % on the 24-wide one (profiles/r3_conv_tune_sd21.txt; equal at 96 and 12), and equal-or-faster only where a
+  // tile is whole rows or whole images (every level of the 512^2 configuration)
+  const bool run_geom = BM % a.W != 0 && BM % (a.H * a.W) != 0;
+  const bool dma = use_dma() && !(run_geom && a.W >= 16);   // below 16 only the DMA form has a patch variant at all (see geom_ok)
+  if (a.up && !((patch || patch_wide) && dma)) return GA_ERR_SHAPE;   // only the patch-DMA kernel gathers from the half-size map
   if (patch_wide) {   // the 13-piece instantiation: one row of a 128-wide map, or a run of a 96- / 48-wide map (geometry 3)
     a.steps_per = (a.Cin / kKC + splits - 1) / splits;
     if constexpr (BN <= 64 || BM == 128) {
-      if (use_dma()) {
+      if (dma) {
         if (splits == 1)
           hipLaunchKernelGGL((conv3x3_patch_dma_kernel<T, BM, BN, false, true>), grid, dim3(kThreads), 0, s, X, Wp, Y,
                              (float*)nullptr, (unsigned*)nullptr, bias, residual, a);
@@ -1002,7 +1008,7 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, con
     a.steps_per = (a.Cin / kKC + splits - 1) / splits;   // this variant splits the depth by channel chunks
     a.lane_rot = a.W == 16 ? 2 : 0;
   }
-  if (patch && use_dma()) {
+  if (patch && dma) {
     // weight-bound launch (few pixels against tens of MB of weights) with about one workgroup per CU: the deep ring
     const bool deep = a.M <= 1024 && (long long)a.tm * a.tn * splits <= 384 && deep_ring();
     if (deep) {

@@ -153,7 +153,7 @@ def replay_launch_us(key, iters=100):
                    for i in range(nt)]
         plan = LossPlan(entries, {"inside_loss_scale": .2, "outside_loss_scale": .2, "shrink_factor": .15})
         heads_all = max(H, 1)
-        per = 8 if heads_all % 8 == 0 else heads_all
+        per = D if D and heads_all % D == 0 else (8 if heads_all % 8 == 0 else heads_all)   # heads per stored tensor, as counted
         maps = [torch.softmax(torch.randn(per, npix, Kt, device=dev), -1).to(dtype) for _ in range(heads_all // per)]
         A = torch.softmax(torch.randn(npix, Kt, device=dev), -1)
         if kind == "aggregate_maps":
@@ -429,7 +429,7 @@ def aggregate_maps(maps):
     ptrs = (ctypes.c_void_p * n)(*[m.data_ptr() for m in maps])
     heads = (ctypes.c_int * n)(*[m.shape[0] for m in maps])
     A = torch.empty((npix, Kt), dtype=torch.float32, device=maps[0].device)
-    _count(("aggregate_maps", n, sum(m.shape[0] for m in maps), npix, Kt, 0, False, str(maps[0].dtype)))
+    _count(("aggregate_maps", n, sum(m.shape[0] for m in maps), npix, Kt, maps[0].shape[0], False, str(maps[0].dtype)))
     check(load().ga_aggregate_maps(ptrs, heads, n, npix, Kt, _ptr(A), dtype_code(maps[0]), stream_ptr()),
           "ga_aggregate_maps")
     return A
@@ -593,7 +593,7 @@ def aggregate_loss_fwd(maps, res, first, last, plan):
     A = torch.empty((npix, Kt), dtype=torch.float32, device=dev)
     terms = torch.empty((plan.T, _lib.GA_TERMS), dtype=torch.float32, device=dev)
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
-    _count(("aggregate_loss_fwd", plan.T, sum(m.shape[0] for m in maps), npix, Kt, 0, False, str(maps[0].dtype)))
+    _count(("aggregate_loss_fwd", plan.T, sum(m.shape[0] for m in maps), npix, Kt, maps[0].shape[0], False, str(maps[0].dtype)))
     check(load().ga_aggregate_loss_fwd(ptrs, heads, n, res, Kt, first, last, plan.tokens, plan.T, ctypes.byref(plan.params),
                                        _ptr(A), _ptr(terms), _ptr(loss), _ptr(_ticket(dev)), dtype_code(maps[0]),
                                        stream_ptr()), "ga_aggregate_loss_fwd")
@@ -911,12 +911,16 @@ def conv3x3_plan(B, H, W, Cin, Cout, stride):
         hit = _measured_conv_plans().get((B * Ho * Wo, Cin, Cout, stride))
         if hit is not None:
             bm, bn, sp = hit
-            plan = _conv_plan_cache[key] = (bm, bn, sp, int(load().ga_splitk_workspace_floats(B * Ho * Wo, Cout, bm, bn, sp)))
-            return plan
-        bm, bn, sp, ws = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
-        check(load().ga_conv3x3_plan(B, H, W, Cin, Cout, stride, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp),
-                                     ctypes.byref(ws)), "ga_conv3x3_plan")
-        plan = _conv_plan_cache[key] = (bm.value, bn.value, sp.value, ws.value)
+        else:
+            c_bm, c_bn, c_sp, c_ws = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+            check(load().ga_conv3x3_plan(B, H, W, Cin, Cout, stride, ctypes.byref(c_bm), ctypes.byref(c_bn), ctypes.byref(c_sp),
+                                         ctypes.byref(c_ws)), "ga_conv3x3_plan")
+            bm, bn, sp = c_bm.value, c_bn.value, c_sp.value
+        # the slices' f32 slabs live in the persistent per-device scratch: a plan never asks for more than it holds
+        floats = lambda k: int(load().ga_splitk_workspace_floats(B * Ho * Wo, Cout, bm, bn, k))  # noqa: E731
+        while sp > 1 and floats(sp) > LIN_SLAB_FLOATS:
+            sp -= 1
+        plan = _conv_plan_cache[key] = (bm, bn, sp, floats(sp))
     return plan
 
 
@@ -1164,7 +1168,7 @@ def self_attention_supported(q, heads, channels=None):
 _lin_ws = {}        # device index -> {"slabs": f32 tensor, "tickets": int32 tensor}; never freed (captured graphs hold the pointers)
 _lin_plan_cache = {}
 _lin_plan_table = None
-LIN_SLAB_FLOATS = 16 * 2 ** 20     # 64 MB of split-K slabs per device, allocated once (outside any capture)
+LIN_SLAB_FLOATS = 64 * 2 ** 20     # 256 MB of split-K slabs per device (of 288 GB), allocated once (outside any capture)
 LIN_TICKETS = 1 << 16
 
 
@@ -1229,8 +1233,8 @@ def linear_plan(M, K, N, geglu=False):
                 tiles = -(-M // bm) * -(-n_out // outc)
                 waste = (-(-M // bm) * bm) * (-(-n_out // outc) * outc) / (M * n_out)
                 for sp in (1, 2, 3, 4, 6, 8, 12, 16):
-                    if sp > 1 and steps // sp < 4:
-                        break
+                    if sp > 1 and (steps // sp < 4 or sp * tiles * bm * bn > LIN_SLAB_FLOATS or tiles > LIN_TICKETS):
+                        break     # too shallow a slice, or more slabs / tickets than the persistent scratch holds
                     wgs = tiles * sp
                     rounds = -(-wgs // 256)
                     per_wg = -(-steps // sp) * (0.09 if bm * bn == 128 * 128 else 0.055 if bm * bn == 128 * 64 else 0.04)

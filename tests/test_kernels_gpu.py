@@ -604,6 +604,23 @@ def test_group_norm_act(ops, shape, act, dt):
     assert torch.equal(xd.grad, g2)
 
 
+def test_conv_plans_fit_the_persistent_split_k_scratch(ops):
+    """The planner's split-K factor never asks for more f32 slabs than ops.LIN_SLAB_FLOATS holds — BASELINE configs 4 and 5
+    (768^2 SD-2.1, SDXL) have 1280-channel convolutions at 6912 / 12288 pixels whose three slices need 26 - 47 M floats (the
+    round-3 scratch of 16 M made `bench.py --model sd21 / sdxl` fail) — and such a convolution runs through the default plan."""
+    for B, H, Cin, Cout in ((3, 48, 1280, 1280), (3, 64, 1280, 1280), (3, 96, 640, 640), (3, 128, 320, 320), (2, 48, 2560, 1280)):
+        bm, bn, sp, floats = ops.conv3x3_plan(B, H, H, Cin, Cout, 1)
+        assert floats <= ops.LIN_SLAB_FLOATS and -(-B * H * H // bm) * -(-Cout // bn) <= ops.LIN_TICKETS, (B, H, Cin, Cout, bm, bn, sp)
+    x = dev(hashrand.normalish((3, 1280, 48, 48), 81), torch.half).contiguous(memory_format=torch.channels_last)
+    w = dev(hashrand.normalish((1280, 1280, 3, 3), 82) * (1.0 / math.sqrt(9 * 1280)), torch.half)
+    y = ops.conv3x3(x, w)
+    ref = torch.nn.functional.conv2d(x[:1, :, :12, :12].float(), w.float(), padding=1)[:, :, 1:-1, 1:-1]
+    got = y[:1, :, 1:11, 1:11].float()
+    assert (got - ref).abs().max().item() <= 4e-3 * ref.abs().max().item()
+    up = ops.upsample_conv3x3(x[:, :, :24, :24].contiguous(memory_format=torch.channels_last), w)     # 24 -> 48: the same plan
+    assert tuple(up.shape) == (3, 1280, 48, 48) and bool(torch.isfinite(up).all())
+
+
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(1, 128, 64, 8, 8), (2, 64, 128, 16, 16), (1, 192, 64, 32, 32), (3, 64, 64, 4, 4), (1, 64, 64, 12, 20),
                                    (2, 64, 64, 2, 2)],
@@ -634,7 +651,11 @@ def test_upsample_conv3x3_in_one_launch(ops, shape, dt):
     if fused is not None:
         up = torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest")
         assert torch.equal(fused, ops.conv3x3_nhwc(up, wp, Cout, 1, bias))
-    assert (fused is not None) == (min(2 * H, 2 * W) >= 8), "which shapes the patch kernel serves changed: update this test"
+    # served where the patch-DMA kernel runs: maps of 8 pixels and wider whose tiles are whole rows / whole images (tiles that
+    # are runs of pixels — here the 24 x 40 map — stay on the register-staged kernel, which gathers from a full-size input)
+    bm = ops.conv3x3_plan(B, 2 * H, 2 * W, Cin, Cout, 1)[0]
+    runs = bm % (2 * W) != 0 and bm % (4 * H * W) != 0 and 2 * W >= 16
+    assert (fused is not None) == (min(2 * H, 2 * W) >= 8 and not runs), "which shapes the fused form serves changed: update this test"
 
 
 # ------------------------------------------------------------------------------------- GEGLU, bias + residual

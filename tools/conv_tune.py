@@ -3,7 +3,7 @@
 ga_conv3x3_nhwc for every (tile, split-K) plan — forward; the stride-1 backward-to-input is the same kernel with
 Cin / Cout swapped, listed as its own shape.  hipGraph replay timing.  Prints a table and a JSON line.
 
-  conv_tune.py [batches, default 1,3] [cold] [small] [--write] [variants [all]]
+  conv_tune.py [batches, default 1,3] [cold] [small] [sd21 | sdxl] [--write] [variants [all]]
      cold    : own-kernel launches rotate over enough packed-weight copies to exceed the 256 MB Infinity Cache — in the
                pipeline a convolution's weights are cold (1.7 GB of UNet weights stream through between two uses) while its
                input was just written; warm timings favour plans with too few bytes in flight per CU
@@ -32,6 +32,14 @@ BASE_ALL = [  # (Cin, Cout, H, stride)
 BASE = BASE_ALL if "variants" not in sys.argv or "all" in sys.argv else [(320, 320, 64, 1), (640, 640, 32, 1), (1280, 1280, 16, 1), (1280, 1280, 8, 1)]
 if "small" in sys.argv:        # the weight-bound levels only (16 x 16 and 8 x 8 maps)
     BASE = [b for b in BASE_ALL if b[2] <= 16]
+if "sd21" in sys.argv:         # BASELINE config 4: the same UNet on 96 x 96 latents (768^2 images): maps of 96 / 48 / 24 / 12
+    BASE = [(ci, co, h * 3 // 2, st) for ci, co, h, st in BASE]
+if "sdxl" in sys.argv:         # BASELINE config 5: 128 x 128 latents, three levels (320 / 640 / 1280 channels at 128 / 64 / 32)
+    BASE = [(320, 320, 128, 1), (640, 320, 128, 1), (960, 320, 128, 1), (320, 960, 128, 1), (320, 640, 128, 1), (320, 320, 128, 2),
+            (320, 640, 64, 1), (640, 640, 64, 1), (1280, 640, 64, 1), (1920, 640, 64, 1), (960, 640, 64, 1), (640, 1280, 64, 1),
+            (640, 1920, 64, 1), (640, 960, 64, 1), (640, 640, 64, 2), (640, 640, 128, 1),
+            (640, 1280, 32, 1), (1280, 1280, 32, 1), (2560, 1280, 32, 1), (1920, 1280, 32, 1), (1280, 2560, 32, 1),
+            (1280, 1920, 32, 1), (1280, 1280, 64, 1)]
 
 
 def replay_us(fn, iters=20):

@@ -79,8 +79,15 @@ def cold(N, K, dev):
     return ws, nxt
 
 
+LEVELS = ((4096, 320), (1024, 640), (256, 1280), (64, 1280))          # SD-1.x at 512^2: (tokens, channels) per level
+if "sd21" in sys.argv:                                                   # BASELINE config 4: 96 x 96 latents
+    LEVELS = ((9216, 320), (2304, 640), (576, 1280), (144, 1280))
+if "sdxl" in sys.argv:                                                   # BASELINE config 5: attention at 64^2 / 32^2 only
+    LEVELS = ((4096, 640), (1024, 1280))
+
+
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for a in sys.argv[1:] if not a.startswith("--") and a not in ("sd21", "sdxl")]
     batches = [int(b) for b in (args[0] if args else "1,3").split(",")]
     mode = sys.argv[sys.argv.index("--mode") + 1] if "--mode" in sys.argv else "all"
     if "--mode" in sys.argv:
@@ -114,7 +121,7 @@ def main():
                 res = {p: replay_us(lambda: ops.linear_fused(x, nxt(), bias, plan=p), reps=2) for p in candidates(M, K, N, False)}
                 report("plain", M, K, N, t_lib, res, 2.0 * M * K * N, f"{M},{K},{N},0")
         if mode in ("fused", "all"):
-            for tok, C in ((4096, 320), (1024, 640), (256, 1280), (64, 1280)):
+            for tok, C in LEVELS:
                 M = B * tok
                 x = torch.randn(M, C, device=dev, dtype=torch.half)
                 g, b_ = torch.ones(C, device=dev, dtype=torch.half), torch.zeros(C, device=dev, dtype=torch.half)
