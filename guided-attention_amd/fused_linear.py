@@ -25,6 +25,12 @@ def supported(x, in_features, out_features):
             and x.stride(-1) == 1)
 
 
+def block_folds(x):
+    """Whether a transformer block on the token tensor x (B, N, C) should take the folded form: served at all, and not one of
+    the (tokens, channels) cases where the library form of the whole block was measured faster (ops.library_block)."""
+    return supported(x, x.shape[-1], x.shape[-1]) and not ops.library_block(x.numel() // x.shape[-1], x.shape[-1])
+
+
 def _transposed(weight):
     """W^T (in_features, out_features) contiguous, cached per weight version: dX = dY W is then the SAME NT kernel with W^T as
     its weight (the frozen UNet's Linear weights cost 0.7 GB twice — irrelevant beside 288 GB of HBM)."""

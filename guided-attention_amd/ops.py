@@ -1217,6 +1217,13 @@ def _measured_linear_plans():
     return _lin_plan_table
 
 
+def library_block(M, C):
+    """True when tools/linear_tune.py measured the LIBRARY form of a whole transformer block (hipBLASLt GEMMs + the separate
+    LayerNorm / GEGLU / residual kernels) faster than the folded ga_linear_fused form at M tokens x C channels — the long, wide
+    GEMMs of SDXL's 1280-channel level at batch 3 (K = 1280 - 5120, N up to 10240); key "M,C,-1,-1" of linear_plans.json."""
+    return bool(_measured_linear_plans().get((int(M), int(C), -1, -1), (0,))[0])
+
+
 def linear_plan(M, K, N, geglu=False):
     """(bm, bn, splits) for Y[M][N or N/2] = X[M][K] W[N][K]^T: the measured table (tools/linear_tune.py) or a rule:
     about one workgroup per CU and more; the depth is split when the tiles alone leave most of the chip idle."""

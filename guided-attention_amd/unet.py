@@ -231,7 +231,7 @@ class BasicTransformerBlock(nn.Module):
         """Whether this block takes the folded form for x: the module is installed, the dtype / widths are served and both
         attention processors understand the `folded` keyword (a foreign processor keeps the reference's protocol)."""
         lin = self.lin_impl
-        return (lin is not None and lin.supported(x, x.shape[-1], x.shape[-1]) and
+        return (lin is not None and lin.block_folds(x) and
                 all(getattr(a._processor(), "supports_folded_layer_norm", False) for a in (self.attn1, self.attn2)))
 
     def forward_folded(self, x, xp, context, want_partials):

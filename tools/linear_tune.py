@@ -151,6 +151,18 @@ def main():
                 res = {p: replay_us(lambda: ops.linear_fused(x, nxt(), None, geglu=True, ln=(partials, cs, sh, 1e-5), plan=p), reps=2)
                        for p in candidates(M, C, N // 2, True)}
                 report("geglu", M, C, N, t_lib, res, 2.0 * M * C * N, f"{M},{C},{N},1")
+    # whole transformer block per (tokens, channels): LN->qkv, to_out, LN->to_q, to_out, LN->GEGLU, FF out.  Where the library
+    # form of the block is more than 3 % faster the block keeps it (key "M,C,-1,-1", read by ops.library_block)
+    if mode in ("fused", "all"):
+        for B in batches:
+            for tok, C in LEVELS:
+                M = B * tok
+                rows = [table.get(f"ln,{M},{C},{3 * C}"), table.get(f"res,{M},{C},{C}"), table.get(f"ln,{M},{C},{C}"),
+                        table.get(f"res,{M},{C},{C}"), table.get(f"geglu,{M},{C},{8 * C}"), table.get(f"res,{M},{4 * C},{C}")]
+                if all(rows):
+                    own, lib_ = sum(r["best_us"] for r in rows), sum(r["lib_us"] for r in rows)
+                    print(f"block {M:>6} x {C:>5}: folded {own:7.1f} us, library form {lib_:7.1f} us -> {'library' if lib_ < 0.97 * own else 'folded'}")
+                    plans[f"{M},{C},-1,-1"] = [1 if lib_ < 0.97 * own else 0]
     print(f"own kernel at least as fast as the library form on {wins} of {total} cases (cold weights)")
     print(json.dumps(table))
     if "--write" in sys.argv:
