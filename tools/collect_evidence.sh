@@ -29,6 +29,11 @@ fi
 if want passes; then
 echo "[3] per-pass timings"; python tools/unet_bench.py > $out/unet_bench.txt 2>&1 || true
 grep -E "ms$|ms " $out/unet_bench.txt | head -8
+for pass in eval grad joint; do
+  rm -rf /tmp/ev_pass_$pass
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_pass_$pass -o p -- python3 tools/unet_bench.py only=$pass > $out/pass_$pass.txt 2>&1 || continue
+  python tools/trace_window_stats.py $(find /tmp/ev_pass_$pass -name "*kernel_trace.csv" | head -1) marker axpby 60 $out/pass_${pass}_stats.md "$pass pass: 60 hipGraph replays (tools/unet_bench.py only=$pass)" > /dev/null 2>&1 || true
+done
 fi
 if want models; then
 echo "[4] sd21 768^2 bench"; python bench.py --model sd21 --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_sd21_768.json 2> $out/bench_sd21.err || true

@@ -4,7 +4,10 @@ the window runs from the end of the last warm-up image to the end of the last ti
 `cfg_ddim_step` launches (one per CFG pass: `per_image` of them per image — unet_calls_per_image.fwd_b2).  Warm-up images,
 hipGraph capture, library algorithm searches and the roofline's micro-replays all fall outside the window.
 
-  trace_window_stats.py <kernel_trace.csv> <warmup images> <timed images> <cfg passes per image> <out.md> [title]"""
+  trace_window_stats.py <kernel_trace.csv> <warmup images> <timed images> <cfg passes per image> <out.md> [title]
+  trace_window_stats.py <kernel_trace.csv> marker <kernel substring> <replays> <out.md> [title]
+      the window after the LAST launch whose name holds the substring (tools/unet_bench.py only=<pass> launches a latent
+      axpby as the marker right before its timed replays): the kernels of `replays` replays of one captured pass"""
 import csv
 import sys
 
@@ -33,20 +36,33 @@ def cat(n):
 
 
 def main():
-    path, warm, timed, per_image, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    path, out = sys.argv[1], sys.argv[5]
     title = sys.argv[6] if len(sys.argv) > 6 else "kernel time inside the timed images"
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if "cfg_ddim" in r[2]]
-    need = (warm + timed) * per_image
-    if len(marks) < need:
-        raise SystemExit(f"only {len(marks)} cfg_ddim launches in the trace, expected at least {need}")
-    lo = marks[warm * per_image - 1] + 1 if warm else 0
-    hi = marks[need - 1]
-    win = rows[lo:hi + 1]
+    if sys.argv[2] == "marker":
+        marks = [i for i, r in enumerate(rows) if sys.argv[3] in r[2]]
+        if not marks:
+            raise SystemExit(f"no launch named *{sys.argv[3]}* in the trace")
+        timed = int(sys.argv[4])
+        win = rows[marks[-1] + 1:]
+        header = f"Window: {timed} replays of the captured pass (everything after the marker launch), {len(win)} launches"
+        unit = "replay"
+    else:
+        warm, timed, per_image = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+        marks = [i for i, r in enumerate(rows) if "cfg_ddim" in r[2]]
+        need = (warm + timed) * per_image
+        if len(marks) < need:
+            raise SystemExit(f"only {len(marks)} cfg_ddim launches in the trace, expected at least {need}")
+        lo = marks[warm * per_image - 1] + 1 if warm else 0
+        hi = marks[need - 1]
+        win = rows[lo:hi + 1]
+        header = (f"Window: {timed} timed image(s) after {warm} warm-up image(s) ({per_image} CFG passes per image), "
+                  f"{len(win)} launches")
+        unit = "image"
     span = win[-1][1] - win[0][0]
     per, cats = {}, {}
     for s, e, n in win:
@@ -60,8 +76,7 @@ def main():
         c[1] += e - s
     total = sum(d[1] for d in per.values())
     lines = [f"# {title}", "",
-             f"Window: {timed} timed image(s) after {warm} warm-up image(s) ({per_image} CFG passes per image), {len(win)} launches, "
-             f"span {span / 1e6:.1f} ms = {span / 1e6 / timed:.1f} ms per image, kernel time {total / 1e6:.1f} ms "
+             f"{header}, span {span / 1e6:.1f} ms = {span / 1e6 / timed:.3f} ms per {unit}, kernel time {total / 1e6:.1f} ms "
              f"({100 * total / span:.1f} % of the span; durations under the profiler read high).", "",
              "| category | total ms | % of kernel time | launches | avg us |", "|---|---:|---:|---:|---:|"]
     for c, (n, t) in sorted(cats.items(), key=lambda kv: -kv[1][1]):
