@@ -25,11 +25,6 @@ def supported(x, in_features, out_features):
             and x.stride(-1) == 1)
 
 
-def side_lane():
-    """Context for launches issued on the side stream: its own split-K scratch (ops.workspace_lane)."""
-    return ops.workspace_lane(1)
-
-
 def block_folds(x):
     """Whether a transformer block on the token tensor x (B, N, C) should take the folded form: served at all, and not one of
     the (tokens, channels) cases where the library form of the whole block was measured faster (ops.library_block)."""

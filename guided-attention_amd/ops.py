@@ -1172,44 +1172,14 @@ LIN_SLAB_FLOATS = 64 * 2 ** 20     # 256 MB of split-K slabs per device (of 288 
 LIN_TICKETS = 1 << 16
 
 
-_ws_lane = 0        # which scratch set the launches of this thread use: 0 = the main stream's, 1 = the side stream's (below)
-SIDE_SLAB_FLOATS = 8 * 2 ** 20    # the side lane serves the ResnetBlock 1x1 shortcuts only: 32 MB is several times their need
-
-
-class workspace_lane:
-    """Launches inside `with workspace_lane(1):` take the SECOND set of split-K slabs / tickets: kernels on a side stream run
-    concurrently with the main stream's, and two in-launch reductions must not share slabs or arrival counters."""
-
-    def __init__(self, lane):
-        self.lane = lane
-
-    def __enter__(self):
-        global _ws_lane
-        self.prev, _ws_lane = _ws_lane, self.lane
-
-    def __exit__(self, *exc):
-        global _ws_lane
-        _ws_lane = self.prev
-
-
 def linear_workspace(device):
-    ws = _lin_ws.get((device.index, _ws_lane))
+    ws = _lin_ws.get(device.index)
     if ws is None:
         if torch.cuda.is_current_stream_capturing():
             raise GaError("the Linear workspace must exist before a hipGraph capture (call ops.prepare_device first)")
-        floats = LIN_SLAB_FLOATS if _ws_lane == 0 else SIDE_SLAB_FLOATS
-        ws = _lin_ws[(device.index, _ws_lane)] = {"slabs": torch.empty(floats, dtype=torch.float32, device=device),
-                                                   "tickets": torch.zeros(LIN_TICKETS, dtype=torch.int32, device=device)}
+        ws = _lin_ws[device.index] = {"slabs": torch.empty(LIN_SLAB_FLOATS, dtype=torch.float32, device=device),
+                                      "tickets": torch.zeros(LIN_TICKETS, dtype=torch.int32, device=device)}
     return ws
-
-
-_side_streams = {}
-
-
-def side_stream(device):
-    """The per-device side stream on which independent small launches (the ResnetBlock shortcut GEMMs of the no-grad passes)
-    run beside the main chain; created with its scratch lane by prepare_device."""
-    return _side_streams.get(torch.device(device).index)
 
 
 def splitk_workspace(device, M, N, bm, bn, splits):
@@ -1231,10 +1201,6 @@ def prepare_device(device):
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         linear_workspace(device)
-        with workspace_lane(1):
-            linear_workspace(device)
-        if device.index not in _side_streams:
-            _side_streams[device.index] = torch.cuda.Stream(device=device)
         _ticket(device)
 
 
@@ -1346,11 +1312,8 @@ def linear_fused(x, weight, bias=None, residual=None, geglu=False, want_preact=F
         ws = linear_workspace(x.device)
         tiles = -(-M // bm) * parts
         if splits * tiles * bm * bn > ws["slabs"].numel() or tiles > ws["tickets"].numel():
-            if _ws_lane == 0:
-                raise GaError(f"split-K workspace too small for M={M} N={N} plan {(bm, bn, splits)}")
-            splits = 1        # the side lane's scratch is small: such a call runs its depth in one slice
-        else:
-            slabs, tickets = ws["slabs"], ws["tickets"]
+            raise GaError(f"split-K workspace too small for M={M} N={N} plan {(bm, bn, splits)}")
+        slabs, tickets = ws["slabs"], ws["tickets"]
     _count(("linear", M, K, 0, int(bool(geglu)) + 2 * int(ln is not None) + 4 * int(residual is not None), N, bias is not None,
             str(x.dtype)))
     check(load().ga_linear_fused(_ptr(x), ldx, _ptr(weight), _ptr(y), y.stride(-2) if y.dim() > 1 else n_out,

@@ -131,7 +131,6 @@ class Attention(nn.Module):
 # A/B switches for measurements (tools/unet_bench.py): GA_FUSE_UPSAMPLE=0 / GA_GN_ALIAS=0 restore the separate launches
 _FUSE_UPSAMPLE = os.environ.get("GA_FUSE_UPSAMPLE", "1") != "0"
 _GN_ALIAS = os.environ.get("GA_GN_ALIAS", "1") != "0"
-_SIDE_SHORTCUT = os.environ.get("GA_SIDE_SHORTCUT", "1") != "0"
 
 
 class GroupNormAct(nn.GroupNorm):
@@ -314,27 +313,12 @@ class ResnetBlock2D(nn.Module):
     add_impl = None   # fused conv2-bias + residual add (ops.bias_residual_add)
     conv_impl = None  # implicit-GEMM 3x3 convolution with bias / residual epilogue (ops.conv3x3)
     lin_impl = None   # fused_linear module: the 1x1 shortcut as ga_linear_fused
-    side_stream = None   # torch.cuda.Stream for the shortcut GEMM of the no-grad passes (ops.side_stream), None = serial
 
     def forward(self, x, temb_act):
         """temb_act = SiLU(time embedding), computed once per UNet forward; or the dict the UNet prepared with this
         block's time_emb_proj(temb_act) already evaluated (all blocks in one GEMM)."""
         # norm1 / norm2 carry the SiLU.  conv1's bias rides on the time projection (one add instead of two): the
         # UNet's batched projection already contains it; the stand-alone path adds it here
-        # No-grad passes (the CFG pair, the batch-3 joint pass): the 1x1 shortcut depends on the block's input only and runs on a
-        # SIDE stream beside norm1 -> conv1 -> norm2 (kernels of a few dozen workgroups that leave most of the chip idle); conv2
-        # waits for it.  Inside a hipGraph capture the fork / join become graph edges.  With autograd the block stays serial
-        # (the engine would replay the fork in the backward).
-        shortcut_side = None
-        sc = self.conv_shortcut
-        side = self.side_stream
-        if sc is not None and side is not None and _SIDE_SHORTCUT and not torch.is_grad_enabled() and self.lin_impl is not None and x.is_cuda:
-            xt = nchw_to_tokens(x)
-            if xt.is_contiguous() and self.lin_impl.supported(xt, sc.in_channels, sc.out_channels):
-                main = torch.cuda.current_stream(x.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side), self.lin_impl.side_lane():
-                    shortcut_side, _ = self.lin_impl.linear(xt, sc.weight.reshape(sc.out_channels, sc.in_channels), sc.bias)
         h, x = self.norm1(x, with_alias=True)   # x: the skip connection's view of the input (see GroupNormAct.forward)
         h = conv3x3(h, self.conv1, self.conv_impl, with_bias=False)
         if isinstance(temb_act, dict):
@@ -342,11 +326,7 @@ class ResnetBlock2D(nn.Module):
         else:
             tproj = self.time_emb_proj(temb_act) + self.conv1.bias
         h = self.norm2(h, chan_bias=tproj)  # the time term is added inside the norm's loads
-        if shortcut_side is not None:
-            _, _, hh, ww = x.shape
-            torch.cuda.current_stream(x.device).wait_stream(side)
-            x = tokens_to_nchw(shortcut_side, hh, ww)
-        elif self.conv_shortcut is not None:
+        if self.conv_shortcut is not None:
             _, _, hh, ww = x.shape
             xt = nchw_to_tokens(x)
             sc = self.conv_shortcut
@@ -662,7 +642,7 @@ class UNet2DConditionModel(nn.Module):
             if isinstance(m, GroupNormAct):
                 m.impl = impl
 
-    def set_fused_impl(self, geglu=None, bias_residual_add=None, layer_norms=None, conv=None, linear=None, side_stream=None):
+    def set_fused_impl(self, geglu=None, bias_residual_add=None, layer_norms=None, conv=None, linear=None):
         """Install (or with None remove) the fused element-wise epilogues: GEGLU, conv-bias + residual, and
         (layer_norm, add_layer_norm) for the transformer blocks; `conv` = the implicit-GEMM 3x3 convolution; `linear` = the
         fused_linear module (LayerNorm / GEGLU / residual folded into the transformer blocks' GEMMs, 1x1 shortcuts)."""
@@ -675,7 +655,6 @@ class UNet2DConditionModel(nn.Module):
                 m.add_impl = bias_residual_add
                 m.conv_impl = conv
                 m.lin_impl = linear
-                m.side_stream = side_stream if linear is not None else None
             elif isinstance(m, BasicTransformerBlock):
                 m.ln_impl = layer_norms
                 m.lin_impl = linear
