@@ -119,6 +119,22 @@ class GraphRunner:
                     self._joint_body(store)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # No automatic garbage collection while a capture is open: a cycle collection that happens to run inside one frees
+        # whatever became unreachable earlier — an older runner's hipGraphs, streams, events — and destroying those while this
+        # thread's stream is capturing aborts the process (seen once in the full GPU suite, at a capture after ~500 tests).
+        # torch.cuda.graph() collects on entry; between entry and exit nothing may.
+        with ops.no_gc():
+            self._capture_graphs(store)
+        torch.cuda.synchronize()
+        self.pipe.unet_calls.update(calls)  # capture / warm-up passes are not image work
+        # The captured kernels read the cached text K/V projections of the static prompt buffers by raw pointer:
+        # pin those cache entries so that eager passes with other contexts can never evict (= free) them.
+        self._storages = {b.untyped_storage().data_ptr() for b in (self.embeds, getattr(self, "embeds3", None))
+                          if b is not None}
+        self.pinned = pin_context_projections(self.pipe.unet, self._storages, +1)
+        GraphRunner.captures += 1
+
+    def _capture_graphs(self, store):
         self.g_eval = torch.cuda.CUDAGraph()
         with ops.census_scope() as c_eval, torch.cuda.graph(self.g_eval):
             self.parts, self.store_eval = self._eval_body(store)
@@ -135,14 +151,6 @@ class GraphRunner:
             with ops.census_scope() as c_joint, torch.cuda.graph(self.g_joint, pool=self.g_eval.pool()):
                 self.noise3, self.parts_joint, self.store_joint = self._joint_body(store)
             self.launches["joint"] = c_joint.launches
-        torch.cuda.synchronize()
-        self.pipe.unet_calls.update(calls)  # capture / warm-up passes are not image work
-        # The captured kernels read the cached text K/V projections of the static prompt buffers by raw pointer:
-        # pin those cache entries so that eager passes with other contexts can never evict (= free) them.
-        self._storages = {b.untyped_storage().data_ptr() for b in (self.embeds, getattr(self, "embeds3", None))
-                          if b is not None}
-        self.pinned = pin_context_projections(self.pipe.unet, self._storages, +1)
-        GraphRunner.captures += 1
 
     captures = 0  # how many runners were ever captured (tests assert graph reuse across seeds)
 

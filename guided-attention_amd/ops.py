@@ -58,6 +58,23 @@ def add_census(launches):
             _CENSUS[key] = _CENSUS.get(key, 0) + n
 
 
+class no_gc:
+    """No automatic garbage collection inside the block (collect once on entry): a cycle collection that runs while a stream is
+    capturing may destroy an older hipGraph / stream / event, which aborts the process — every capture of this package sits
+    inside one."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self.was:
+            import gc
+            gc.enable()
+
+
 def replay_launch_us(key, iters=100):
     """Average duration (us) of one launch of a recorded kernel shape, inputs resident in HBM: `iters` launches
     captured into one hipGraph (no host in the loop: a Python-driven loop is launch-bound at ~10 us per call and
@@ -244,7 +261,7 @@ def replay_launch_us(key, iters=100):
             fn()
         side.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
+        with no_gc(), torch.cuda.graph(graph, stream=side):
             for _ in range(iters):
                 fn()
         graph.replay()

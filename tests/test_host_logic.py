@@ -330,3 +330,27 @@ def test_transposed_weight_cache_outlives_the_view_it_was_asked_with():
     assert t3 is not t1 and torch.equal(t3, conv.weight.reshape(16, 8).t())
     lin = torch.nn.Linear(8, 16)
     assert fused_linear._transposed(lin.weight) is fused_linear._transposed(lin.weight)
+
+
+def test_no_gc_scope_restores_the_collector():
+    """ops.no_gc (every hipGraph capture of the package runs inside it): automatic collection off inside, back to what it was
+    after, also when the body raises."""
+    import gc
+    from guided_attention_amd import ops
+    assert gc.isenabled()
+    with ops.no_gc():
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    try:
+        with ops.no_gc():
+            raise RuntimeError("x")
+    except RuntimeError:
+        pass
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with ops.no_gc():
+            pass
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
