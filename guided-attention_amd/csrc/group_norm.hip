@@ -30,7 +30,8 @@ struct Item {
   T v[W];
 };
 
-__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + __expf(-z)); }
+// v_rcp_f32 (1 ulp), not an IEEE division (ten instructions per element in every GroupNorm + SiLU pass)
+__device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
 
 // optional per-(image, channel) bias added to x on load (the ResnetBlock's time-embedding term): normalising
 // x + bias[c] without a separate broadcast-add pass over the tensor

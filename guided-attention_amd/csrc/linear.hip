@@ -148,7 +148,7 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 g) {
   q = __builtin_elementwise_fma(q, x2, c(-1.68282697438203e-03f));
   q = __builtin_elementwise_fma(q, x2, c(-7.37332916720468e-03f));
   q = __builtin_elementwise_fma(q, x2, c(-1.42647390514189e-02f));
-  const f32x2 rq = {__frcp_rn(q.x), __frcp_rn(q.y)};
+  const f32x2 rq = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};   // v_rcp_f32 (1 ulp); __frcp_rn is a ten-instruction IEEE division
   const f32x2 erf = x * p * rq;
   const f32x2 hg = g * 0.5f;
   return __builtin_elementwise_fma(hg, erf, hg);
