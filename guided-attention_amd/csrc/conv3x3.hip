@@ -71,6 +71,24 @@ struct Mma32<bf16_t> {
   }
 };
 
+// x / d for a divisor known to the host: one 32-bit multiply-high, m = floor(2^32 / d) + 1, exact while x d < 2^32.  The host
+// checks that against the largest dividend (make_fastdiv -> ok = false otherwise, and launch_tile then keeps the launch off
+// the kernels that rely on it); d = 1 is m = 0 and returns x.
+struct FastDiv {
+  unsigned d, m;
+};
+inline FastDiv make_fastdiv(long long d, unsigned long long max_x, bool& ok) {
+  FastDiv f{(unsigned)(d > 0 ? d : 1), 0u};
+  if (d > 1) {
+    if (max_x * (unsigned long long)d < (1ull << 32)) f.m = (unsigned)((1ull << 32) / (unsigned long long)d) + 1u;
+    else ok = false;
+  }
+  return f;
+}
+__device__ __forceinline__ int fdiv(int x, FastDiv f) {   // x >= 0
+  return f.m != 0u ? (int)__umulhi((unsigned)x, f.m) : x;
+}
+
 struct ConvArgs {
   int B, H, W, Cin, Ho, Wo, Cout, stride;
   int M;            // B * Ho * Wo
@@ -89,6 +107,12 @@ struct ConvArgs {
   // GEMM entry point reads (the framework's own Linear weights; w_row = K, w_chunk = 64) the same fetch is 64 pieces of 128
   // bytes 2 K bytes apart, and the cold weight streams of the 1280-channel levels ran at 1.3 - 1.8 TB/s on it.
   int w_tap, w_blk, w_row, w_chunk;
+  // Patch kernels: the tile geometry (patch_geometry) and the divisors of the per-thread index arithmetic, prepared by the
+  // host.  The prologue of conv3x3_patch_dma_kernel computed all of it per workgroup with runtime integer divisions — 12
+  // reciprocals and 962 VALU instructions, 190 of them quarter-rate 32-bit multiplies, before the first load was issued
+  // (~2.6 us on the critical path of a 17 - 30 us launch).
+  int pg_nseg, pg_srows;
+  FastDiv d_tm, d_tn, d_w, d_hw, d_pw, d_segpw, d_segpx;
   int up;           // 1: X is [B][H/2][W/2][Cin] and the convolution runs on its nearest-neighbour 2x up-sampling (H, W are the
                     // up-sampled sizes): only the patch gather of conv3x3_patch_dma_kernel changes — pixel (iy, ix) of the
                     // patch is read from (iy >> 1, ix >> 1) — and the [B][H][W][Cin] intermediate is never written
@@ -118,17 +142,16 @@ __device__ __forceinline__ void tile_of_workgroup(const ConvArgs& a, int& m0, in
   const int total = gridDim.x, q = total >> 3, r = total & 7;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  if (a.n_fastest) {   // activations outweigh the weights (64x64 level): an XCD keeps an m tile's pixels, sweeps the n tiles
-    const int nt = logical % a.tn, rest = logical / a.tn;
-    n0 = nt * BN;
-    m0 = (rest % a.tm) * BM;
-    split = rest / a.tm;
-  } else {
-    const int mt = logical % a.tm, rest = logical / a.tm;
-    m0 = mt * BM;
-    n0 = (rest % a.tn) * BN;
-    split = rest / a.tn;
-  }
+  // n_fastest: activations outweigh the weights (64x64 level): an XCD keeps an m tile's pixels and sweeps the n tiles.
+  // Written with selects, not two branches assigning m0 / n0 in turn (the compiler merged those into a two-element stack array)
+  const bool nf = a.n_fastest != 0;
+  const FastDiv d1 = nf ? a.d_tn : a.d_tm, d2 = nf ? a.d_tm : a.d_tn;
+  const int t1 = nf ? a.tn : a.tm, t2 = nf ? a.tm : a.tn;
+  const int rest = fdiv(logical, d1), i1 = logical - rest * t1;
+  split = fdiv(rest, d2);
+  const int i2 = rest - split * t2;
+  m0 = (nf ? i2 : i1) * BM;
+  n0 = (nf ? i1 : i2) * BN;
 }
 
 // Epilogue of both kernels.  acc[j][i][r]: output channel n = n0 + wn*WN + j*32 + (r & 3) + 8 * (r >> 2) + 4 * fh,
@@ -700,12 +723,17 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
   const int cchunks = a.Cin / kKC;
   const int c_begin = split * a.steps_per, c_end = min(cchunks, c_begin + a.steps_per);   // chunks of this split
 
-  PatchGeom g;
-  patch_geometry(BM, a.H, a.W, g, WIDE);
-  const bool run = BM % a.W != 0 && BM % (a.H * a.W) != 0;
-  const int col0 = run ? (m0 % (a.H * a.W)) % a.W : 0;
-  const int PW = a.W + 2, seg_px = run ? BM : g.srows * a.W, seg_rows = g.srows + 2;
-  const int npatch = g.nseg * seg_rows * PW;
+  // tile geometry and divisors from the host (launch_tile): no runtime division in this prologue
+  PatchGeom g{a.pg_nseg, a.pg_srows};
+  const int hw = a.H * a.W;
+  const bool run = a.d_segpx.d == (unsigned)BM && BM != g.srows * a.W;   // seg_px = BM only for tiles that are runs of pixels
+  int col0 = 0;
+  if (run) {
+    const int in_image = m0 - fdiv(m0, a.d_hw) * hw;
+    col0 = in_image - fdiv(in_image, a.d_w) * a.W;
+  }
+  const int PW = a.W + 2, seg_px = (int)a.d_segpx.d, seg_rows = g.srows + 2, seg_pw = seg_rows * PW;
+  const int npatch = g.nseg * seg_pw;
 
   constexpr unsigned kOob = 0x80000000u;
   const int srow = tid / QP, sq = tid % QP;
@@ -718,10 +746,10 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
 #pragma unroll
   for (int p = 0; p < kPatchPieces; ++p) {
     const int q = srow + RPP * p;
-    const int seg = q / (seg_rows * PW), rem = q - seg * (seg_rows * PW);
-    const int pr = rem / PW, pc = rem - pr * PW;
+    const int seg = fdiv(q, a.d_segpw), rem = q - seg * seg_pw;
+    const int pr = fdiv(rem, a.d_pw), pc = rem - pr * PW;
     const int mseg = m0 + seg * seg_px;
-    const int b = mseg / (a.H * a.W), y0 = (mseg - b * (a.H * a.W)) / a.W;
+    const int b = fdiv(mseg, a.d_hw), y0 = fdiv(mseg - b * hw, a.d_w);
     const int iy = y0 + pr - 1, ix = pc - 1;
     const bool ok = q < npatch && mseg < a.M && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     const int pix = a.up ? (b * (a.H >> 1) + (iy >> 1)) * (a.W >> 1) + (ix >> 1) : (b * a.H + iy) * a.W + ix;
@@ -771,8 +799,8 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
 #pragma unroll
   for (int i = 0; i < IM; ++i) {
     const int pm = wm * WM + i * 32 + lane_pixel(fr, a.lane_rot);
-    const int seg = pm / seg_px, rem = pm - seg * seg_px + col0;
-    const int r = rem / a.W, c = rem - r * a.W;
+    const int seg = fdiv(pm, a.d_segpx), rem = pm - seg * seg_px + col0;
+    const int r = fdiv(rem, a.d_w), c = rem - r * a.W;
     pix_adr[i] = lds0 + (unsigned)((((seg * seg_rows + r) * PW + c) * kLD + fh * 8) * (int)sizeof(T));
   }
 #pragma unroll
@@ -970,7 +998,7 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, con
     a.n_fastest = n_first < m_first ? 1 : 0;
   }
   dim3 grid((unsigned)(a.tm * a.tn * splits));
-  PatchGeom pg;
+  PatchGeom pg{1, 1};
   // 8x8 maps: the register-staged patch kernel never took them (the halo makes the patch 100 pixels for 64, the depth splits
   // only by chunks), and the 32 KB DMA ring measured the same as the per-tap kernel (15.4 vs 15.1 us): these launches are a
   // 29.5 - 59 MB weight stream — what they need is bytes in flight, i.e. the DEEP ring below
@@ -982,7 +1010,26 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, con
   // and up to 17 % on the 24-wide one (profiles/r3_conv_tune_sd21.txt; equal at 96 and 12), and equal-or-faster only where a
   // tile is whole rows or whole images (every level of the 512^2 configuration)
   const bool run_geom = BM % a.W != 0 && BM % (a.H * a.W) != 0;
-  const bool dma = use_dma() && !(run_geom && a.W >= 16);   // below 16 only the DMA form has a patch variant at all (see geom_ok)
+  const bool dma_wanted = use_dma() && !(run_geom && a.W >= 16);   // below 16 only the DMA form has a patch variant at all (see geom_ok)
+  bool fast_ok = true;
+  {  // everything the kernels would otherwise divide for (FastDiv: exact for the dividends named here)
+    const unsigned long long wgs = (unsigned long long)a.tm * a.tn * splits;
+    bool map_ok = true;
+    a.d_tm = make_fastdiv(a.tm, wgs, map_ok);
+    a.d_tn = make_fastdiv(a.tn, wgs, map_ok);
+    if (!map_ok) return GA_ERR_SHAPE;   // more than 2^32 / max(tm, tn) workgroups: no such launch exists below the 2^31-element limits
+    a.pg_nseg = pg.nseg;
+    a.pg_srows = pg.srows;
+    const long long seg_px = run_geom ? BM : (long long)pg.srows * a.W, seg_pw = (long long)(pg.srows + 2) * (a.W + 2);
+    a.d_w = make_fastdiv(a.W, (unsigned long long)a.H * a.W + seg_px + a.W, fast_ok);
+    a.d_hw = make_fastdiv((long long)a.H * a.W, (unsigned long long)a.M + 2ull * BM, fast_ok);
+    a.d_pw = make_fastdiv(a.W + 2, (unsigned long long)seg_pw + 512, fast_ok);
+    a.d_segpw = make_fastdiv(seg_pw, 1024, fast_ok);
+    a.d_segpx = make_fastdiv(seg_px, 2ull * BM, fast_ok);
+  }
+  // the DMA patch kernel divides by multiplication only: a shape whose dividends overflow that (batch x pixels^2 >= 2^32: sixteen
+  // 128 x 128 maps in one launch) takes the register-staged kernels, which divide properly
+  const bool dma = dma_wanted && fast_ok;
   if (a.up && !((patch || patch_wide) && dma)) return GA_ERR_SHAPE;   // only the patch-DMA kernel gathers from the half-size map
   if (patch_wide) {   // the 13-piece instantiation: one row of a 128-wide map, or a run of a 96- / 48-wide map (geometry 3)
     a.steps_per = (a.Cin / kKC + splits - 1) / splits;
