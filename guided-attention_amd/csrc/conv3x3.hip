@@ -71,24 +71,6 @@ struct Mma32<bf16_t> {
   }
 };
 
-// x / d for a divisor known to the host: one 32-bit multiply-high, m = floor(2^32 / d) + 1, exact while x d < 2^32.  The host
-// checks that against the largest dividend (make_fastdiv -> ok = false otherwise, and launch_tile then keeps the launch off
-// the kernels that rely on it); d = 1 is m = 0 and returns x.
-struct FastDiv {
-  unsigned d, m;
-};
-inline FastDiv make_fastdiv(long long d, unsigned long long max_x, bool& ok) {
-  FastDiv f{(unsigned)(d > 0 ? d : 1), 0u};
-  if (d > 1) {
-    if (max_x * (unsigned long long)d < (1ull << 32)) f.m = (unsigned)((1ull << 32) / (unsigned long long)d) + 1u;
-    else ok = false;
-  }
-  return f;
-}
-__device__ __forceinline__ int fdiv(int x, FastDiv f) {   // x >= 0
-  return f.m != 0u ? (int)__umulhi((unsigned)x, f.m) : x;
-}
-
 struct ConvArgs {
   int B, H, W, Cin, Ho, Wo, Cout, stride;
   int M;            // B * Ho * Wo
@@ -112,7 +94,7 @@ struct ConvArgs {
   // reciprocals and 962 VALU instructions, 190 of them quarter-rate 32-bit multiplies, before the first load was issued
   // (~2.6 us on the critical path of a 17 - 30 us launch).
   int pg_nseg, pg_srows;
-  FastDiv d_tm, d_tn, d_w, d_hw, d_pw, d_segpw, d_segpx;
+  FastDiv d_tm, d_tn, d_w, d_hw, d_pw, d_segpw, d_segpx, d_wo, d_howo;
   int up;           // 1: X is [B][H/2][W/2][Cin] and the convolution runs on its nearest-neighbour 2x up-sampling (H, W are the
                     // up-sampled sizes): only the patch gather of conv3x3_patch_dma_kernel changes — pixel (iy, ix) of the
                     // patch is read from (iy >> 1, ix >> 1) — and the [B][H][W][Cin] intermediate is never written
@@ -303,8 +285,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
     const int m = m0 + srow + RPP * p;
     const bool ok = m < a.M;
     const int mm = ok ? m : 0;
-    const int b = mm / (a.Ho * a.Wo), rem = mm - b * (a.Ho * a.Wo);
-    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    const int b = sdiv(mm, a.d_howo), rem = mm - b * (a.Ho * a.Wo);
+    const int oy = sdiv(rem, a.d_wo), ox = rem - oy * a.Wo;
     a_iy[p] = ok ? oy * a.stride - a.pad : -4;
     a_ix[p] = ox * a.stride - a.pad;
     a_off[p] = (((b * a.H + a_iy[p]) * a.W + a_ix[p]) * a.Cin + 8 * sq) * (int)sizeof(T);
@@ -509,13 +491,19 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
   const int cchunks = a.Cin / kKC;
   const int c_begin = split * a.steps_per, c_end = min(cchunks, c_begin + a.steps_per);   // chunks of this split
 
-  PatchGeom g;
-  patch_geometry(BM, a.H, a.W, g, WIDE);
+  // geometry and divisors from the host (launch_tile), as in the DMA form below; sdiv: this kernel also takes the shapes
+  // whose dividends the multiply-high form cannot serve
+  PatchGeom g{a.pg_nseg, a.pg_srows};
+  const int hw = a.H * a.W;
   // geometry (3) (a run that is not made of whole rows): one segment that starts in the middle of a row
-  const bool run = BM % a.W != 0 && BM % (a.H * a.W) != 0;
-  const int col0 = run ? (m0 % (a.H * a.W)) % a.W : 0;
-  const int PW = a.W + 2, seg_px = run ? BM : g.srows * a.W, seg_rows = g.srows + 2;
-  const int npatch = g.nseg * seg_rows * PW;
+  const bool run = a.d_segpx.d == (unsigned)BM && BM != g.srows * a.W;
+  int col0 = 0;
+  if (run) {
+    const int in_image = m0 - sdiv(m0, a.d_hw) * hw;
+    col0 = in_image - sdiv(in_image, a.d_w) * a.W;
+  }
+  const int PW = a.W + 2, seg_px = (int)a.d_segpx.d, seg_rows = g.srows + 2, seg_pw = seg_rows * PW;
+  const int npatch = g.nseg * seg_pw;
 
   constexpr unsigned kOob = 0x80000000u;
   const int srow = tid / QP, sq = tid % QP;
@@ -528,10 +516,10 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
 #pragma unroll
   for (int p = 0; p < kPatchPieces; ++p) {
     const int q = srow + RPP * p;
-    const int seg = q / (seg_rows * PW), rem = q - seg * (seg_rows * PW);
-    const int pr = rem / PW, pc = rem - pr * PW;
+    const int seg = sdiv(q, a.d_segpw), rem = q - seg * seg_pw;
+    const int pr = sdiv(rem, a.d_pw), pc = rem - pr * PW;
     const int mseg = m0 + seg * seg_px;                  // first output pixel of the segment
-    const int b = mseg / (a.H * a.W), y0 = (mseg - b * (a.H * a.W)) / a.W;
+    const int b = sdiv(mseg, a.d_hw), y0 = sdiv(mseg - b * hw, a.d_w);
     const int iy = y0 + pr - 1, ix = pc - 1;
     const bool ok = q < npatch && mseg < a.M && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     pa_off[p] = ok ? (unsigned)((((b * a.H + iy) * a.W + ix) * a.Cin + 8 * sq) * (int)sizeof(T)) : kOob;
@@ -591,8 +579,8 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
 #pragma unroll
   for (int i = 0; i < IM; ++i) {
     const int pm = wm * WM + i * 32 + lane_pixel(fr, a.lane_rot);
-    const int seg = pm / seg_px, rem = pm - seg * seg_px + col0;   // col0: the column the tile's first pixel sits in
-    const int r = rem / a.W, c = rem - r * a.W;
+    const int seg = sdiv(pm, a.d_segpx), rem = pm - seg * seg_px + col0;   // col0: the column the tile's first pixel sits in
+    const int r = sdiv(rem, a.d_w), c = rem - r * a.W;
     pix_base[i] = ((seg * seg_rows + r) * PW + c) * kLD + fh * 8;
   }
   auto mma_tap = [&](int buf, int ky, int kx) {
@@ -1026,6 +1014,9 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, con
     a.d_pw = make_fastdiv(a.W + 2, (unsigned long long)seg_pw + 512, fast_ok);
     a.d_segpw = make_fastdiv(seg_pw, 1024, fast_ok);
     a.d_segpx = make_fastdiv(seg_px, 2ull * BM, fast_ok);
+    bool tap_ok = true;   // the per-tap kernel: its own two divisors (sdiv: it divides properly where these cannot serve)
+    a.d_howo = make_fastdiv((long long)a.Ho * a.Wo, (unsigned long long)a.M + 2ull * BM, tap_ok);
+    a.d_wo = make_fastdiv(a.Wo, (unsigned long long)a.Ho * a.Wo, tap_ok);
   }
   // the DMA patch kernel divides by multiplication only: a shape whose dividends overflow that (batch x pixels^2 >= 2^32: sixteen
   // 128 x 128 maps in one launch) takes the register-staged kernels, which divide properly

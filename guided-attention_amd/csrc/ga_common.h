@@ -140,6 +140,27 @@ inline int check_launch() {
   return e == hipSuccess ? GA_OK : GA_ERR_LAUNCH;
 }
 
+// x / d for a divisor known to the host: one 32-bit multiply-high, m = floor(2^32 / d) + 1, exact while x d < 2^32.  The host
+// checks that against the largest dividend (make_fastdiv -> ok = false otherwise, and launch_tile then keeps the launch off
+// the kernels that rely on it); d = 1 is m = 0 and returns x.
+struct FastDiv {
+  unsigned d, m;
+};
+inline FastDiv make_fastdiv(long long d, unsigned long long max_x, bool& ok) {
+  FastDiv f{(unsigned)(d > 0 ? d : 1), 0u};
+  if (d > 1) {
+    if (max_x * (unsigned long long)d < (1ull << 32)) f.m = (unsigned)((1ull << 32) / (unsigned long long)d) + 1u;
+    else ok = false;
+  }
+  return f;
+}
+__device__ __forceinline__ int fdiv(int x, FastDiv f) {   // x >= 0; the host vouched for the divisor (launch_tile: fast_ok)
+  return f.m != 0u ? (int)__umulhi((unsigned)x, f.m) : x;
+}
+__device__ __forceinline__ int sdiv(int x, FastDiv f) {   // the same for the kernels that also take the shapes it cannot serve
+  return f.m != 0u ? (int)__umulhi((unsigned)x, f.m) : (int)((unsigned)x / f.d);
+}
+
 // Holds `v` in its registers up to this point of the instruction stream.  Used after the sc1 (write-through) buffer stores
 // of the split-K slabs: the compiler re-used a stored accumulator register for the NEXT store's address in the instruction
 // right behind `buffer_store_dwordx4 ... sc1` (it knows no hazard there when the store has an SGPR offset), and on the MI355X

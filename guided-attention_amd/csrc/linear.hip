@@ -61,6 +61,7 @@ struct LinArgs {
   int M, N, K;               // N = rows of W (GEGLU: 2F)
   int ldx, ldy, ld_res, ld_pre;
   int tm, tn, splits, steps, steps_per, n_fastest;
+  FastDiv d_tm, d_tn;        // tile mapping by multiply-high (lin_tile)
   int F;                     // GEGLU: features of the result (N / 2); 0 otherwise
   int ln_parts;              // LayerNorm fold: partial sums per row; 0 = no fold
   float ln_eps, ln_inv_k;
@@ -87,17 +88,16 @@ __device__ __forceinline__ void lin_tile(const LinArgs& a, int& mt, int& nt, int
   const int total = gridDim.x, q = total >> 3, r = total & 7;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  if (a.n_fastest) {
-    nt = logical % a.tn;
-    const int rest = logical / a.tn;
-    mt = rest % a.tm;
-    split = rest / a.tm;
-  } else {
-    mt = logical % a.tm;
-    const int rest = logical / a.tm;
-    nt = rest % a.tn;
-    split = rest / a.tn;
-  }
+  // divisions by multiply-high with the host's reciprocals (two runtime integer divisions were ~100 instructions in front of
+  // every workgroup's first load); selects instead of two branches assigning mt / nt in turn (see conv3x3.hip)
+  const bool nf = a.n_fastest != 0;
+  const FastDiv d1 = nf ? a.d_tn : a.d_tm, d2 = nf ? a.d_tm : a.d_tn;
+  const int t1 = nf ? a.tn : a.tm, t2 = nf ? a.tm : a.tn;
+  const int rest = fdiv(logical, d1), i1 = logical - rest * t1;
+  split = fdiv(rest, d2);
+  const int i2 = rest - split * t2;
+  mt = nf ? i2 : i1;
+  nt = nf ? i1 : i2;
 }
 
 // Inline asm with GPU register constraints only exists in the device pass: the host pass parses kernel bodies too, and a
@@ -485,6 +485,13 @@ int launch_lin(const T* X, const T* W, T* Y, LinArgs a, const LinPtrs& p, hipStr
     const double xb = (double)a.M * a.K, wb = (double)a.N * a.K;
     const double m_first = wb + xb * (a.tn * a.splits < 8 ? a.tn * a.splits : 8), n_first = xb + wb * (a.tm < 8 ? a.tm : 8);
     a.n_fastest = n_first < m_first ? 1 : 0;
+  }
+  {
+    bool ok = true;
+    const unsigned long long wgs = (unsigned long long)a.tm * a.tn * a.splits;
+    a.d_tm = make_fastdiv(a.tm, wgs, ok);
+    a.d_tn = make_fastdiv(a.tn, wgs, ok);
+    if (!ok) return GA_ERR_SHAPE;   // workgroups x tiles >= 2^32: no such launch below the 2^31-byte operand limits
   }
   const dim3 grid((unsigned)(a.tm * a.tn * a.splits));
   const bool ln = a.ln_parts > 0;
