@@ -94,6 +94,7 @@ struct ConvArgs {
   // reciprocals and 962 VALU instructions, 190 of them quarter-rate 32-bit multiplies, before the first load was issued
   // (~2.6 us on the critical path of a 17 - 30 us launch).
   int pg_nseg, pg_srows;
+  int pg_dpr, pg_dpc;   // a thread's next patch piece is 32 patch pixels on: 32 / (W + 2) rows and 32 % (W + 2) columns
   FastDiv d_tm, d_tn, d_w, d_hw, d_pw, d_segpw, d_segpx, d_wo, d_howo;
   int up;           // 1: X is [B][H/2][W/2][Cin] and the convolution runs on its nearest-neighbour 2x up-sampling (H, W are the
                     // up-sampled sizes): only the patch gather of conv3x3_patch_dma_kernel changes — pixel (iy, ix) of the
@@ -721,7 +722,6 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
     col0 = in_image - fdiv(in_image, a.d_w) * a.W;
   }
   const int PW = a.W + 2, seg_px = (int)a.d_segpx.d, seg_rows = g.srows + 2, seg_pw = seg_rows * PW;
-  const int npatch = g.nseg * seg_pw;
 
   constexpr unsigned kOob = 0x80000000u;
   const int srow = tid / QP, sq = tid % QP;
@@ -729,20 +729,34 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wp), 0, a.w_bytes, 0x00020000);
   const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)lds);
 
-  // ---- patch staging (as above; the LDS stores are asm)
+  // ---- patch staging (as above; the LDS stores are asm).  Piece p of this thread = patch pixel q = srow + RPP p: its
+  // (segment, patch row, patch column) advance by RPP pixels per piece — carries, no division per piece; 24-bit multiplies
+  // (full rate; the host checked pixel count and row bytes < 2^24).  Called AFTER the first weight DMAs are issued: the
+  // arithmetic runs under their latency.
   unsigned pa_off[kPatchPieces];
+  auto patch_offsets = [&]() {
+    int seg = fdiv(srow, a.d_segpw);
+    const int rem0 = srow - seg * seg_pw;
+    int pr = fdiv(rem0, a.d_pw), pc = rem0 - pr * PW;
+    const int b0 = fdiv(m0, a.d_hw), y00 = fdiv(m0 - b0 * hw, a.d_w);   // wave-uniform: image and row of the tile's first pixel
+    const unsigned row_bytes = (unsigned)(a.Cin * (int)sizeof(T));
+    const int SH = a.up ? a.H >> 1 : a.H, SW = a.up ? a.W >> 1 : a.W;
 #pragma unroll
-  for (int p = 0; p < kPatchPieces; ++p) {
-    const int q = srow + RPP * p;
-    const int seg = fdiv(q, a.d_segpw), rem = q - seg * seg_pw;
-    const int pr = fdiv(rem, a.d_pw), pc = rem - pr * PW;
-    const int mseg = m0 + seg * seg_px;
-    const int b = fdiv(mseg, a.d_hw), y0 = fdiv(mseg - b * hw, a.d_w);
-    const int iy = y0 + pr - 1, ix = pc - 1;
-    const bool ok = q < npatch && mseg < a.M && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-    const int pix = a.up ? (b * (a.H >> 1) + (iy >> 1)) * (a.W >> 1) + (ix >> 1) : (b * a.H + iy) * a.W + ix;
-    pa_off[p] = ok ? (unsigned)((pix * a.Cin + 8 * sq) * (int)sizeof(T)) : kOob;
-  }
+    for (int p = 0; p < kPatchPieces; ++p) {
+      const int mseg = m0 + seg * seg_px;
+      const int b = b0 + seg;     // several segments = whole images per segment; one segment: seg = 0 for every live piece
+      const int iy = y00 + pr - 1, ix = pc - 1;
+      const bool ok = seg < g.nseg && mseg < a.M && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const int sy = a.up ? iy >> 1 : iy, sx = a.up ? ix >> 1 : ix;
+      const unsigned pix = __umul24(__umul24((unsigned)b, (unsigned)SH) + (unsigned)sy, (unsigned)SW) + (unsigned)sx;
+      pa_off[p] = ok ? __umul24(pix, row_bytes) + (unsigned)(8 * sq * (int)sizeof(T)) : kOob;
+      pc += a.pg_dpc;
+      pr += a.pg_dpr;
+      if (pc >= PW) { pc -= PW; ++pr; }
+      if (pr >= seg_rows) { pr -= seg_rows; ++seg; }
+      if (pr >= seg_rows) { pr -= seg_rows; ++seg; }
+    }
+  };
   u32x4_t rp[kPatchPieces];
   auto load_patch = [&](int chunk) {
     const unsigned step = (unsigned)(chunk * kKC * (int)sizeof(T));
@@ -840,10 +854,11 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
 
   if (c_begin < c_end) {
     // prologue: patch of the first chunk (registers -> LDS), weights of its first PD steps into ring slots 0 .. PD - 1
-    load_patch(c_begin);
 #pragma unroll
-    for (int t = 0; t < PD; ++t) issue_w(c_begin, t, t);
-    store_patch();                 // the compiler waits for rp[] itself (its count includes the DMA instructions issued after)
+    for (int t = 0; t < PD; ++t) issue_w(c_begin, t, t);   // first: they need the tile's n0 only
+    patch_offsets();
+    load_patch(c_begin);
+    store_patch();                 // the compiler waits for rp[] itself (the youngest loads: the DMAs above have landed by then)
     conv_wait_lgkmcnt<0>();
     int s = 0;                     // global step counter of this workgroup: ring slot = s % NW
     for (int c = c_begin; c < c_end; ++c) {
@@ -1014,6 +1029,9 @@ int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, con
     a.d_pw = make_fastdiv(a.W + 2, (unsigned long long)seg_pw + 512, fast_ok);
     a.d_segpw = make_fastdiv(seg_pw, 1024, fast_ok);
     a.d_segpx = make_fastdiv(seg_px, 2ull * BM, fast_ok);
+    a.pg_dpr = 32 / (a.W + 2);
+    a.pg_dpc = 32 % (a.W + 2);
+    if ((long long)a.B * a.H * a.W >= (1 << 24) || (long long)a.Cin * 2 >= (1 << 24)) fast_ok = false;   // 24-bit multiplies
     bool tap_ok = true;   // the per-tap kernel: its own two divisors (sdiv: it divides properly where these cannot serve)
     a.d_howo = make_fastdiv((long long)a.Ho * a.Wo, (unsigned long long)a.M + 2ull * BM, tap_ok);
     a.d_wo = make_fastdiv(a.Wo, (unsigned long long)a.Ho * a.Wo, tap_ok);

@@ -851,6 +851,9 @@ CONV_SHAPES = [  # B, Cin, Cout, H, W, stride
     # whose images must not share a tile and a 40-wide map (runs of 64 pixels: 1.6 rows)
     (1, 320, 320, 96, 96, 1), (1, 640, 640, 48, 48, 1), (3, 1280, 1280, 24, 24, 1),
     (2, 64, 64, 24, 24, 1), (1, 64, 128, 48, 48, 1), (2, 128, 64, 32, 40, 1),
+    # 12 x 12 maps (the 768^2 configuration's lowest level): runs of pixels on the DMA patch kernel (the only patch form below
+    # 16 columns), 10 x 10: a map whose pixel count no tile divides (per-tap kernel)
+    (2, 64, 128, 12, 12, 1), (4, 128, 64, 12, 12, 1), (1, 64, 64, 10, 10, 1),
 ]
 
 
