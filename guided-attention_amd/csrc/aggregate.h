@@ -44,17 +44,22 @@ __device__ __forceinline__ float aggregate_element(const AggArgs& a, int e, int 
       if (m0 + i < a.n_maps) hmax = max(hmax, a.heads[m0 + i] & ~7);
     for (int h0 = 0; h0 < hmax; h0 += 8) {
       T v[4][8];
+      bool lv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool live = m0 + i < a.n_maps && h0 + 8 <= (a.heads[m0 + i < a.n_maps ? m0 + i : 0] & ~7);
+        // every load is issued, from an address that exists (head 0 of the batch's first tensor when the slot is not
+        // live), and dropped by the select in the sum: `live ? load : 0` compiled to one load and one wait at a time —
+        // 32 dependent round trips where 32 loads in flight were meant
         const T* src = static_cast<const T*>(a.maps[live ? m0 + i : m0]) + e;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[i][j] = live ? src[(size_t)(h0 + j) * n_elem] : Traits<T>::zero();
+        for (int j = 0; j < 8; ++j) v[i][j] = src[(size_t)(live ? h0 + j : 0) * n_elem];
+        lv[i] = live;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += Traits<T>::to_f32(v[i][j]);
+        for (int j = 0; j < 8; ++j) acc += lv[i] ? Traits<T>::to_f32(v[i][j]) : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

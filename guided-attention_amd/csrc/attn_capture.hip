@@ -366,6 +366,18 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
   typename Tr::frag xq[NK], xdo[NK];
   load_row_frags<T, NK>(Q + row_off, ok, D, g, xq);
   load_row_frags<T, NK>(dO + row_off, ok, D, g, xdo);
+  // the gradient that arrives through the stored map (the loss's dA), this lane's 4 NT probabilities: requested here, with
+  // the other operands, from clamped addresses (without one: from K, and dropped below).  Loaded where it is added — one
+  // 2-byte load per key under `if (key < Kt)`, each waited for on its own — it was 4 NT dependent round trips in the
+  // middle of the kernel.
+  T up[NT][4];
+  {
+    const T* src = dP != nullptr ? dP + (long long)(b * H + head) * dP_sb + (long long)(ok ? q : 0) * dP_sn : K + kv_off;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) up[t][r] = src[min(t * 16 + 4 * g + r, Kt - 1)];
+  }
   stage_kv2<T, NT, NK, WAVES * 64>(K + kv_off, Ks, Ktr, V + kv_off, Vs, nullptr, H, Kt, D);
   __syncthreads();
 
@@ -375,15 +387,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_capture_bwd_kernel(
   else softmax_keys<NT>(p, Kt, g, scale);      // identical instruction sequence to the forward
   qk_tiles<T, NT, NK>(xdo, Vs, KS, c, g, dp);  // dP^T[key][q] = sum_d V[key][d] dO[q][d]
 
-  if (dP != nullptr && ok) {
-    const T* src = dP + (long long)(b * H + head) * dP_sb + (long long)q * dP_sn;
+  {
+    const bool use = dP != nullptr && ok;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = t * 16 + 4 * g + r;
-        if (key < Kt) dp[t][r] += Tr::to_f32(src[key]);
-      }
+      for (int r = 0; r < 4; ++r) dp[t][r] += (use && t * 16 + 4 * g + r < Kt) ? Tr::to_f32(up[t][r]) : 0.f;
   }
   float dot = 0.f;
 #pragma unroll

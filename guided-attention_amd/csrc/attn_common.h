@@ -35,11 +35,17 @@ struct TileLds {
 template <typename T, int NK>
 __device__ __forceinline__ void load_row_frags(const T* __restrict__ xrow, bool ok, int D, int g,
                                                typename Traits<T>::frag (&x)[NK]) {
+  // `xrow` is a valid row also when !ok (the callers clamp the row index).  Every chunk is loaded, from a column clamped
+  // into the row, and dropped by a select where it lies past the head size or the row does not exist: under
+  // `if (ok && d < D)` each load sat in a block of its own and was waited for there — NK dependent round trips
+  // (ten at head size 160, twice that in the backward) in front of the K/V staging they were meant to overlap.
+  typename Traits<T>::frag v[NK];
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc) v[kc] = load_frag<T>(xrow + min((kc << 4) + (g << 2), D - 4));
 #pragma unroll
   for (int kc = 0; kc < NK; ++kc) {
     const int d = (kc << 4) + (g << 2);
-    x[kc] = zero_frag<T>();
-    if (ok && d < D) x[kc] = load_frag<T>(xrow + d);
+    x[kc] = (ok && d < D) ? v[kc] : zero_frag<T>();
   }
 }
 

@@ -155,8 +155,30 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T
   constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, JN = WN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, fr = lane_pixel(lane & 31, a.lane_rot), fh = lane >> 5;
+  // Bias and residual of this thread's output vectors, requested in ONE batch with clamped addresses — at entry, or, in a
+  // split-K launch, by the slice that goes on to reduce (in front of its slab reads).  The first form loaded them inside the
+  // output loop, each behind its own wait: two dependent round trips per output vector, 8 (128 x 64 tile) to 16 (128 x 128) in
+  // a row at the end of every launch.
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int VPR = BN / 8;                      // 16-byte vectors per tile row
+  constexpr int NV = BM * VPR / kThreads;          // output vectors per thread; kThreads % VPR == 0: one column run per thread
+  static_assert(BM * VPR % kThreads == 0 && kThreads % VPR == 0, "output vector map");
+  const int cv = (tid % VPR) * 8, r0 = tid / VPR;
+  u32x4 bvec = {0u, 0u, 0u, 0u}, rvec[NV];
+  auto prefetch = [&]() {
+    const int nc = min(n0 + cv, a.Cout - 8);
+    if (bias != nullptr) bvec = *reinterpret_cast<const u32x4*>(bias + nc);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      rvec[k] = u32x4{0u, 0u, 0u, 0u};
+      if (residual != nullptr) {
+        const int m = min(m0 + r0 + k * (kThreads / VPR), a.M - 1);
+        rvec[k] = *reinterpret_cast<const u32x4*>(residual + (size_t)m * a.Cout + nc);
+      }
+    }
+  };
+  if constexpr (!SPLITK) prefetch();
   if constexpr (SPLITK) {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr int QUADS = JN * IM * 4;
     const int tile = (n0 / BN) * a.tm + m0 / BM;
     const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(part, 0, 0x7ffffff0, 0x00020000);
@@ -190,6 +212,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T
     const int last = flag[0];
     __syncthreads();
     if (!last) return;
+    prefetch();
 #pragma unroll
     for (int j = 0; j < JN; ++j)
 #pragma unroll
@@ -226,24 +249,20 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T
           store_frag<T>(Cs + (wm * WM + i * 32 + fr) * LDC + wn * WN + j * 32 + 8 * qd + 4 * fh, f);
         }
     __syncthreads();
-    constexpr int VPR = BN / 8;                    // 16-byte vectors per tile row
-    for (int v = tid; v < BM * VPR; v += kThreads) {
-      const int r = v / VPR, cv = (v - r * VPR) * 8;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int r = r0 + k * (kThreads / VPR);
       const int m = m0 + r, n = n0 + cv;
-      if (m >= a.M || n >= a.Cout) continue;
       uint4 val = *reinterpret_cast<const uint4*>(Cs + r * LDC + cv);
       if (bias != nullptr || residual != nullptr) {
         T* e = reinterpret_cast<T*>(&val);
-        uint4 bv = uint4{0, 0, 0, 0}, rv = uint4{0, 0, 0, 0};
-        if (bias != nullptr) bv = *reinterpret_cast<const uint4*>(bias + n);
-        if (residual != nullptr) rv = *reinterpret_cast<const uint4*>(residual + (size_t)m * a.Cout + n);
-        const T* be = reinterpret_cast<const T*>(&bv);
-        const T* re = reinterpret_cast<const T*>(&rv);
+        const T* be = reinterpret_cast<const T*>(&bvec);
+        const T* re = reinterpret_cast<const T*>(&rvec[k]);
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          e[k] = Traits<T>::from_f32(Traits<T>::to_f32(e[k]) + Traits<T>::to_f32(be[k]) + Traits<T>::to_f32(re[k]));
+        for (int q = 0; q < 8; ++q)
+          e[q] = Traits<T>::from_f32(Traits<T>::to_f32(e[q]) + Traits<T>::to_f32(be[q]) + Traits<T>::to_f32(re[q]));
       }
-      *reinterpret_cast<uint4*>(Y + (size_t)m * a.Cout + n) = val;
+      if (m < a.M && n < a.Cout) *reinterpret_cast<uint4*>(Y + (size_t)m * a.Cout + n) = val;
     }
   }
 }

@@ -30,6 +30,36 @@ struct Item {
   T v[W];
 };
 
+// Two statements that pin "request everything, then compute" in the instruction stream: `loads_issued()` is a compiler
+// barrier for memory operations (the loads above it stay above it), and a value passed through `opaque()` BELOW it cannot be
+// consumed above it.  Without them the scheduler converts a freshly loaded per-channel constant right behind its load — a
+// wait for that one load in front of all the loads that follow it.
+__device__ __forceinline__ void loads_issued() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::: "memory");
+#endif
+}
+template <typename V>
+__device__ __forceinline__ void opaque(V& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (sizeof(V) == 4) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    asm volatile("" : "+v"(u));
+    v = __builtin_bit_cast(V, u);
+  } else if constexpr (sizeof(V) == 8) {
+    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    asm volatile("" : "+v"(u));
+    v = __builtin_bit_cast(V, u);
+  } else {
+    static_assert(sizeof(V) == 16, "opaque(): 4, 8 or 16 bytes");
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t u = __builtin_bit_cast(u32x4_t, v);
+    asm volatile("" : "+v"(u));
+    v = __builtin_bit_cast(V, u);
+  }
+#endif
+}
+
 // v_rcp_f32 (1 ulp), not an IEEE division (ten instructions per element in every GroupNorm + SiLU pass)
 __device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
 
@@ -122,14 +152,17 @@ __device__ __forceinline__ void fold_partials(const float* __restrict__ partial,
     float2 v[kMaxStatsNB / 8];
 #pragma unroll
     for (int i = 0; i < kMaxStatsNB / 8; ++i) {
+      // clamped, not predicated: sixteen loads back to back (under a condition each sat in its own block and the first was
+      // waited for alone); what lies past the edge is dropped by the selects below
       const int nb = part + 8 * i;
-      v[i] = (g < G && nb < NB) ? pp[(size_t)nb * G + g] : float2{0.f, 0.f};
+      v[i] = pp[(size_t)min(nb, NB - 1) * G + min(g, G - 1)];
     }
     float sa = 0.f, sc = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxStatsNB / 8; ++i) {
-      sa += v[i].x;
-      sc += v[i].y;
+      const bool in = g < G && part + 8 * i < NB;
+      sa += in ? v[i].x : 0.f;
+      sc += in ? v[i].y : 0.f;
     }
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) {
@@ -424,17 +457,20 @@ __global__ __launch_bounds__(kThreads) void gn_wide_stats_kernel(const T* __rest
 #pragma unroll
   for (int j = 0; j < 8; ++j) c0[j] = c1[j] = cb[j] = 0.f;
   if (m.active) {
+    const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
+    // the first (normally the only) batch of activation loads goes out before the channel bias is touched: converted where
+    // it was loaded, the bias was a round trip of its own in front of them
+    Vec8<T> v[kUS];
+    int p = p0 + m.pr;
+#pragma unroll
+    for (int u = 0; u < kUS; ++u)
+      if (p + u * m.RP < p1) v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
     if (cbias != nullptr) {
       const Vec8<T> bv = reinterpret_cast<const Vec8<T>*>(cbias + (size_t)b * C)[m.vec];
 #pragma unroll
       for (int j = 0; j < 8; ++j) cb[j] = Traits<T>::to_f32(bv.v[j]);
     }
-    const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
-    for (int p = p0 + m.pr; p < p1; p += kUS * m.RP) {
-      Vec8<T> v[kUS];
-#pragma unroll
-      for (int u = 0; u < kUS; ++u)
-        if (p + u * m.RP < p1) v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
+    for (; p < p1; p += kUS * m.RP) {
 #pragma unroll
       for (int u = 0; u < kUS; ++u)
         if (p + u * m.RP < p1) {
@@ -445,6 +481,10 @@ __global__ __launch_bounds__(kThreads) void gn_wide_stats_kernel(const T* __rest
             c1[j] += a * a;
           }
         }
+      const int pn = p + kUS * m.RP;
+#pragma unroll
+      for (int u = 0; u < kUS; ++u)
+        if (pn + u * m.RP < p1) v[u] = xb[(size_t)(pn + u * m.RP) * m.VP];
     }
   }
   wide_fold(m, c0, c1, C, G, lds4, partial + ((size_t)b * gridDim.x + nb) * G * 2);
@@ -471,14 +511,17 @@ __global__ __launch_bounds__(kThreads) void gn_wide_apply_kernel(const T* __rest
     for (int u = 0; u < kU; ++u)
       if (p + u * m.RP < p1) v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
   }
+  // gamma / beta (cold weights) and the channel bias are requested here too: behind the fold they were one more dependent
+  // round trip to memory after its barrier
+  // by every thread (m.vec is a valid vector index for the idle ones too): under `if (m.active)` the three values were
+  // merged behind waits before the fold's own loads could go out
+  const Vec8<T> gm = reinterpret_cast<const Vec8<T>*>(gamma)[m.vec], bt = reinterpret_cast<const Vec8<T>*>(beta)[m.vec];
+  const Vec8<T> bv = reinterpret_cast<const Vec8<T>*>(cbias != nullptr ? cbias + (size_t)b * C : x + (size_t)b * HW * C)[m.vec];
   fold_partials<true>(partial, b, NB, G, inv_n, eps, res, blockIdx.x == 0 ? stats : nullptr);
   if (!m.active) return;
   const float* mr = reinterpret_cast<const float*>(res);
   float sc[8], sh[8];
   {
-    const Vec8<T> gm = reinterpret_cast<const Vec8<T>*>(gamma)[m.vec], bt = reinterpret_cast<const Vec8<T>*>(beta)[m.vec];
-    Vec8<T> bv;
-    if (cbias != nullptr) bv = reinterpret_cast<const Vec8<T>*>(cbias + (size_t)b * C)[m.vec];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int g = j < m.split ? m.gA : m.gA + 1;
@@ -507,23 +550,32 @@ __global__ __launch_bounds__(kThreads) void gn_wide_apply_kernel(const T* __rest
   }
 }
 
-// the per-channel constants the backward kernels share
+// the per-channel constants the backward kernels share: `fetch` only requests them (gamma / beta are cold weights), `finish`
+// converts — between the two the kernels issue their activation loads, so that everything is one round trip
 template <typename T>
 struct WideBwdConst {
+  Vec8<T> g8, b8, c8;
+  float2 st[2];
   float mu[8], rs[8], gm[8], bt[8], cb[8];
-  __device__ __forceinline__ void load(const WideMap& m, const T* cbias, const T* gamma, const T* beta,
-                                       const float* stats, int b, int C, int G) {
-    const Vec8<T> g8 = reinterpret_cast<const Vec8<T>*>(gamma)[m.vec], b8 = reinterpret_cast<const Vec8<T>*>(beta)[m.vec];
-    Vec8<T> c8;
-    if (cbias != nullptr) c8 = reinterpret_cast<const Vec8<T>*>(cbias + (size_t)b * C)[m.vec];
+  // x_img: the image's activations — what the bias load reads when there is no channel bias (dropped by `finish`)
+  __device__ __forceinline__ void fetch(const WideMap& m, const T* cbias, const T* gamma, const T* beta, const float* stats,
+                                        const T* x_img, int b, int C, int G) {
+    g8 = reinterpret_cast<const Vec8<T>*>(gamma)[m.vec];
+    b8 = reinterpret_cast<const Vec8<T>*>(beta)[m.vec];
+    c8 = reinterpret_cast<const Vec8<T>*>(cbias != nullptr ? cbias + (size_t)b * C : x_img)[m.vec];   // no branch (see opaque())
+    const float2* s2 = reinterpret_cast<const float2*>(stats) + (size_t)b * G;
+    st[0] = s2[m.gA];
+    st[1] = s2[min(m.gA + 1, G - 1)];
+  }
+  __device__ __forceinline__ void finish(const WideMap& m, bool has_cb) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int g = j < m.split ? m.gA : m.gA + 1;
-      mu[j] = stats[((size_t)b * G + g) * 2];
-      rs[j] = stats[((size_t)b * G + g) * 2 + 1];
+      const float2 s = j < m.split ? st[0] : st[1];
+      mu[j] = s.x;
+      rs[j] = s.y;
       gm[j] = Traits<T>::to_f32(g8.v[j]);
       bt[j] = Traits<T>::to_f32(b8.v[j]);
-      cb[j] = cbias != nullptr ? Traits<T>::to_f32(c8.v[j]) : 0.f;
+      cb[j] = has_cb ? Traits<T>::to_f32(c8.v[j]) : 0.f;
     }
   }
 };
@@ -544,17 +596,19 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_stats_kernel(const T* __
   for (int j = 0; j < 8; ++j) c0[j] = c1[j] = 0.f;
   if (m.active) {
     WideBwdConst<T> k;
-    k.load(m, cbias, gamma, beta, stats, b, C, G);
+    k.fetch(m, cbias, gamma, beta, stats, x + (size_t)b * HW * C, b, C, G);
     const Vec8<T>* xb = reinterpret_cast<const Vec8<T>*>(x + (size_t)b * HW * C) + m.vec;
     const Vec8<T>* db = reinterpret_cast<const Vec8<T>*>(dy + (size_t)b * HW * C) + m.vec;
-    for (int p = p0 + m.pr; p < p1; p += kU * m.RP) {
-      Vec8<T> v[kU], d[kU];
+    Vec8<T> v[kU], d[kU];
+    int p = p0 + m.pr;
 #pragma unroll
-      for (int u = 0; u < kU; ++u)
-        if (p + u * m.RP < p1) {
-          v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
-          d[u] = db[(size_t)(p + u * m.RP) * m.VP];
-        }
+    for (int u = 0; u < kU; ++u)
+      if (p + u * m.RP < p1) {
+        v[u] = xb[(size_t)(p + u * m.RP) * m.VP];
+        d[u] = db[(size_t)(p + u * m.RP) * m.VP];
+      }
+    k.finish(m, cbias != nullptr);
+    for (; p < p1; p += kU * m.RP) {
 #pragma unroll
       for (int u = 0; u < kU; ++u)
         if (p + u * m.RP < p1) {
@@ -565,6 +619,13 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_stats_kernel(const T* __
             c0[j] += dh;
             c1[j] += dh * yh;
           }
+        }
+      const int pn = p + kU * m.RP;
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (pn + u * m.RP < p1) {
+          v[u] = xb[(size_t)(pn + u * m.RP) * m.VP];
+          d[u] = db[(size_t)(pn + u * m.RP) * m.VP];
         }
     }
   }
@@ -598,10 +659,11 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
         if (gres != nullptr) gr[u] = rb[(size_t)(p + u * m.RP) * m.VP];
       }
   }
+  WideBwdConst<T> k;
+  k.fetch(m, cbias, gamma, beta, stats, x + (size_t)b * HW * C, b, C, G);   // by every thread: no merge behind a wait
   fold_partials<false>(partial, b, NB, G, inv_n, 0.f, res, nullptr);
   if (!m.active) return;
-  WideBwdConst<T> k;
-  k.load(m, cbias, gamma, beta, stats, b, C, G);
+  k.finish(m, cbias != nullptr);
   float a1[8], a2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -636,8 +698,8 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
 
 // ---- small slabs (the 16x16 and 8x8 levels, and 32x32 at 640 channels: a group's slab of <= 20 480 elements): one launch,
 // one workgroup per (image, group).
-// The group's slab (HW pixels x C/G channels, <= 20 480 elements) is read once into LDS while the sums are taken,
-// reduced in-block, then normalised from LDS: a single ~4 us latency chain instead of three launches.
+// The group's slab (HW pixels x C/G channels, <= 20 480 elements) is read once into REGISTERS while the sums are taken,
+// reduced in-block, then normalised from there: a single latency chain instead of three launches.
 constexpr int kSmallMaxElems = 20480;
 // pixels per thread at most: ceil(HW / floor(NT / hp)) <= 2 HW hp / NT + 1, with HW hp <= 10240 at NT = 1024 and < 2048 at
 // NT = 256 (small_wide): 21 and 17
@@ -667,35 +729,42 @@ __device__ __forceinline__ void block_sum2(float& a, float& c, float* red) {
 
 // Thread t owns channel pair j = t % (Cg/2) of the group for pixels p0, p0 + rows, ... (rows = NT / (Cg/2)), so the
 // per-channel gamma / beta / bias are loaded once and the loops carry no integer division.
-template <typename T, bool ACT, int NT>
+// EVERYTHING a thread reads from memory — its <= kSmallIters slab pieces, the channel bias, gamma, beta — is requested in one
+// batch up front and the slab stays in registers between the two passes.  The first form took the bias first (a round trip of
+// its own), then the slab four pieces per round trip (`#pragma unroll 4`: five dependent round trips at 32 x 32 x 640), then
+// gamma / beta behind the block reduction (cold weights: a third kind of round trip) — ~7 us for a 40 KB slab.
+// IT = pieces per thread the launch is built for (the host takes the smallest of 4 / 8 / 12 / 24 that covers the shape): the
+// loads are unconditional with clamped addresses — a load under `if (k < iters)` into a register array came out of the
+// compiler as load, wait, copy, one at a time.
+template <typename T, bool ACT, int NT, int IT>
 __global__ __launch_bounds__(NT) void gn_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
                                                           const T* __restrict__ gamma, const T* __restrict__ beta,
                                                           T* __restrict__ y, float* __restrict__ stats, int HW,
                                                           int C, int G, float eps) {
   extern __shared__ __attribute__((aligned(16))) char smem_small[];
   float* red = reinterpret_cast<float*>(smem_small);
-  float2* slab = reinterpret_cast<float2*>(red + 32);  // [HW][Cg/2]: x + channel bias
   const int g = blockIdx.x, b = blockIdx.y, Cg = C / G, hp = Cg >> 1;
   const int rows = NT / hp, p0 = threadIdx.x / hp, j = threadIdx.x - p0 * hp;
   const bool active = p0 < rows;
-  const int ch = g * Cg + 2 * j;
+  const int ch = g * Cg + 2 * (active ? j : 0);
   const size_t base = (size_t)b * HW * C + ch;
-  float cb0 = 0.f, cb1 = 0.f;
-  if (active && cbias != nullptr) {
-    cb0 = Traits<T>::to_f32(cbias[(size_t)b * C + ch]);
-    cb1 = Traits<T>::to_f32(cbias[(size_t)b * C + ch + 1]);
-  }
+  // no branch around any of these loads (a conditional load is waited for where it is issued): without a channel bias the
+  // bias load reads a stand-in (not gamma: the compiler then re-uses gamma's register behind a wait) and a select drops it
+  // the per-channel constants are requested LAST: whatever consumes one waits for everything, and everything is on its way
+  Item<T, 2> xv[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) xv[k] = *reinterpret_cast<const Item<T, 2>*>(x + base + (size_t)min(p0 + k * rows, HW - 1) * C);
+  const Item<T, 2> gmv = *reinterpret_cast<const Item<T, 2>*>(gamma + ch), btv = *reinterpret_cast<const Item<T, 2>*>(beta + ch);
+  const Item<T, 2> cbv = *reinterpret_cast<const Item<T, 2>*>(cbias != nullptr ? cbias + (size_t)b * C + ch : x + base);
+  const float cb0 = cbias != nullptr ? Traits<T>::to_f32(cbv.v[0]) : 0.f, cb1 = cbias != nullptr ? Traits<T>::to_f32(cbv.v[1]) : 0.f;
   float sa = 0.f, sc = 0.f;
-  if (active) {
-#pragma unroll 4
-    for (int p = p0; p < HW; p += rows) {
-      const Item<T, 2> v = *reinterpret_cast<const Item<T, 2>*>(x + base + (size_t)p * C);
-      const float a0 = Traits<T>::to_f32(v.v[0]) + cb0, a1 = Traits<T>::to_f32(v.v[1]) + cb1;
-      slab[p * hp + j] = make_float2(a0, a1);
+#pragma unroll
+  for (int k = 0; k < IT; ++k)
+    if (active && p0 + k * rows < HW) {
+      const float a0 = Traits<T>::to_f32(xv[k].v[0]) + cb0, a1 = Traits<T>::to_f32(xv[k].v[1]) + cb1;
       sa += a0 + a1;
       sc += a0 * a0 + a1 * a1;
     }
-  }
   block_sum2<NT>(sa, sc, red);
   const float inv_n = 1.0f / ((float)HW * (float)Cg);
   const double mean_d = (double)sa * inv_n;
@@ -706,24 +775,29 @@ __global__ __launch_bounds__(NT) void gn_small_fwd_kernel(const T* __restrict__ 
     stats[((size_t)b * G + g) * 2 + 1] = rstd;
   }
   if (!active) return;
-  const float g0 = Traits<T>::to_f32(gamma[ch]) * rstd, g1 = Traits<T>::to_f32(gamma[ch + 1]) * rstd;
-  const float b0 = Traits<T>::to_f32(beta[ch]) - mean * g0, b1 = Traits<T>::to_f32(beta[ch + 1]) - mean * g1;
-#pragma unroll 4
-  for (int p = p0; p < HW; p += rows) {
-    const float2 a = slab[p * hp + j];
-    float z0 = a.x * g0 + b0, z1 = a.y * g1 + b1;
-    if (ACT) {
-      z0 *= sigmoidf_(z0);
-      z1 *= sigmoidf_(z1);
+  const float g0 = Traits<T>::to_f32(gmv.v[0]) * rstd, g1 = Traits<T>::to_f32(gmv.v[1]) * rstd;
+  const float b0 = Traits<T>::to_f32(btv.v[0]) - mean * g0, b1 = Traits<T>::to_f32(btv.v[1]) - mean * g1;
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int p = p0 + k * rows;
+    if (p < HW) {
+      float z0 = (Traits<T>::to_f32(xv[k].v[0]) + cb0) * g0 + b0, z1 = (Traits<T>::to_f32(xv[k].v[1]) + cb1) * g1 + b1;
+      if (ACT) {
+        z0 *= sigmoidf_(z0);
+        z1 *= sigmoidf_(z1);
+      }
+      Item<T, 2> o;
+      o.v[0] = Traits<T>::from_f32(z0);
+      o.v[1] = Traits<T>::from_f32(z1);
+      *reinterpret_cast<Item<T, 2>*>(y + base + (size_t)p * C) = o;
     }
-    Item<T, 2> o;
-    o.v[0] = Traits<T>::from_f32(z0);
-    o.v[1] = Traits<T>::from_f32(z1);
-    *reinterpret_cast<Item<T, 2>*>(y + base + (size_t)p * C) = o;
   }
 }
 
-template <typename T, bool ACT, int NT>
+// Backward of the same: x, dy, the skip connection's gradient, the forward's statistics and the per-channel constants are all
+// requested in one batch (the first form read the statistics, then the constants, then x / dy four pixels per round trip).
+// IT as in the forward; at IT = 24 (no SD shape) the skip connection's gradient is loaded where it is used (register budget).
+template <typename T, bool ACT, int NT, int IT>
 __global__ __launch_bounds__(NT) void gn_small_bwd_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
                                                           const T* __restrict__ dy, const T* __restrict__ gamma,
                                                           const T* __restrict__ beta,
@@ -734,43 +808,55 @@ __global__ __launch_bounds__(NT) void gn_small_bwd_kernel(const T* __restrict__ 
   float* red = reinterpret_cast<float*>(smem_small);
   float2* dh = reinterpret_cast<float2*>(red + 32);  // [HW][Cg/2] dL/dyhat
   const int g = blockIdx.x, b = blockIdx.y, Cg = C / G, hp = Cg >> 1;
-  Item<T, 2>* xs = reinterpret_cast<Item<T, 2>*>(dh + HW * hp);  // [HW][Cg/2] x as read (yhat is recomputed)
   const int rows = NT / hp, p0 = threadIdx.x / hp, j = threadIdx.x - p0 * hp;
   const bool active = p0 < rows;
   const int ch = g * Cg + 2 * j;
   const size_t base = (size_t)b * HW * C + ch;
-  const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
-  float s0 = 0.f, s1 = 0.f, cb0 = 0.f, cb1 = 0.f;
-  if (active) {
-    if (cbias != nullptr) {
-      cb0 = Traits<T>::to_f32(cbias[(size_t)b * C + ch]);
-      cb1 = Traits<T>::to_f32(cbias[(size_t)b * C + ch + 1]);
-    }
-    cb0 -= mean;
-    cb1 -= mean;
-    const float g0 = Traits<T>::to_f32(gamma[ch]), g1 = Traits<T>::to_f32(gamma[ch + 1]);
-    const float b0 = Traits<T>::to_f32(beta[ch]), b1 = Traits<T>::to_f32(beta[ch + 1]);
-#pragma unroll 4
-    for (int p = p0; p < HW; p += rows) {
-      const Item<T, 2> v = *reinterpret_cast<const Item<T, 2>*>(x + base + (size_t)p * C);
-      const Item<T, 2> d = *reinterpret_cast<const Item<T, 2>*>(dy + base + (size_t)p * C);
-      const float y0 = (Traits<T>::to_f32(v.v[0]) + cb0) * rstd;
-      const float y1 = (Traits<T>::to_f32(v.v[1]) + cb1) * rstd;
-      const float d0 = dyhat_of<ACT>(y0, Traits<T>::to_f32(d.v[0]), g0, b0);
-      const float d1 = dyhat_of<ACT>(y1, Traits<T>::to_f32(d.v[1]), g1, b1);
-      dh[p * hp + j] = make_float2(d0, d1);
-      xs[p * hp + j] = v;
-      s0 += d0 + d1;
-      s1 += d0 * y0 + d1 * y1;
+  constexpr bool kBatch = sizeof(T) == 2 || IT <= 12;       // fp32 at 24 pieces (no SD shape): loads where they are used
+  constexpr bool kEarlyRes = kBatch && IT <= 12;             // register budget (128 VGPRs at 1024 threads)
+  // no branch around any load, the per-channel constants last (see the forward)
+  Item<T, 2> xv[kBatch ? IT : 1], dv[kBatch ? IT : 1], gr[kEarlyRes ? IT : 1];
+  if constexpr (kBatch) {
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const size_t off = base + (size_t)min(p0 + k * rows, HW - 1) * C;
+      xv[k] = *reinterpret_cast<const Item<T, 2>*>(x + off);
+      dv[k] = *reinterpret_cast<const Item<T, 2>*>(dy + off);
     }
   }
-  // the skip connection's gradient: all of this thread's loads in flight across the block reduction
-  Item<T, 2> gr[kSmallIters];
-  if (active && gres != nullptr) {
+  if constexpr (kEarlyRes) {
+    const T* gsrc = gres != nullptr ? gres : dy;             // valid stand-in, dropped by the select below
 #pragma unroll
-    for (int k = 0; k < kSmallIters; ++k) {
-      const int p = p0 + k * rows;
-      if (p < HW) gr[k] = *reinterpret_cast<const Item<T, 2>*>(gres + base + (size_t)p * C);
+    for (int k = 0; k < IT; ++k) gr[k] = *reinterpret_cast<const Item<T, 2>*>(gsrc + base + (size_t)min(p0 + k * rows, HW - 1) * C);
+  }
+  const float2 mr = *reinterpret_cast<const float2*>(stats + ((size_t)b * G + g) * 2);
+  const Item<T, 2> gmv = *reinterpret_cast<const Item<T, 2>*>(gamma + ch), btv = *reinterpret_cast<const Item<T, 2>*>(beta + ch);
+  const Item<T, 2> cbv = *reinterpret_cast<const Item<T, 2>*>(cbias != nullptr ? cbias + (size_t)b * C + ch : x + base);
+  const float mean = mr.x, rstd = mr.y;
+  const float cb0 = (cbias != nullptr ? Traits<T>::to_f32(cbv.v[0]) : 0.f) - mean;
+  const float cb1 = (cbias != nullptr ? Traits<T>::to_f32(cbv.v[1]) : 0.f) - mean;
+  const float g0 = Traits<T>::to_f32(gmv.v[0]), g1 = Traits<T>::to_f32(gmv.v[1]);
+  const float b0 = Traits<T>::to_f32(btv.v[0]), b1 = Traits<T>::to_f32(btv.v[1]);
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int p = p0 + k * rows;
+    if (active && p < HW) {
+      Item<T, 2> xk, dk;
+      if constexpr (kBatch) {
+        xk = xv[k];
+        dk = dv[k];
+      } else {
+        xk = *reinterpret_cast<const Item<T, 2>*>(x + base + (size_t)p * C);
+        dk = *reinterpret_cast<const Item<T, 2>*>(dy + base + (size_t)p * C);
+      }
+      const float y0 = (Traits<T>::to_f32(xk.v[0]) + cb0) * rstd;
+      const float y1 = (Traits<T>::to_f32(xk.v[1]) + cb1) * rstd;
+      const float d0 = dyhat_of<ACT>(y0, Traits<T>::to_f32(dk.v[0]), g0, b0);
+      const float d1 = dyhat_of<ACT>(y1, Traits<T>::to_f32(dk.v[1]), g1, b1);
+      dh[p * hp + j] = make_float2(d0, d1);   // own entries only: read back by this thread after the reduction
+      s0 += d0 + d1;
+      s1 += d0 * y0 + d1 * y1;
     }
   }
   block_sum2<NT>(s0, s1, red);
@@ -778,35 +864,59 @@ __global__ __launch_bounds__(NT) void gn_small_bwd_kernel(const T* __restrict__ 
   const float inv_n = 1.0f / ((float)HW * (float)Cg);
   const float m1 = s0 * inv_n, m2 = s1 * inv_n;
 #pragma unroll
-  for (int k = 0; k < kSmallIters; ++k) {
+  for (int k = 0; k < IT; ++k) {
     const int p = p0 + k * rows;
-    if (p >= HW) break;
-    const float2 a = dh[p * hp + j];
-    const Item<T, 2> v = xs[p * hp + j];
-    const float y0 = (Traits<T>::to_f32(v.v[0]) + cb0) * rstd;
-    const float y1 = (Traits<T>::to_f32(v.v[1]) + cb1) * rstd;
-    const float r0 = gres != nullptr ? Traits<T>::to_f32(gr[k].v[0]) : 0.f;
-    const float r1 = gres != nullptr ? Traits<T>::to_f32(gr[k].v[1]) : 0.f;
-    Item<T, 2> o;
-    o.v[0] = Traits<T>::from_f32(rstd * (a.x - m1 - y0 * m2) + r0);
-    o.v[1] = Traits<T>::from_f32(rstd * (a.y - m1 - y1 * m2) + r1);
-    *reinterpret_cast<Item<T, 2>*>(dx + base + (size_t)p * C) = o;
+    if (p < HW) {
+      const float2 a = dh[p * hp + j];
+      Item<T, 2> xk;
+      if constexpr (kBatch) xk = xv[k];
+      else xk = *reinterpret_cast<const Item<T, 2>*>(x + base + (size_t)p * C);
+      const float y0 = (Traits<T>::to_f32(xk.v[0]) + cb0) * rstd;
+      const float y1 = (Traits<T>::to_f32(xk.v[1]) + cb1) * rstd;
+      float r0 = 0.f, r1 = 0.f;
+      if (gres != nullptr) {
+        Item<T, 2> gv;
+        if constexpr (kEarlyRes) gv = gr[k];
+        else gv = *reinterpret_cast<const Item<T, 2>*>(gres + base + (size_t)p * C);
+        r0 = Traits<T>::to_f32(gv.v[0]);
+        r1 = Traits<T>::to_f32(gv.v[1]);
+      }
+      Item<T, 2> o;
+      o.v[0] = Traits<T>::from_f32(rstd * (a.x - m1 - y0 * m2) + r0);
+      o.v[1] = Traits<T>::from_f32(rstd * (a.y - m1 - y1 * m2) + r1);
+      *reinterpret_cast<Item<T, 2>*>(dx + base + (size_t)p * C) = o;
+    }
   }
 }
 
 constexpr size_t kSmallHeader = 32 * sizeof(float);
 inline bool small_wide(int HW, int C, int G) { return (C / G) / 2 > 256 || HW * ((C / G) / 2) >= 2048; }
 
-template <typename T, bool ACT, int NT>
-int small_fwd_launch(const void* x, const void* cb, const void* gamma, const void* beta, void* y, float* stats, int B,
-                     int HW, int C, int G, float eps, hipStream_t s) {
-  const size_t lds = kSmallHeader + sizeof(float) * (size_t)HW * (C / G);
-  auto k = gn_small_fwd_kernel<T, ACT, NT>;
-  const int rc = set_dyn_lds(k, lds);
-  if (rc != GA_OK) return rc;
+template <typename T, bool ACT, int NT, int IT>
+int small_fwd_launch_it(const void* x, const void* cb, const void* gamma, const void* beta, void* y, float* stats, int B,
+                        int HW, int C, int G, float eps, hipStream_t s) {
+  const size_t lds = kSmallHeader;   // the slab stays in registers
+  auto k = gn_small_fwd_kernel<T, ACT, NT, IT>;
   hipLaunchKernelGGL(k, dim3(G, B), dim3(NT), lds, s, (const T*)x, (const T*)cb, (const T*)gamma, (const T*)beta,
                      (T*)y, stats, HW, C, G, eps);
   return check_launch();
+}
+
+// pieces per thread of a small-slab launch: ceil(HW / rows), rows = NT / (Cg / 2) — at most 21 (see kSmallIters)
+inline int small_iters(int HW, int C, int G, int NT) {
+  const int rows = NT / ((C / G) / 2);
+  return (HW + rows - 1) / rows;
+}
+
+template <typename T, bool ACT, int NT>
+int small_fwd_launch(const void* x, const void* cb, const void* gamma, const void* beta, void* y, float* stats, int B,
+                     int HW, int C, int G, float eps, hipStream_t s) {
+  const int it = small_iters(HW, C, G, NT);
+  if (it <= 4) return small_fwd_launch_it<T, ACT, NT, 4>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
+  if (it <= 8) return small_fwd_launch_it<T, ACT, NT, 8>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
+  if (it <= 12) return small_fwd_launch_it<T, ACT, NT, 12>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
+  if (it <= kSmallIters) return small_fwd_launch_it<T, ACT, NT, kSmallIters>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
+  return GA_ERR_SHAPE;
 }
 
 template <typename T>
@@ -819,16 +929,27 @@ int small_fwd(const void* x, const void* cb, const void* gamma, const void* beta
              : small_fwd_launch<T, false, 256>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
 }
 
-template <typename T, bool ACT, int NT>
-int small_bwd_launch(const void* x, const void* cb, const void* dy, const void* gamma, const void* beta,
-                     const float* stats, const void* gres, void* dx, int B, int HW, int C, int G, hipStream_t s) {
-  const size_t lds = kSmallHeader + (sizeof(float) + sizeof(T)) * (size_t)HW * (C / G);
-  auto k = gn_small_bwd_kernel<T, ACT, NT>;
+template <typename T, bool ACT, int NT, int IT>
+int small_bwd_launch_it(const void* x, const void* cb, const void* dy, const void* gamma, const void* beta,
+                        const float* stats, const void* gres, void* dx, int B, int HW, int C, int G, hipStream_t s) {
+  const size_t lds = kSmallHeader + sizeof(float) * (size_t)HW * (C / G);   // dL/dyhat; x stays in registers
+  auto k = gn_small_bwd_kernel<T, ACT, NT, IT>;
   const int rc = set_dyn_lds(k, lds);
   if (rc != GA_OK) return rc;
   hipLaunchKernelGGL(k, dim3(G, B), dim3(NT), lds, s, (const T*)x, (const T*)cb, (const T*)dy, (const T*)gamma,
                      (const T*)beta, stats, (const T*)gres, (T*)dx, HW, C, G);
   return check_launch();
+}
+
+template <typename T, bool ACT, int NT>
+int small_bwd_launch(const void* x, const void* cb, const void* dy, const void* gamma, const void* beta,
+                     const float* stats, const void* gres, void* dx, int B, int HW, int C, int G, hipStream_t s) {
+  const int it = small_iters(HW, C, G, NT);
+  if (it <= 4) return small_bwd_launch_it<T, ACT, NT, 4>(x, cb, dy, gamma, beta, stats, gres, dx, B, HW, C, G, s);
+  if (it <= 8) return small_bwd_launch_it<T, ACT, NT, 8>(x, cb, dy, gamma, beta, stats, gres, dx, B, HW, C, G, s);
+  if (it <= 12) return small_bwd_launch_it<T, ACT, NT, 12>(x, cb, dy, gamma, beta, stats, gres, dx, B, HW, C, G, s);
+  if (it <= kSmallIters) return small_bwd_launch_it<T, ACT, NT, kSmallIters>(x, cb, dy, gamma, beta, stats, gres, dx, B, HW, C, G, s);
+  return GA_ERR_SHAPE;
 }
 
 template <typename T>

@@ -104,42 +104,47 @@ __global__ __launch_bounds__(kThreads) void add_ln_bwd_kernel(const T* __restric
   const long long row = (long long)blockIdx.x * kRowsPerWg + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int cv = C / N;
-  const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+  // every operand of the row is requested in one batch, from vector indices clamped into the row (the statistics last: what
+  // consumes them then waits for everything, and everything is on its way).  Under `if (j < cv)` each vector's loads were
+  // issued and waited for in a block of their own, behind the statistics, and the skip connection's gradient in the second
+  // pass: five dependent round trips at 1280 channels.
+  Vec<T> xv[NV], dv[NV], gv[NV], rv[NV];
+  const T* rsrc = gres != nullptr ? gres : dy;   // stand-in, dropped below
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int j = min(lane + 64 * k, cv - 1);
+    xv[k] = reinterpret_cast<const Vec<T>*>(x + row * C)[j];
+    dv[k] = reinterpret_cast<const Vec<T>*>(dy + row * C)[j];
+    gv[k] = reinterpret_cast<const Vec<T>*>(gamma)[j];
+    rv[k] = reinterpret_cast<const Vec<T>*>(rsrc + row * C)[j];
+  }
+  const float2 mr = *reinterpret_cast<const float2*>(stats + row * 2);
+  __builtin_amdgcn_sched_barrier(0);   // the loads above are issued before anything below is scheduled
+  const float mean = mr.x, rstd = mr.y;
   float xh[NV][N], dh[NV][N];
   float s0 = 0.f, s1 = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int j = lane + 64 * k;
-    if (j < cv) {
-      const Vec<T> v = reinterpret_cast<const Vec<T>*>(x + row * C)[j];
-      const Vec<T> d = reinterpret_cast<const Vec<T>*>(dy + row * C)[j];
-      const Vec<T> gm = reinterpret_cast<const Vec<T>*>(gamma)[j];
+    const bool in = lane + 64 * k < cv;
 #pragma unroll
-      for (int e = 0; e < N; ++e) {
-        xh[k][e] = (Traits<T>::to_f32(v.v[e]) - mean) * rstd;
-        dh[k][e] = Traits<T>::to_f32(d.v[e]) * Traits<T>::to_f32(gm.v[e]);
-        s0 += dh[k][e];
-        s1 += dh[k][e] * xh[k][e];
-      }
+    for (int e = 0; e < N; ++e) {
+      xh[k][e] = (Traits<T>::to_f32(xv[k].v[e]) - mean) * rstd;
+      dh[k][e] = Traits<T>::to_f32(dv[k].v[e]) * Traits<T>::to_f32(gv[k].v[e]);
+      s0 += in ? dh[k][e] : 0.f;
+      s1 += in ? dh[k][e] * xh[k][e] : 0.f;
     }
   }
   const float m0 = wave_reduce_sum(s0) / (float)C, m1 = wave_reduce_sum(s1) / (float)C;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int j = lane + 64 * k;
-    if (j < cv) {
-      Vec<T> o;
-      if (gres != nullptr) {
-        const Vec<T> r = reinterpret_cast<const Vec<T>*>(gres + row * C)[j];
+    // computed by every lane, stored by those inside the row: with the arithmetic under the condition the compiler moved the
+    // skip gradient's loads into that block — behind the row reduction, where they are a dependent round trip again
+    Vec<T> o;
 #pragma unroll
-        for (int e = 0; e < N; ++e)
-          o.v[e] = Traits<T>::from_f32(rstd * (dh[k][e] - m0 - xh[k][e] * m1) + Traits<T>::to_f32(r.v[e]));
-      } else {
-#pragma unroll
-        for (int e = 0; e < N; ++e) o.v[e] = Traits<T>::from_f32(rstd * (dh[k][e] - m0 - xh[k][e] * m1));
-      }
-      reinterpret_cast<Vec<T>*>(dx + row * C)[j] = o;
-    }
+    for (int e = 0; e < N; ++e)
+      o.v[e] = Traits<T>::from_f32(rstd * (dh[k][e] - m0 - xh[k][e] * m1) + (gres != nullptr ? Traits<T>::to_f32(rv[k].v[e]) : 0.f));
+    if (j < cv) reinterpret_cast<Vec<T>*>(dx + row * C)[j] = o;
   }
 }
 

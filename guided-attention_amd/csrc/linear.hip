@@ -109,6 +109,12 @@ __device__ __forceinline__ void lds_read128(u32x4& dst, unsigned byte_address) {
   dst = u32x4{byte_address, 0u, 0u, 0u};
 #endif
 }
+// the value passes through an empty volatile asm: what is computed from it cannot be scheduled above this point
+__device__ __forceinline__ void opaque(u32x4& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#endif
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -154,18 +160,71 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 g) {
   return __builtin_elementwise_fma(hg, erf, hg);
 }
 
+// What the epilogue reads from memory besides the accumulators — bias or the LayerNorm fold's (shift, colsum) per output
+// column, the residual rows — is requested BEHIND THE FIRST RING LOADS and sits in registers when the main loop ends.  Loaded
+// where it is used (the first form of this kernel) the epilogue was a chain of dependent round trips at the end of every
+// launch: four bias loads, each behind its own `if (column < N)` and waited for on its own, then one residual load per
+// output vector — 3-5 us of pure latency in launches of 6-10 us.  Addresses are clamped instead of predicated (columns /
+// rows past the edge are computed and never stored).
+template <typename T, int BM, int BN, bool GEGLU, bool LN>
+struct LinPrefetch {
+  static constexpr int JN = BN / 64;
+  static constexpr int OUTC = GEGLU ? BN / 2 : BN;
+  static constexpr int VPR = OUTC / 8;                       // 16-byte vectors per output row
+  static constexpr int NV = BM * VPR / kThreads;             // output vectors per thread
+  static_assert(BM * VPR % kThreads == 0, "every thread stores the same number of vectors");
+  typename Traits<T>::frag bias[LN ? 1 : JN][LN ? 1 : 4];
+  f32x4 shift[LN ? JN : 1][LN ? 4 : 1], colsum[LN ? JN : 1][LN ? 4 : 1];
+  u32x4 res[GEGLU ? 1 : NV];
+  bool has_bias, has_res;
+
+  __device__ __forceinline__ void load(const LinArgs& a, const LinPtrs& p, int m0, int n0) {
+    constexpr int WN = BN / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, fh = lane >> 5;
+    const T* bp = static_cast<const T*>(p.bias);
+    has_bias = !LN && bp != nullptr;
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int c = wn * WN + j * 32 + 8 * qd + 4 * fh;
+        int n;                                               // row of W this column came from, clamped into the matrix
+        if (GEGLU) n = c < BN / 2 ? min(n0 + c, a.F - 4) : a.F + min(n0 + c - BN / 2, a.F - 4);
+        else n = min(n0 + c, a.N - 4);
+        if constexpr (LN) {
+          shift[j][qd] = *reinterpret_cast<const f32x4*>(p.ln_shift + n);
+          colsum[j][qd] = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+        } else {
+          if (has_bias) bias[j][qd] = load_frag<T>(bp + n);
+        }
+      }
+    const T* rp = static_cast<const T*>(p.residual);
+    has_res = !GEGLU && rp != nullptr;
+    if constexpr (!GEGLU) {
+      if (has_res) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          const int v = tid + k * kThreads, r = v / VPR, cv = (v - r * VPR) * 8;
+          const int m = min(m0 + r, a.M - 1), n = min(n0 + cv, a.N - 8);
+          res[k] = *reinterpret_cast<const u32x4*>(rp + (size_t)m * a.ld_res + n);
+        }
+      }
+    }
+  }
+};
+
 // Epilogue of both kernels: bias / LayerNorm algebra in registers, the tile through LDS (`Cs`, BM x (BN + 8) elements that no
 // pending LDS-DMA targets), out as whole 16-byte row pieces with GEGLU / the residual applied and the row partial sums taken.
 // acc[j][i][r]: tile column c = wn * WN + j * 32 + 8 * (r >> 2) + 4 * fh + (r & 3), tile row wm * WM + i * 32 + fr.
 template <typename T, int BM, int BN, bool GEGLU, bool LN>
 __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T* Cs, T* __restrict__ Y, const LinArgs& a,
                                              const LinPtrs& p, int m0, int n0, int nt, const float (&ln_mean)[BM / 64],
-                                             const float (&ln_rstd)[BM / 64]) {
+                                             const float (&ln_rstd)[BM / 64], const LinPrefetch<T, BM, BN, GEGLU, LN>& pre) {
   constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, JN = WN / 32;
   constexpr int LDC = BN + 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
-  const T* bias = static_cast<const T*>(p.bias);
 #pragma unroll
   for (int i = 0; i < IM; ++i)
 #pragma unroll
@@ -173,20 +232,14 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         const int c = wn * WN + j * 32 + 8 * qd + 4 * fh;
-        int n;                                               // row of W this column came from
-        if (GEGLU) n = c < BN / 2 ? n0 + c : a.F + n0 + c - BN / 2;
-        else n = n0 + c;
-        const bool ok = GEGLU ? (c < BN / 2 ? n0 + c : n0 + c - BN / 2) < a.F : n < a.N;
         float add[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-          if constexpr (LN) {
-            const f32x4 sv = *reinterpret_cast<const f32x4*>(p.ln_shift + n), cv = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+        if constexpr (LN) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) add[r] = sv[r], cs[r] = cv[r];
-          } else if (bias != nullptr) {
-            const typename Traits<T>::frag bv = load_frag<T>(bias + n);
+          for (int r = 0; r < 4; ++r) add[r] = pre.shift[j][qd][r], cs[r] = pre.colsum[j][qd][r];
+        } else {
+          if (pre.has_bias) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) add[r] = Traits<T>::to_f32(bv[r]);
+            for (int r = 0; r < 4; ++r) add[r] = Traits<T>::to_f32(pre.bias[j][qd][r]);
           }
         }
         typename Traits<T>::frag f;
@@ -211,10 +264,12 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
   __syncthreads();
   constexpr int OUTC = GEGLU ? BN / 2 : BN;       // columns of Y this tile writes
   constexpr int VPR = OUTC / 8;                   // 16-byte vectors per output row
+  constexpr int NV = BM * VPR / kThreads;
   static_assert((VPR & (VPR - 1)) == 0 && VPR <= 64, "the row reduction below shuffles inside a wave");
-  const T* residual = static_cast<const T*>(p.residual);
   const int n_out = GEGLU ? a.F : a.N;
-  for (int v = tid; v < BM * VPR; v += kThreads) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = tid + k * kThreads;
     const int r = v / VPR, cv = (v - r * VPR) * 8;
     const int m = m0 + r, n = n0 + cv;
     const bool ok = m < a.M && n < n_out;
@@ -222,23 +277,26 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
     T* e = reinterpret_cast<T*>(&val);
     if constexpr (GEGLU) {
       if (ok && p.preact != nullptr) {
-        T* pre = static_cast<T*>(p.preact) + (size_t)m * a.ld_pre;
-        *reinterpret_cast<uint4*>(pre + n) = val;
-        *reinterpret_cast<uint4*>(pre + a.F + n) = *reinterpret_cast<const uint4*>(Cs + r * LDC + BN / 2 + cv);
+        T* pre_row = static_cast<T*>(p.preact) + (size_t)m * a.ld_pre;
+        *reinterpret_cast<uint4*>(pre_row + n) = val;
+        *reinterpret_cast<uint4*>(pre_row + a.F + n) = *reinterpret_cast<const uint4*>(Cs + r * LDC + BN / 2 + cv);
       }
       const uint4 gv = *reinterpret_cast<const uint4*>(Cs + r * LDC + BN / 2 + cv);
       const T* ge = reinterpret_cast<const T*>(&gv);
 #pragma unroll
-      for (int k = 0; k < 8; k += 2) {
-        const f32x2 gl = gelu_erf2(f32x2{Traits<T>::to_f32(ge[k]), Traits<T>::to_f32(ge[k + 1])});
-        e[k] = Traits<T>::from_f32(Traits<T>::to_f32(e[k]) * gl.x);
-        e[k + 1] = Traits<T>::from_f32(Traits<T>::to_f32(e[k + 1]) * gl.y);
+      for (int q = 0; q < 8; q += 2) {
+        const f32x2 gl = gelu_erf2(f32x2{Traits<T>::to_f32(ge[q]), Traits<T>::to_f32(ge[q + 1])});
+        e[q] = Traits<T>::from_f32(Traits<T>::to_f32(e[q]) * gl.x);
+        e[q + 1] = Traits<T>::from_f32(Traits<T>::to_f32(e[q + 1]) * gl.y);
       }
-    } else if (residual != nullptr && ok) {
-      const uint4 rv = *reinterpret_cast<const uint4*>(residual + (size_t)m * a.ld_res + n);
-      const T* re = reinterpret_cast<const T*>(&rv);
+    } else {
+      if (pre.has_res) {
+        u32x4 rv = pre.res[k];
+        opaque(rv);   // the unpacking stays here: hoisted to the loads it made the prologue wait for them
+        const T* re = reinterpret_cast<const T*>(&rv);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) e[k] = Traits<T>::from_f32(Traits<T>::to_f32(e[k]) + Traits<T>::to_f32(re[k]));
+        for (int q = 0; q < 8; ++q) e[q] = Traits<T>::from_f32(Traits<T>::to_f32(e[q]) + Traits<T>::to_f32(re[q]));
+      }
     }
     if (ok) *reinterpret_cast<uint4*>(Y + (size_t)m * a.ldy + n) = val;
     if (p.row_partials_out != nullptr) {
@@ -246,8 +304,8 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
       float s1 = 0.f, s2 = 0.f;
       if (ok) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float x = Traits<T>::to_f32(e[k]);
+        for (int q = 0; q < 8; ++q) {
+          const float x = Traits<T>::to_f32(e[q]);
           s1 += x;
           s2 += x * x;
         }
@@ -342,29 +400,49 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 80 * 1024 ? 2
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-  // ---- LayerNorm fold: this lane's rows' statistics from the producer's partial sums (loads issued before the ring starts)
-  float ln_mean[IM], ln_rstd[IM];
-  if constexpr (LN) {
-#pragma unroll
-    for (int i = 0; i < IM; ++i) {
-      const int m = min(m0 + wm * WM + i * 32 + fr, a.M - 1);
-      float s1 = 0.f, s2 = 0.f;
-      for (int q = 0; q < a.ln_parts; ++q) {
-        const float2 v = *reinterpret_cast<const float2*>(p.ln_partials + ((size_t)m * a.ln_parts + q) * 2);
-        s1 += v.x;
-        s2 += v.y;
-      }
-      const float mean = s1 * a.ln_inv_k;
-      ln_mean[i] = mean;
-      ln_rstd[i] = rsqrtf(fmaxf(s2 * a.ln_inv_k - mean * mean, 0.f) + a.ln_eps);
-    }
-  }
-
   // ---- main loop: ring of NSTAGE slots, NSTAGE - 1 k-steps in flight
   constexpr int PRE = NSTAGE - 1;
 #pragma unroll
   for (int s = 0; s < PRE; ++s)
     if (s < nsteps) issue(s, s);
+  LinPrefetch<T, BM, BN, GEGLU, LN> pre;
+  pre.load(a, p, m0, n0);
+  // ---- LayerNorm fold: this lane's rows' statistics from the producer's partial sums.  Requested behind the first ring loads
+  // (in front of them they were a dependent round trip before the first operand load), four parts per row in flight (one
+  // load, one wait per part was up to 20 serial round trips at 1280 channels); summed in part order as before.
+  float ln_mean[IM], ln_rstd[IM];
+  if constexpr (LN) {
+    const float2* part[IM];
+    float s1[IM], s2[IM];
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+      const int m = min(m0 + wm * WM + i * 32 + fr, a.M - 1);
+      part[i] = reinterpret_cast<const float2*>(p.ln_partials) + (size_t)m * a.ln_parts;
+      s1[i] = s2[i] = 0.f;
+    }
+    for (int q0 = 0; q0 < a.ln_parts; q0 += 4) {
+      float2 v[IM][4];
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[i][u] = part[i][min(q0 + u, a.ln_parts - 1)];
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (q0 + u < a.ln_parts) {
+            s1[i] += v[i][u].x;
+            s2[i] += v[i][u].y;
+          }
+    }
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+      const float mean = s1[i] * a.ln_inv_k;
+      ln_mean[i] = mean;
+      ln_rstd[i] = rsqrtf(fmaxf(s2[i] * a.ln_inv_k - mean * mean, 0.f) + a.ln_eps);
+    }
+  }
+
   for (int it = 0; it < nsteps; ++it) {
     // my loads of step `it` have landed when at most the younger steps' instructions are outstanding
     const int younger = min(nsteps - 1 - it, PRE - 1);
@@ -471,7 +549,7 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 80 * 1024 ? 2
     ln_m[i] = LN ? ln_mean[i] : 0.f;
     ln_r[i] = LN ? ln_rstd[i] : 1.f;
   }
-  lin_epilogue<T, BM, BN, GEGLU, LN>(acc, lds, Y, a, p, m0, n0, nt, ln_m, ln_r);
+  lin_epilogue<T, BM, BN, GEGLU, LN>(acc, lds, Y, a, p, m0, n0, nt, ln_m, ln_r, pre);
 }
 
 template <typename T, int BM, int BN, int NSTAGE>

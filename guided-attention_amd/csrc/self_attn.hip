@@ -68,6 +68,7 @@ struct Stage {
   const T* base;      // the [rows][D] slice (wave-uniform: the loads take it as their scalar base)
   unsigned off[NP];   // PRE: byte offset of this lane's vector u inside tile 0, clamped in-bounds for idle lanes
   int aux[NP];        // PRE: row inside the tile, -1 = idle lane; else aux[0] = D
+  int tile_row0, seq_rows;   // !PRE: first row of the tile in flight and the sequence length (uniform), for value()
 
   __device__ __forceinline__ void init(const T* __restrict__ slice, int D, size_t row_stride) {
     base = slice;
@@ -116,8 +117,10 @@ struct Stage {
           }
         }
       }
-    } else {
+    } else if constexpr (sizeof(T) == 4 && NK > 5) {   // fp32 at head sizes > 80: register budget (no UNet here runs it)
       const int D = aux[0];
+      tile_row0 = 0;
+      seq_rows = 1 << 30;   // value(): what was not loaded is already zero
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const int idx = u * NT + (threadIdx.x & (NT - 1));
@@ -126,9 +129,32 @@ struct Stage {
         if (idx < TOTAL && row0 + r < N && d < D)
           v[u] = *reinterpret_cast<const uint4*>(base + (size_t)(row0 + r) * row_stride + d);
       }
+    } else {
+      // Unconditional loads from (row, column) clamped into the slice; what is dead (beyond the tile, the sequence or the
+      // head size) becomes zero in value(), where the data is consumed.  With the load under the condition every vector
+      // sat in a block of its own behind a wait: the "prefetch" of the backward kernels was one round trip per vector.
+      const int D = aux[0];
+      tile_row0 = row0;
+      seq_rows = N;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int idx = u * NT + (threadIdx.x & (NT - 1));
+        const int r = idx / VPR, d = (idx - r * VPR) * VEC;
+        const int rc = min(row0 + min(r, KT - 1), N - 1), dc = min(d, D - VEC);
+        v[u] = *reinterpret_cast<const uint4*>(base + (size_t)rc * row_stride + dc);
+      }
     }
   }
-  __device__ __forceinline__ uint4 value(int u) const { return v[u]; }
+  __device__ __forceinline__ uint4 value(int u) const {
+    if constexpr (PRE || (sizeof(T) == 4 && NK > 5)) {
+      return v[u];
+    } else {
+      const int idx = u * NT + (threadIdx.x & (NT - 1));
+      const int r = idx / VPR, d = (idx - r * VPR) * VEC;
+      const bool live = idx < TOTAL && tile_row0 + r < seq_rows && d < aux[0];
+      return live ? v[u] : uint4{0, 0, 0, 0};
+    }
+  }
   // ones_d >= 0: the 16-byte vector that starts at column ones_d (the first pad vector of a head size that is not a
   // multiple of 16) is stored as {1, 0, 0, ...} instead of what was loaded: a column of ones in the V image makes the
   // P.V product deliver the softmax row sum in output row ones_d — no VALU adds for it (forward, 16-bit types).
@@ -362,15 +388,32 @@ __device__ __forceinline__ void tileT_times_frags(const T* col_image, const type
 template <typename T, int NK, int CB>
 __device__ __forceinline__ void load_col_frags(const T* __restrict__ base, size_t row_stride, int row0, int N, int D,
                                                int c, int g, typename Traits<T>::frag (&x)[CB][NK]) {
+  // Every chunk is loaded, from a (row, column) clamped into the tensor, and dropped by a select where it lies past the head
+  // size or the sequence: under `if (row < N && d < D)` each load sat in a block of its own and was waited for there — NK
+  // dependent round trips per operand in front of the first K/V tile (ten at head size 160, thirty in the dQ kernel, which
+  // loads Q, dO and O this way).
+  if constexpr (sizeof(T) == 4 && NK > 5) {   // fp32 at head sizes > 80 (register budget; not a shape any UNet here runs)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const int row = row0 + cb * 16 + c;
+#pragma unroll
+      for (int kc = 0; kc < NK; ++kc) {
+        const int d = kc * 16 + 4 * g;
+        x[cb][kc] = zero_frag<T>();
+        if (row < N && d < D) x[cb][kc] = load_frag<T>(base + (size_t)row * row_stride + d);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
     const int row = row0 + cb * 16 + c;
+    const T* src = base + (size_t)min(row, N - 1) * row_stride;
+    typename Traits<T>::frag v[NK];
 #pragma unroll
-    for (int kc = 0; kc < NK; ++kc) {
-      const int d = kc * 16 + 4 * g;
-      x[cb][kc] = zero_frag<T>();
-      if (row < N && d < D) x[cb][kc] = load_frag<T>(base + (size_t)row * row_stride + d);
-    }
+    for (int kc = 0; kc < NK; ++kc) v[kc] = load_frag<T>(src + min(kc * 16 + 4 * g, D - 4));
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) x[cb][kc] = (row < N && kc * 16 + 4 * g < D) ? v[kc] : zero_frag<T>();
   }
 }
 
