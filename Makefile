@@ -7,7 +7,11 @@ OBJS    := $(SRCS:.hip=.o)
 LIB     := guided-attention_amd/libga_hip.so
 # -amdgpu-mfma-vgpr-form: MFMA results stay in VGPRs (gfx950's register file is unified), which removes the
 # v_accvgpr_read/write traffic around every softmax step (108 -> 0 per loop iteration in self_attn_fwd)
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form
+# -amdgpu-kernarg-preload-count=16: the first 16 dwords of scalar / pointer kernel arguments arrive in SGPRs at wave launch
+# (gfx940+; the kernels keep a compatibility prologue that loads them when the firmware does not preload) — the scalar-load
+# round trip in front of every kernel's first address computation goes away (all four passes -0.3 ... -0.9 % by the flag
+# alone, profiles/r3_ab_kernarg_preload.txt; linear_kernel takes its tile geometry as 14 such dwords for it)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-kernarg-preload-count=16
 
 all: $(LIB)
 

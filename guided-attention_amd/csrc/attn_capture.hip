@@ -173,12 +173,17 @@ template <typename T, int NT>
 __device__ __forceinline__ void softmax_keys_biased(f32x4 (&acc)[NT], const T* __restrict__ bias_row, float coef, int Kt,
                                                     int g, float scale, f32x4 (&bias_out)[NT]) {
   float m = -INFINITY;
+  T braw[NT][4];   // all of this lane's bias entries requested together, from keys clamped into the row (see load_row_frags)
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) braw[t][r] = bias_row[min(t * 16 + 4 * g + r, Kt - 1)];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = t * 16 + 4 * g + r;
-      const float bv = key < Kt ? Traits<T>::to_f32(bias_row[key]) : 0.f;
+      const float bv = key < Kt ? Traits<T>::to_f32(braw[t][r]) : 0.f;
       bias_out[t][r] = bv;
       acc[t][r] = acc[t][r] * scale + bv * coef;
       if (key < Kt) m = fmaxf(m, acc[t][r]);

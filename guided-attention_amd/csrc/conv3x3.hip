@@ -101,6 +101,26 @@ struct ConvArgs {
                     // patch is read from (iy >> 1, ix >> 1) — and the [B][H][W][Cin] intermediate is never written
 };
 
+// All of the argument block in SGPRs at this point: an empty asm that "reads" every field makes the compiler fetch them in
+// one batch of scalar loads behind ONE wait.  Left to itself it loads a field where it is first used — the patch-DMA kernel
+// began with four dependent load / wait stages over the block's four cache lines (two of the stages missed the scalar cache)
+// in front of its first weight DMA.
+__device__ __forceinline__ void conv_args_resident(const ConvArgs& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GA_TOUCH(x) asm volatile("" ::"s"(x))
+  GA_TOUCH(a.B); GA_TOUCH(a.H); GA_TOUCH(a.W); GA_TOUCH(a.Cin); GA_TOUCH(a.Ho); GA_TOUCH(a.Wo); GA_TOUCH(a.Cout); GA_TOUCH(a.stride);
+  GA_TOUCH(a.M); GA_TOUCH(a.steps); GA_TOUCH(a.steps_per); GA_TOUCH(a.tm); GA_TOUCH(a.tn); GA_TOUCH(a.splits); GA_TOUCH(a.n_fastest);
+  GA_TOUCH(a.pad); GA_TOUCH(a.lane_rot); GA_TOUCH(a.x_bytes); GA_TOUCH(a.w_bytes);
+  GA_TOUCH(a.w_tap); GA_TOUCH(a.w_blk); GA_TOUCH(a.w_row); GA_TOUCH(a.w_chunk);
+  GA_TOUCH(a.pg_nseg); GA_TOUCH(a.pg_srows); GA_TOUCH(a.pg_dpr); GA_TOUCH(a.pg_dpc);
+  GA_TOUCH(a.d_tm.d); GA_TOUCH(a.d_tm.m); GA_TOUCH(a.d_tn.d); GA_TOUCH(a.d_tn.m); GA_TOUCH(a.d_w.d); GA_TOUCH(a.d_w.m);
+  GA_TOUCH(a.d_hw.d); GA_TOUCH(a.d_hw.m); GA_TOUCH(a.d_pw.d); GA_TOUCH(a.d_pw.m); GA_TOUCH(a.d_segpw.d); GA_TOUCH(a.d_segpw.m);
+  GA_TOUCH(a.d_segpx.d); GA_TOUCH(a.d_segpx.m); GA_TOUCH(a.d_wo.d); GA_TOUCH(a.d_wo.m); GA_TOUCH(a.d_howo.d); GA_TOUCH(a.d_howo.m);
+  GA_TOUCH(a.up);
+#undef GA_TOUCH
+#endif
+}
+
 __device__ __forceinline__ unsigned w_row_bytes(const ConvArgs& a, int n, int piece) {   // (row n, 16-byte piece) of chunk 0, tap 0
   return (unsigned)(((n >> 6) * a.w_blk + (n & 63) * a.w_row + 8 * piece) * 2);
 }
@@ -122,7 +142,7 @@ __device__ __forceinline__ int lane_pixel(int fr, int rot) { return fr < 16 || r
 // algorithmic bytes at the fabric counters).  Bijective for any grid size; placement is a speed matter only.
 template <int BM, int BN>
 __device__ __forceinline__ void tile_of_workgroup(const ConvArgs& a, int& m0, int& n0, int& split) {
-  const int total = gridDim.x, q = total >> 3, r = total & 7;
+  const int total = a.tm * a.tn * a.splits, q = total >> 3, r = total & 7;   // == gridDim.x, without the hidden-argument load
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   // n_fastest: activations outweigh the weights (64x64 level): an XCD keeps an m tile's pixels and sweeps the n tiles.
@@ -219,19 +239,31 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T
       for (int i = 0; i < IM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-    for (int sp = 0; sp < a.splits; ++sp) {
-      u32x4 v[QUADS];
+    // SB slices' slabs in flight at a time (one slice per round trip was `splits` dependent round trips); slots past the last
+    // slice re-read it and add zero.  Still summed in slice order.
+    constexpr int SB = QUADS <= 4 ? 4 : (QUADS <= 8 ? 2 : 1);
+    for (int s0 = 0; s0 < a.splits; s0 += SB) {
+      u32x4 v[SB][QUADS];
 #pragma unroll
-      for (int q = 0; q < QUADS; ++q)
-        v[q] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, tbase + q * (kThreads * 16u), sp * per_slice, 16);   // sc1
+      for (int sb = 0; sb < SB; ++sb) {
+        const unsigned soff = (unsigned)min(s0 + sb, a.splits - 1) * per_slice;
 #pragma unroll
-      for (int j = 0; j < JN; ++j)
+        for (int q = 0; q < QUADS; ++q)
+          v[sb][q] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, tbase + q * (kThreads * 16u), soff, 16);   // sc1
+      }
 #pragma unroll
-        for (int i = 0; i < IM; ++i)
+      for (int sb = 0; sb < SB; ++sb) {
+        const bool in = s0 + sb < a.splits;
 #pragma unroll
-          for (int qd = 0; qd < 4; ++qd)
+        for (int j = 0; j < JN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[j][i][4 * qd + r] += __uint_as_float(v[(j * IM + i) * 4 + qd][r]);
+          for (int i = 0; i < IM; ++i)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                acc[j][i][4 * qd + r] += in ? __uint_as_float(v[sb][(j * IM + i) * 4 + qd][r]) : 0.f;
+      }
     }
   }
   {
@@ -287,6 +319,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const T* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int m0, n0, split;
+  conv_args_resident(a);
   tile_of_workgroup<BM, BN>(a, m0, n0, split);
   const int it0 = split * a.steps_per, it1 = min(a.steps, it0 + a.steps_per);
   const int cchunks = a.Cin / kKC;
@@ -507,6 +540,7 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int m0, n0, split;
+  conv_args_resident(a);
   tile_of_workgroup<BM, BN>(a, m0, n0, split);
   const int cchunks = a.Cin / kKC;
   const int c_begin = split * a.steps_per, c_end = min(cchunks, c_begin + a.steps_per);   // chunks of this split
@@ -727,6 +761,7 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int m0, n0, split;
+  conv_args_resident(a);
   tile_of_workgroup<BM, BN>(a, m0, n0, split);
   const int cchunks = a.Cin / kKC;
   const int c_begin = split * a.steps_per, c_end = min(cchunks, c_begin + a.steps_per);   // chunks of this split

@@ -68,6 +68,17 @@ struct LinArgs {
   unsigned x_bytes, w_bytes;
 };
 
+// The scalar head of the argument list (see linear_kernel).  Passed as SEPARATE kernel parameters — only leading scalar /
+// pointer parameters are preloaded, an aggregate ends the sequence — and re-assembled by the launch stub below.
+struct LinHead {
+  int M, ldx;
+  unsigned kn;          // K | N << 16
+  int tm;
+  unsigned tn_splits;   // tn | splits << 16
+  unsigned steps;       // steps | steps_per << 16 | n_fastest << 31
+  unsigned dtm_m, dtn_m;
+};
+
 struct LinPtrs {
   const void* bias;          // [N] T or null
   const void* residual;      // [M][ld_res] T or null
@@ -85,7 +96,7 @@ struct LinPtrs {
 // the tiles that share a weight slice (or a token slab) meet in one L2.  Bijective for any grid size.
 template <int BM, int BN>
 __device__ __forceinline__ void lin_tile(const LinArgs& a, int& mt, int& nt, int& split) {
-  const int total = gridDim.x, q = total >> 3, r = total & 7;
+  const int total = a.tm * a.tn * a.splits, q = total >> 3, r = total & 7;   // == gridDim.x, without the hidden-argument load
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   // divisions by multiply-high with the host's reciprocals (two runtime integer divisions were ~100 instructions in front of
@@ -324,7 +335,23 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
 // GEGLU: BN columns of the tile = BN/2 h features followed by the BN/2 gate features of the same output columns
 template <typename T, int BM, int BN, int NSTAGE, bool GEGLU, bool LN>
 __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 80 * 1024 ? 2 : 1) void linear_kernel(
-    const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ Y, LinArgs a, LinPtrs p) {
+    const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ Y, int h_M, int h_ldx, unsigned h_kn, int h_tm,
+    unsigned h_tn_splits, unsigned h_steps, unsigned h_dtm_m, unsigned h_dtn_m, LinArgs a_in, LinPtrs p) {
+  const LinHead h{h_M, h_ldx, h_kn, h_tm, h_tn_splits, h_steps, h_dtm_m, h_dtn_m};
+  // Everything in front of the first operand load comes from `X, W, Y, h`: 14 dwords of scalar arguments that the hardware
+  // PRELOADS into SGPRs at wave launch (-amdgpu-kernarg-preload-count, Makefile) — the kernel's first instructions used to
+  // be three dependent scalar loads of the argument block (one cache miss, two hits) in front of the tile mapping.  The
+  // rest of the arguments (strides of the outputs, LayerNorm constants, pointers of the epilogue) is loaded while the
+  // ring fills.
+  LinArgs a;
+  a.M = h.M; a.ldx = h.ldx; a.K = (int)(h.kn & 0xffffu); a.N = (int)(h.kn >> 16);
+  a.tm = h.tm; a.tn = (int)(h.tn_splits & 0xffffu); a.splits = (int)(h.tn_splits >> 16);
+  a.steps = (int)(h.steps & 0xffffu); a.steps_per = (int)((h.steps >> 16) & 0x7fffu); a.n_fastest = (int)(h.steps >> 31);
+  a.d_tm = FastDiv{(unsigned)a.tm, h.dtm_m}; a.d_tn = FastDiv{(unsigned)a.tn, h.dtn_m};
+  a.F = GEGLU ? a.N / 2 : 0;
+  a.x_bytes = (unsigned)(((a.M - 1) * a.ldx + a.K) * 2); a.w_bytes = (unsigned)(a.N * a.K * 2);
+  a.ldy = a_in.ldy; a.ld_res = a_in.ld_res; a.ld_pre = a_in.ld_pre;
+  a.ln_parts = a_in.ln_parts; a.ln_eps = a_in.ln_eps; a.ln_inv_k = a_in.ln_inv_k;
   constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, JN = WN / 32;
   constexpr int kStage = (BM + BN) * kBK;                  // elements per ring slot
   constexpr int IPS = (BM + BN) / 32;                      // LDS-DMA wave-instructions per slot and wave (8 rows each)
@@ -527,19 +554,31 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 80 * 1024 ? 2
       for (int i = 0; i < IM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-    for (int s = 0; s < a.splits; ++s) {
-      u32x4 v[QUADS];
+    // SB slices' slabs in flight at a time (one slice per round trip was up to six dependent round trips here); slots past the
+    // last slice re-read it and add zero.  Still summed in slice order.
+    constexpr int SB = QUADS <= 4 ? 4 : (QUADS <= 8 ? 2 : 1);
+    for (int s0 = 0; s0 < a.splits; s0 += SB) {
+      u32x4 v[SB][QUADS];
 #pragma unroll
-      for (int q = 0; q < QUADS; ++q)
-        v[q] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, tbase + q * (kThreads * 16u), s * per_slice, 16);         // sc1
+      for (int sb = 0; sb < SB; ++sb) {
+        const unsigned soff = (unsigned)min(s0 + sb, a.splits - 1) * per_slice;
 #pragma unroll
-      for (int j = 0; j < JN; ++j)
+        for (int q = 0; q < QUADS; ++q)
+          v[sb][q] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, tbase + q * (kThreads * 16u), soff, 16);         // sc1
+      }
 #pragma unroll
-        for (int i = 0; i < IM; ++i)
+      for (int sb = 0; sb < SB; ++sb) {
+        const bool in = s0 + sb < a.splits;
 #pragma unroll
-          for (int qd = 0; qd < 4; ++qd)
+        for (int j = 0; j < JN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[j][i][4 * qd + r] += __uint_as_float(v[(j * IM + i) * 4 + qd][r]);
+          for (int i = 0; i < IM; ++i)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                acc[j][i][4 * qd + r] += in ? __uint_as_float(v[sb][(j * IM + i) * 4 + qd][r]) : 0.f;
+      }
     }
   }
 
@@ -573,7 +612,13 @@ int launch_lin(const T* X, const T* W, T* Y, LinArgs a, const LinPtrs& p, hipStr
   }
   const dim3 grid((unsigned)(a.tm * a.tn * a.splits));
   const bool ln = a.ln_parts > 0;
-#define GA_LIN_LAUNCH(G, L) hipLaunchKernelGGL((linear_kernel<T, BM, BN, NSTAGE, G, L>), grid, dim3(kThreads), 0, s, X, W, Y, a, p)
+  // the packed head (LinHead): 16-bit fields — K, N <= 65535 elements, <= 65535 column tiles / k-steps (checked here)
+  if (a.K > 0xffff || a.N > 0xffff || a.tn > 0xffff || a.splits > 0xffff || a.steps > 0xffff || a.steps_per > 0x7fff) return GA_ERR_SHAPE;
+  const LinHead h{a.M, a.ldx, (unsigned)a.K | ((unsigned)a.N << 16), a.tm, (unsigned)a.tn | ((unsigned)a.splits << 16),
+                  (unsigned)a.steps | ((unsigned)a.steps_per << 16) | ((unsigned)(a.n_fastest != 0) << 31), a.d_tm.m, a.d_tn.m};
+#define GA_LIN_LAUNCH(G, L)                                                                                                \
+  hipLaunchKernelGGL((linear_kernel<T, BM, BN, NSTAGE, G, L>), grid, dim3(kThreads), 0, s, X, W, Y, h.M, h.ldx, h.kn, h.tm, \
+                     h.tn_splits, h.steps, h.dtm_m, h.dtn_m, a, p)
   if (a.F) {
     if (ln) GA_LIN_LAUNCH(true, true);
     else GA_LIN_LAUNCH(true, false);
