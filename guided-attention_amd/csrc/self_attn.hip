@@ -18,6 +18,7 @@
 // layout: no LDS round trip between chained MFMAs.  Tensors stay in the projection layout [B][N][H][D].
 // Workgroup ids run head-fastest so that, with 8 heads and round-robin XCD dispatch, the workgroups that sweep one
 // head's K/V share an XCD L2.   MFMA-bound for N >= 1024 (4 N^2 D flops per head forward), latency-bound below.
+#include <cstdlib>
 #include "attn_common.h"
 
 using namespace ga;
@@ -1359,9 +1360,14 @@ constexpr size_t kLdsLimit = 160 * 1024;
 //             (384 workgroups of 86 KB LDS = two rounds of one per CU), B<=2 CB=1 better
 //   backward  4096x40: B=1 CB=1 236 / CB=2 245
 // Hence CB = 2 from 192 column-block pairs per launch in the forward, from 512 in the backward.
+inline long long env_threshold(const char* name, long long dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoll(v) : dflt;
+}
 template <int NK>
 bool wide_columns(int B, int H, int N, bool backward) {
-  return NK <= 5 && (long long)B * H * ((N + 127) / 128) >= (backward ? 512 : 192);
+  static const long long bwd_min = env_threshold("GA_SA_BWD_WIDE_MIN", 512), fwd_min = env_threshold("GA_SA_FWD_WIDE_MIN", 192);
+  return NK <= 5 && (long long)B * H * ((N + 127) / 128) >= (backward ? bwd_min : fwd_min);
 }
 
 template <typename T, int NK, int KT>
