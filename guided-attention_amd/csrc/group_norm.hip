@@ -60,6 +60,15 @@ __device__ __forceinline__ void opaque(V& v) {
 #endif
 }
 
+// A channel PAIR as one access (even channel index: 4-byte aligned for the 16-bit types).  Read through Item<T, 2>, whose
+// alignment is that of T, the pair becomes two 2-byte loads the scheduler places apart — and the later one decides where the
+// wait for "the pair" sits.
+template <typename T>
+__device__ __forceinline__ Item<T, 2> load_pair(const T* p) {
+  if constexpr (sizeof(T) == 2) return __builtin_bit_cast(Item<T, 2>, *reinterpret_cast<const unsigned*>(p));
+  else return __builtin_bit_cast(Item<T, 2>, *reinterpret_cast<const unsigned long long*>(p));
+}
+
 // v_rcp_f32 (1 ulp), not an IEEE division (ten instructions per element in every GroupNorm + SiLU pass)
 __device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
 
@@ -143,9 +152,14 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const T* __restrict_
 // workgroup also stores the results (the forward's (mean, rstd) that the backward reads).
 constexpr int kMaxStatsNB = 128;
 
-template <bool FWD>
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `after_loads` runs once, when the (first pass of the) fold's own loads are out: the callers request their per-channel
+// constants there — cold weights, needed only behind the fold's barrier, so the fold runs under their latency.
+template <bool FWD, typename Hook = NoHook>
 __device__ __forceinline__ void fold_partials(const float* __restrict__ partial, int b, int NB, int G, float inv_n,
-                                              float eps, float2* res, float* keep) {
+                                              float eps, float2* res, float* keep, Hook after_loads = Hook()) {
   const float2* pp = reinterpret_cast<const float2*>(partial) + (size_t)b * NB * G;
   for (int g0 = 0; g0 < G; g0 += kThreads / 8) {
     const int g = g0 + (threadIdx.x >> 3), part = threadIdx.x & 7;
@@ -157,6 +171,7 @@ __device__ __forceinline__ void fold_partials(const float* __restrict__ partial,
       const int nb = part + 8 * i;
       v[i] = pp[(size_t)min(nb, NB - 1) * G + min(g, G - 1)];
     }
+    if (g0 == 0) after_loads();
     float sa = 0.f, sc = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxStatsNB / 8; ++i) {
@@ -515,9 +530,12 @@ __global__ __launch_bounds__(kThreads) void gn_wide_apply_kernel(const T* __rest
   // round trip to memory after its barrier
   // by every thread (m.vec is a valid vector index for the idle ones too): under `if (m.active)` the three values were
   // merged behind waits before the fold's own loads could go out
-  const Vec8<T> gm = reinterpret_cast<const Vec8<T>*>(gamma)[m.vec], bt = reinterpret_cast<const Vec8<T>*>(beta)[m.vec];
-  const Vec8<T> bv = reinterpret_cast<const Vec8<T>*>(cbias != nullptr ? cbias + (size_t)b * C : x + (size_t)b * HW * C)[m.vec];
-  fold_partials<true>(partial, b, NB, G, inv_n, eps, res, blockIdx.x == 0 ? stats : nullptr);
+  Vec8<T> gm, bt, bv;
+  fold_partials<true>(partial, b, NB, G, inv_n, eps, res, blockIdx.x == 0 ? stats : nullptr, [&]() {
+    gm = reinterpret_cast<const Vec8<T>*>(gamma)[m.vec];
+    bt = reinterpret_cast<const Vec8<T>*>(beta)[m.vec];
+    bv = reinterpret_cast<const Vec8<T>*>(cbias != nullptr ? cbias + (size_t)b * C : x + (size_t)b * HW * C)[m.vec];
+  });
   if (!m.active) return;
   const float* mr = reinterpret_cast<const float*>(res);
   float sc[8], sh[8];
@@ -659,9 +677,9 @@ __global__ __launch_bounds__(kThreads) void gn_wide_bwd_apply_kernel(const T* __
         if (gres != nullptr) gr[u] = rb[(size_t)(p + u * m.RP) * m.VP];
       }
   }
-  WideBwdConst<T> k;
-  k.fetch(m, cbias, gamma, beta, stats, x + (size_t)b * HW * C, b, C, G);   // by every thread: no merge behind a wait
-  fold_partials<false>(partial, b, NB, G, inv_n, 0.f, res, nullptr);
+  WideBwdConst<T> k;   // fetched by every thread (no merge behind a wait), behind the fold's own loads
+  fold_partials<false>(partial, b, NB, G, inv_n, 0.f, res, nullptr,
+                       [&]() { k.fetch(m, cbias, gamma, beta, stats, x + (size_t)b * HW * C, b, C, G); });
   if (!m.active) return;
   k.finish(m, cbias != nullptr);
   float a1[8], a2[8];
@@ -754,8 +772,12 @@ __global__ __launch_bounds__(NT) void gn_small_fwd_kernel(const T* __restrict__ 
   Item<T, 2> xv[IT];
 #pragma unroll
   for (int k = 0; k < IT; ++k) xv[k] = *reinterpret_cast<const Item<T, 2>*>(x + base + (size_t)min(p0 + k * rows, HW - 1) * C);
-  const Item<T, 2> gmv = *reinterpret_cast<const Item<T, 2>*>(gamma + ch), btv = *reinterpret_cast<const Item<T, 2>*>(beta + ch);
-  const Item<T, 2> cbv = *reinterpret_cast<const Item<T, 2>*>(cbias != nullptr ? cbias + (size_t)b * C + ch : x + base);
+  // gamma / beta (cold weights: the slowest of these loads) go out last and are first needed behind the block reduction, the
+  // channel bias (first pass) in front of them: the first pass's wait leaves the two outstanding and the reduction runs
+  // under their latency
+  const Item<T, 2> cbv = load_pair<T>(cbias != nullptr ? cbias + (size_t)b * C + ch : x + base);
+  __builtin_amdgcn_sched_barrier(0);   // gamma / beta stay the YOUNGEST loads (the scheduler moved slab loads behind them)
+  const Item<T, 2> gmv = load_pair<T>(gamma + ch), btv = load_pair<T>(beta + ch);
   const float cb0 = cbias != nullptr ? Traits<T>::to_f32(cbv.v[0]) : 0.f, cb1 = cbias != nullptr ? Traits<T>::to_f32(cbv.v[1]) : 0.f;
   float sa = 0.f, sc = 0.f;
 #pragma unroll
