@@ -30,36 +30,6 @@ struct Item {
   T v[W];
 };
 
-// Two statements that pin "request everything, then compute" in the instruction stream: `loads_issued()` is a compiler
-// barrier for memory operations (the loads above it stay above it), and a value passed through `opaque()` BELOW it cannot be
-// consumed above it.  Without them the scheduler converts a freshly loaded per-channel constant right behind its load — a
-// wait for that one load in front of all the loads that follow it.
-__device__ __forceinline__ void loads_issued() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" ::: "memory");
-#endif
-}
-template <typename V>
-__device__ __forceinline__ void opaque(V& v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (sizeof(V) == 4) {
-    unsigned u = __builtin_bit_cast(unsigned, v);
-    asm volatile("" : "+v"(u));
-    v = __builtin_bit_cast(V, u);
-  } else if constexpr (sizeof(V) == 8) {
-    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    asm volatile("" : "+v"(u));
-    v = __builtin_bit_cast(V, u);
-  } else {
-    static_assert(sizeof(V) == 16, "opaque(): 4, 8 or 16 bytes");
-    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-    u32x4_t u = __builtin_bit_cast(u32x4_t, v);
-    asm volatile("" : "+v"(u));
-    v = __builtin_bit_cast(V, u);
-  }
-#endif
-}
-
 // A channel PAIR as one access (even channel index: 4-byte aligned for the 16-bit types).  Read through Item<T, 2>, whose
 // alignment is that of T, the pair becomes two 2-byte loads the scheduler places apart — and the later one decides where the
 // wait for "the pair" sits.
@@ -580,7 +550,7 @@ struct WideBwdConst {
                                         const T* x_img, int b, int C, int G) {
     g8 = reinterpret_cast<const Vec8<T>*>(gamma)[m.vec];
     b8 = reinterpret_cast<const Vec8<T>*>(beta)[m.vec];
-    c8 = reinterpret_cast<const Vec8<T>*>(cbias != nullptr ? cbias + (size_t)b * C : x_img)[m.vec];   // no branch (see opaque())
+    c8 = reinterpret_cast<const Vec8<T>*>(cbias != nullptr ? cbias + (size_t)b * C : x_img)[m.vec];   // no branch around the load
     const float2* s2 = reinterpret_cast<const float2*>(stats) + (size_t)b * G;
     st[0] = s2[m.gA];
     st[1] = s2[min(m.gA + 1, G - 1)];

@@ -28,7 +28,6 @@ from code_object_check import extract_code_objects  # noqa: E402
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 LOAD = re.compile(r"^\s*(global_load|buffer_load|flat_load)\w*\s")
 LDS_DMA = re.compile(r"\blds\b")
-WAIT0 = re.compile(r"^\s*s_waitcnt\b.*vmcnt\(0\)")
 WAITN = re.compile(r"^\s*s_waitcnt\b.*vmcnt\((\d+)\)")
 
 
