@@ -71,6 +71,7 @@ PROTOTYPES = {
     "ga_geglu_fwd": [_vp, _vp, _i64, _i, _i, _vp],
     "ga_geglu_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "ga_bias_residual_add": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "ga_cat_channels": [_vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "ga_conv3x3_packed_elems": [_i, _i],
     "ga_conv3x3_pack_weights": [_vp, _vp, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp],
     "ga_conv3x3_plan": [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i),

@@ -130,7 +130,73 @@ int bias_residual(const void* y, const void* bias, const void* res, void* out, l
   return check_launch();
 }
 
+// out[m][0 .. C1) = a[m][:], out[m][C1 .. C1 + C2) = b[m][:] in 16-byte vectors: the UpBlock's channel concatenation of the
+// running activation with the skip connection on channels-last tensors (diffusers 0.12.1 CrossAttnUpBlock2D / UpBlock2D:
+// `torch.cat([hidden_states, res_hidden_states], dim=1)`, run by the reference inside pipeline_guided_attention.py:583-743).
+// Each source is walked densely (vector i of a source is element i of its array: coalesced, no address select), four vectors
+// per thread with all four loads issued before the first store; only the destination row needs a division (multiply-high).
+constexpr int kCatPerThread = 4;
+// row = i / vp without a branch: multiply-high by the host's reciprocal, plus i itself where vp == 1 (reciprocal 0, mask ~0).
+// fdiv()'s `m != 0 ? ... : x` compiles to a (uniform) branch per use — four basic blocks the loads were then sunk into.
+struct CatDiv {
+  unsigned m, mask;
+};
+__device__ __forceinline__ void cat_part(const uint4* __restrict__ src, uint4* __restrict__ out, long long n, int vp, int off,
+                                         int vt, CatDiv d_vp, long long base, long long stride) {
+  auto dest = [&](long long i) -> uint4* {
+    const int row = (int)(__umulhi((unsigned)i, d_vp.m) + ((unsigned)i & d_vp.mask)), col = (int)i - row * vp;
+    return out + ((long long)row * vt + off + col);
+  };
+  if (base + (kCatPerThread - 1) * stride < n) {
+    // all four in range (every thread but the last few): nothing is conditional, the four loads go out together — with each
+    // store under `if (i < n)` the compiler moved its load in there too: load, wait, store, four times in a row
+    uint4 v[kCatPerThread];
+#pragma unroll
+    for (int k = 0; k < kCatPerThread; ++k) v[k] = src[base + k * stride];
+    __builtin_amdgcn_sched_barrier(0);   // left alone the scheduler pairs each load with its store: load, wait, store, ...
+#pragma unroll
+    for (int k = 0; k < kCatPerThread; ++k) *dest(base + k * stride) = v[k];
+  } else {
+    for (int k = 0; k < kCatPerThread; ++k) {
+      const long long i = base + k * stride;
+      if (i < n) *dest(i) = src[i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void cat_rows_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
+                                                            uint4* __restrict__ out, long long rows, int v1, int v2,
+                                                            CatDiv d_v1, CatDiv d_v2) {
+  const long long na = rows * v1, nb = rows * v2, nmax = na > nb ? na : nb;
+  const long long base = (long long)blockIdx.x * kThreads + threadIdx.x;
+  // == gridDim.x * kThreads, from the (preloaded) arguments instead of the hidden grid-size argument
+  const long long stride = ((nmax + kThreads * kCatPerThread - 1) / (kThreads * kCatPerThread)) * kThreads;
+  cat_part(a, out, na, v1, 0, v1 + v2, d_v1, base, stride);
+  cat_part(b, out, nb, v2, v1, v1 + v2, d_v2, base, stride);
+}
+
 }  // namespace
+
+extern "C" int ga_cat_channels(const void* a, const void* b, void* out, int64_t rows, int C1, int C2, int elem_bytes,
+                               ga_stream_t stream) {
+  if (!a || !b || !out) return GA_ERR_NULL;
+  if (rows < 1 || C1 < 1 || C2 < 1 || (elem_bytes != 2 && elem_bytes != 4)) return GA_ERR_SHAPE;
+  const int per = 16 / elem_bytes;
+  if (C1 % per != 0 || C2 % per != 0) return GA_ERR_SHAPE;
+  if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return GA_ERR_ALIGN;
+  const int v1 = C1 / per, v2 = C2 / per;
+  const long long na = (long long)rows * v1, nb = (long long)rows * v2, nmax = na > nb ? na : nb;
+  if (na >= (1LL << 31) || nb >= (1LL << 31)) return GA_ERR_SHAPE;   // 32-bit vector index in the row division
+  bool ok = true;
+  const FastDiv d1 = make_fastdiv(v1, (unsigned long long)na, ok), d2 = make_fastdiv(v2, (unsigned long long)nb, ok);
+  if (!ok) return GA_ERR_SHAPE;
+  const long long per_wg = (long long)kThreads * kCatPerThread;
+  const unsigned grid = (unsigned)((nmax + per_wg - 1) / per_wg);
+  const CatDiv c1{d1.m, d1.m ? 0u : ~0u}, c2{d2.m, d2.m ? 0u : ~0u};
+  hipLaunchKernelGGL(cat_rows_kernel, dim3(grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream), (const uint4*)a,
+                     (const uint4*)b, (uint4*)out, (long long)rows, v1, v2, c1, c2);
+  return check_launch();
+}
 
 extern "C" int ga_geglu_fwd(const void* x, void* y, int64_t rows, int F, int dtype, ga_stream_t stream) {
   if (!x || !y) return GA_ERR_NULL;

@@ -793,6 +793,52 @@ def geglu_backward(x, dy):
     return dx
 
 
+def cat_channels_supported(a, b):
+    """Both channels-last-dense 4-D tensors of one 16- or 32-bit dtype on the GPU, same (B, H, W), channel counts that are
+    whole 16-byte vectors, and a vector count the kernel's 32-bit row division serves."""
+    if not (a.is_cuda and b.is_cuda and a.dim() == 4 and b.dim() == 4 and a.dtype == b.dtype):
+        return False
+    if a.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+        return False
+    if a.shape[0] != b.shape[0] or a.shape[2:] != b.shape[2:]:
+        return False
+    per = 16 // a.element_size()
+    if a.shape[1] % per or b.shape[1] % per:
+        return False
+    rows = a.shape[0] * a.shape[2] * a.shape[3]
+    return all(rows * (t.shape[1] // per) ** 2 < (1 << 32) for t in (a, b))   # the kernel's 32-bit multiply-high row division
+
+
+class CatChannels(torch.autograd.Function):
+    """torch.cat([a, b], dim=1) on channels-last activations as one ga_cat_channels launch (the UpBlock's concatenation of
+    the running activation with the skip connection: diffusers 0.12.1 UpBlock2D / CrossAttnUpBlock2D, called from the
+    reference's UNet forward pipeline_guided_attention.py:583-743).  Backward: the two channel slices of the gradient, as
+    views — what torch.cat's own backward returns."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        require_cuda(a, b)
+        a, b = _nhwc(a), _nhwc(b)
+        B, C1, H, W = a.shape
+        C2 = b.shape[1]
+        out = torch.empty((B, C1 + C2, H, W), dtype=a.dtype, device=a.device, memory_format=torch.channels_last)
+        check(load().ga_cat_channels(_ptr(a), _ptr(b), _ptr(out), B * H * W, C1, C2, a.element_size(), stream_ptr()),
+              "ga_cat_channels")
+        ctx.c1 = C1
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.c1], g[:, ctx.c1:]
+
+
+def cat_channels(a, b):
+    """torch.cat([a, b], dim=1); the HIP launch where cat_channels_supported, the library otherwise (CPU oracle, odd widths)."""
+    if cat_channels_supported(a, b):
+        return CatChannels.apply(a, b)
+    return torch.cat([a, b], dim=1)
+
+
 class BiasResidualAdd(torch.autograd.Function):
     """out = y + bias[c] + residual on channels-last activations (ResnetBlock2D: conv2's bias and the skip
     connection in one pass).  bias receives no gradient (frozen UNet)."""

@@ -136,7 +136,8 @@ class GuidedAttention:
             from . import fused_linear
             linear = fused_linear if os.environ.get("GA_LIBRARY_LINEAR", "0") != "1" else None
             ops.prepare_device(self.unet.device)   # split-K slabs / tickets exist before any hipGraph capture
-            self.unet.set_fused_impl(ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm), conv, linear)
+            cat = ops.cat_channels if os.environ.get("GA_LIBRARY_CAT", "0") != "1" else None   # GA_LIBRARY_CAT=1: torch.cat (A/B runs)
+            self.unet.set_fused_impl(ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm), conv, linear, cat)
             # MIOpen: time the candidate conv kernels once per shape — for the 16-bit production dtypes only.  In
             # fp32 (parity runs) the library's default choice is kept: the exhaustive search executes every
             # candidate solver, and the fp32 96x96 backward-data search was seen to abort the process once.

@@ -430,13 +430,16 @@ class UpBlock(nn.Module):
                                              for _ in range(n)])
         self.upsamplers = nn.ModuleList([Upsample2D(out_c)]) if add_upsample else None
 
+    cat_impl = None   # ops.cat_channels: the concatenation with the skip connection as one HIP launch (set_fused_impl)
+
     def forward(self, x, skips, temb_act, context, upsample_size=None, n_layers=None):
         """`skips` is consumed from its end.  n_layers < len(resnets) stops early (truncated guidance
         forward) and returns before the upsampler."""
         for i, resnet in enumerate(self.resnets):
             if n_layers is not None and i >= n_layers:
                 return x
-            x = resnet(torch.cat([x, skips.pop()], dim=1), temb_act)
+            skip = skips.pop()
+            x = resnet(self.cat_impl(x, skip) if self.cat_impl is not None else torch.cat([x, skip], dim=1), temb_act)
             if self.has_cross_attention:
                 x = self.attentions[i](x, context)
         if n_layers is None and self.upsamplers is not None:
@@ -642,10 +645,11 @@ class UNet2DConditionModel(nn.Module):
             if isinstance(m, GroupNormAct):
                 m.impl = impl
 
-    def set_fused_impl(self, geglu=None, bias_residual_add=None, layer_norms=None, conv=None, linear=None):
+    def set_fused_impl(self, geglu=None, bias_residual_add=None, layer_norms=None, conv=None, linear=None, cat=None):
         """Install (or with None remove) the fused element-wise epilogues: GEGLU, conv-bias + residual, and
         (layer_norm, add_layer_norm) for the transformer blocks; `conv` = the implicit-GEMM 3x3 convolution; `linear` = the
-        fused_linear module (LayerNorm / GEGLU / residual folded into the transformer blocks' GEMMs, 1x1 shortcuts)."""
+        fused_linear module (LayerNorm / GEGLU / residual folded into the transformer blocks' GEMMs, 1x1 shortcuts); `cat` = the
+        UpBlocks' channel concatenation (ops.cat_channels)."""
         for m in self.modules():
             if isinstance(m, (Downsample2D, Upsample2D)):
                 m.conv_impl = conv
@@ -658,6 +662,8 @@ class UNet2DConditionModel(nn.Module):
             elif isinstance(m, BasicTransformerBlock):
                 m.ln_impl = layer_norms
                 m.lin_impl = linear
+            elif isinstance(m, UpBlock):
+                m.cat_impl = cat
 
     @property
     def dtype(self):

@@ -243,6 +243,14 @@ int ga_geglu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int F, i
 int ga_bias_residual_add(const void* y, const void* bias, const void* residual, void* out, int64_t rows, int C,
                          int dtype, ga_stream_t stream);
 
+/* UNet host helper: out[m][0 .. C1) = a[m][:], out[m][C1 .. C1 + C2) = b[m][:] for `rows` rows — the channel concatenation
+ * of the running activation with a skip connection on channels-last tensors (diffusers 0.12.1 CrossAttnUpBlock2D /
+ * UpBlock2D `torch.cat([hidden_states, res_hidden_states], dim=1)`, run by the reference inside
+ * pipeline_guided_attention.py:583-743).  a [rows][C1], b [rows][C2], out [rows][C1 + C2], all dense; elem_bytes 2 or 4;
+ * C1, C2 multiples of 16 / elem_bytes; pointers 16-byte aligned; rows * (C1 + C2) * elem_bytes < 32 GiB. */
+int ga_cat_channels(const void* a, const void* b, void* out, int64_t rows, int C1, int C2, int elem_bytes,
+                    ga_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * UNet host helper: 3x3 convolution, pad 1, stride 1 or 2, on channels-last activations as an implicit GEMM on MFMA
  * (diffusers 0.12.1 ResnetBlock2D / Upsample2D / Downsample2D convolutions, run by the reference inside

@@ -698,6 +698,43 @@ def test_bias_residual_add(ops, shape, dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 640, 320, 64, 64), (3, 1280, 640, 32, 32), (2, 1280, 1280, 8, 8), (1, 8, 16, 3, 5),
+                                   (1, 24, 8, 1, 1), (3, 320, 320, 64, 64)])
+def test_cat_channels(ops, shape, dt):
+    """ops.cat_channels == torch.cat([a, b], dim=1), bit for bit, on channels-last tensors (the UpBlocks' concatenation
+    with the skip connection: diffusers 0.12.1 UpBlock2D / CrossAttnUpBlock2D inside the reference's UNet forward,
+    pipeline_guided_attention.py:583-743); gradients are the two channel slices; shapes the kernel does not serve go to
+    the library."""
+    B, C1, C2, H, W = shape
+    a = dev(hashrand.normalish((B, C1, H, W), 51 + C1), DT[dt]).contiguous(memory_format=torch.channels_last)
+    b = dev(hashrand.normalish((B, C2, H, W), 52 + C2), DT[dt])  # NCHW input is accepted and converted
+    assert ops.cat_channels_supported(a, b)
+    aa, bb = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out = ops.cat_channels(aa, bb)
+    assert out.shape == (B, C1 + C2, H, W) and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out, torch.cat([a, b], dim=1))
+    g = dev(hashrand.normalish((B, C1 + C2, H, W), 53), DT[dt]).contiguous(memory_format=torch.channels_last)
+    out.backward(g)
+    assert torch.equal(aa.grad, g[:, :C1]) and torch.equal(bb.grad, g[:, C1:])
+    # channel counts that are not whole 16-byte vectors: the library's cat, same result
+    per = 16 // a.element_size()
+    odd = dev(hashrand.normalish((B, per + 1, H, W), 54), DT[dt])
+    assert not ops.cat_channels_supported(a, odd)
+    assert torch.equal(ops.cat_channels(a, odd), torch.cat([a, odd], dim=1))
+
+
+def test_cat_channels_errors(ops):
+    lib = ops.load()
+    a = torch.zeros(4, 8, device="cuda", dtype=torch.float16)
+    o = torch.zeros(4, 16, device="cuda", dtype=torch.float16)
+    s = ops.stream_ptr()
+    assert lib.ga_cat_channels(None, ops._ptr(a), ops._ptr(o), 4, 8, 8, 2, s) == -1          # GA_ERR_NULL
+    assert lib.ga_cat_channels(ops._ptr(a), ops._ptr(a), ops._ptr(o), 4, 8, 4, 2, s) != 0   # C2 not a whole vector
+    assert lib.ga_cat_channels(ops._ptr(a), ops._ptr(a), ops._ptr(o), 4, 8, 8, 3, s) != 0   # element size
+    assert lib.ga_cat_channels(ops._ptr(a), ops._ptr(a), ops._ptr(o), 0, 8, 8, 2, s) != 0   # no rows
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("shape", [(1, 4096, 320), (2, 1024, 640), (1, 256, 1280), (2, 64, 1280), (3, 5, 64), (1, 1, 8),
                                    (1, 3, 2048)])
 def test_add_layer_norm(ops, shape, dt):
