@@ -18,6 +18,7 @@ def cat(n):
     if "add_ln" in n: return "ga residual+LayerNorm"
     if "geglu" in n: return "ga GEGLU"
     if "bias_residual" in n: return "ga bias+residual"
+    if "cat_rows" in n: return "ga channel concatenation"
     if "smooth_loss" in n or "aggregate" in n or "axp" in n or "cfg_ddim" in n: return "ga loss / aggregate / latent ops"
     if "elementwise" in n or "CatArray" in n or "upsample" in n.lower() or "copy" in n.lower() or "fill" in n.lower():
         return "torch element-wise / cat / copy / upsample"
