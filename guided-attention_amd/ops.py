@@ -806,6 +806,11 @@ def cat_channels_supported(a, b):
     if a.shape[1] % per or b.shape[1] % per:
         return False
     rows = a.shape[0] * a.shape[2] * a.shape[3]
+    # Measured domain: maps of <= 64 x 64 pixels and results of <= 24 MB (every concatenation of the 512^2 SD-1.x passes:
+    # -0.8 ... -0.9 % per forward pass, profiles/r3_ab_cat_channels.txt).  On the 768^2 configuration (96 x 96 maps, results up
+    # to 53 MB) the library's copy was the faster one (0.917 against 0.887 images/s with every concatenation on this kernel).
+    if a.shape[2] * a.shape[3] > 4096 or rows * (a.shape[1] + b.shape[1]) * a.element_size() > 24 * 1024 * 1024:
+        return False
     return all(rows * (t.shape[1] // per) ** 2 < (1 << 32) for t in (a, b))   # the kernel's 32-bit multiply-high row division
 
 
