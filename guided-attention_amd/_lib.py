@@ -13,6 +13,7 @@ import torch
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("GA_HIP_LIB", _HERE / "libga_hip.so"))
 
+GA_VERSION = 130   # the GA_VERSION of include/ga_hip.h these prototypes were written for (tests/test_abi.py compares the two)
 GA_F16, GA_BF16, GA_F32 = 0, 1, 2
 GA_TOK_COOR, GA_TOK_BOX = 0, 1
 GA_TERMS = 8
@@ -98,6 +99,12 @@ def load():
             raise GaError(f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); "
                           "the guided-attention path has no CPU fallback")
         lib = ctypes.CDLL(str(LIB_PATH))
+        lib.ga_version.argtypes, lib.ga_version.restype = [], ctypes.c_int
+        built = lib.ga_version()
+        if built != GA_VERSION:
+            # signatures changed between versions by pointers inserted in the MIDDLE of argument lists: a mismatched pair would
+            # hand e.g. the bias where the ticket array is expected — refuse before the first call
+            raise GaError(f"{LIB_PATH} is ABI version {built}, this binding is written for {GA_VERSION}: rebuild with `make`")
         for name, argtypes in PROTOTYPES.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes

@@ -47,7 +47,7 @@ def _transposed(weight):
         # guidance backward transposed 27 weight matrices again (round 3: 14 strided-copy launches per backward pass)
         owner = weight._base if weight._base is not None else weight
         hit = _wt_cache[key] = (weakref.ref(owner), wt)
-    return hit[1]
+    return ops.keep_alive(hit[1])
 
 
 _wt_cache = {}
@@ -98,7 +98,10 @@ def _folded(weight, bias, norm):
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), None if bias is None else (bias.data_ptr(), bias._version),
            norm.weight._version, norm.bias._version, weight.dtype)
     cache = norm.__dict__.setdefault("_ga_folded", {})
-    hit = cache.get(key)
+    entry = cache.get(key)
+    # good only for the weight object it was made from (a freed weight's address may be handed to another tensor)
+    owner = weight._base if weight._base is not None else weight
+    hit = entry[1] if entry is not None and entry[0]() is owner else None
     if hit is None:
         with torch.no_grad():
             wg = (weight.float() * norm.weight.float()[None, :]).to(weight.dtype).contiguous()
@@ -108,8 +111,16 @@ def _folded(weight, bias, norm):
                 shift = shift + bias.float()
             hit = (wg, colsum, shift.contiguous())
         if len(cache) > 8:
-            cache.clear()
-        cache[key] = hit
+            # Entries of weights that are gone, and entries a newer version of the same weight has replaced.  Captured hipGraphs
+            # read wg / colsum / shift by raw pointer — a runner keeps what it captured against alive itself
+            # (ops.keepalive_scope), so dropping an entry here can never free memory a live graph replays on.
+            def stale(k, ref):
+                w = ref()
+                return w is None or w._version != k[1] or norm.weight._version != k[4] or norm.bias._version != k[5]
+            for k in [k for k, (ref, _) in cache.items() if stale(k, ref)]:
+                del cache[k]
+        cache[key] = (weakref.ref(owner), hit)
+    ops.keep_alive(*hit)
     return hit
 
 

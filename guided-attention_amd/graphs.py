@@ -108,7 +108,10 @@ class GraphRunner:
         calls = dict(self.pipe.unet_calls)
         self._set_t(981, *self.tp)
         torch.cuda.synchronize()
-        side = torch.cuda.Stream()
+        # warm-up and capture run on the package's ONE side stream per device: the split-K scratch is kept per (device, stream)
+        # and must exist before the capture opens (ops.prepare_device); the captured launches keep that stream's set
+        side = self.stream = ops.side_stream(self.lat_g.device)
+        ops.prepare_device(self.lat_g.device, side)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):  # warm-up: library algorithm selection and workspace allocation happen here
@@ -123,8 +126,12 @@ class GraphRunner:
         # whatever became unreachable earlier — an older runner's hipGraphs, streams, events — and destroying those while this
         # thread's stream is capturing aborts the process (seen once in the full GPU suite, at a capture after ~500 tests).
         # torch.cuda.graph() collects on entry; between entry and exit nothing may.
-        with ops.no_gc():
+        # The captured launches read derived weight tensors (LayerNorm-folded weights, transposes, convolution packs) by raw
+        # pointer: the runner keeps every one handed out during the capture alive for as long as it lives itself — the caches
+        # that made them may evict as they like
+        with ops.no_gc(), ops.keepalive_scope() as keep:
             self._capture_graphs(store)
+        self._keep = keep.tensors
         torch.cuda.synchronize()
         self.pipe.unet_calls.update(calls)  # capture / warm-up passes are not image work
         # The captured kernels read the cached text K/V projections of the static prompt buffers by raw pointer:
@@ -136,19 +143,19 @@ class GraphRunner:
 
     def _capture_graphs(self, store):
         self.g_eval = torch.cuda.CUDAGraph()
-        with ops.census_scope() as c_eval, torch.cuda.graph(self.g_eval):
+        with ops.census_scope() as c_eval, torch.cuda.graph(self.g_eval, stream=self.stream):
             self.parts, self.store_eval = self._eval_body(store)
         self.loss = self.parts[1]
         self.g_grad = torch.cuda.CUDAGraph()
-        with ops.census_scope() as c_grad, torch.cuda.graph(self.g_grad, pool=self.g_eval.pool()):
+        with ops.census_scope() as c_grad, torch.cuda.graph(self.g_grad, pool=self.g_eval.pool(), stream=self.stream):
             self.grad = self._grad_body(self.loss)
         self.g_cfg = torch.cuda.CUDAGraph()
-        with ops.census_scope() as c_cfg, torch.cuda.graph(self.g_cfg, pool=self.g_eval.pool()):
+        with ops.census_scope() as c_cfg, torch.cuda.graph(self.g_cfg, pool=self.g_eval.pool(), stream=self.stream):
             self.noise, self.store_cfg = self._cfg_body(store)
         self.launches = {"eval": c_eval.launches, "grad": c_grad.launches, "cfg": c_cfg.launches}
         if self.joint:
             self.g_joint = torch.cuda.CUDAGraph()
-            with ops.census_scope() as c_joint, torch.cuda.graph(self.g_joint, pool=self.g_eval.pool()):
+            with ops.census_scope() as c_joint, torch.cuda.graph(self.g_joint, pool=self.g_eval.pool(), stream=self.stream):
                 self.noise3, self.parts_joint, self.store_joint = self._joint_body(store)
             self.launches["joint"] = c_joint.launches
 
@@ -159,6 +166,10 @@ class GraphRunner:
         if self._storages:
             pin_context_projections(self.pipe.unet, self._storages, -1)
             self._storages = set()
+            # every completed split-K / fused-loss launch returns its arrival tickets to zero; a word left non-zero means a
+            # launch died half-way and every later launch on that tile silently skipped its epilogue
+            if not ops.tickets_are_zero(self.lat_g.device):
+                raise ops.GaError("an arrival-ticket word is non-zero after the runner's last replay: a split-K launch did not complete")
 
     # -- replays
     def _publish(self, store, snapshot):

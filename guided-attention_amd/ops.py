@@ -75,6 +75,44 @@ class no_gc:
             gc.enable()
 
 
+_KEEP = None   # while a hipGraph is being captured: every cached tensor a captured launch reads by raw pointer
+
+
+class keepalive_scope:
+    """Collect into `.tensors` every derived weight tensor (folded LayerNorm weights, transposes, convolution packs) handed
+    out inside the block.  A GraphRunner captures inside one and keeps the list: its graphs read those tensors by raw pointer,
+    so they must live exactly as long as the runner does, whatever the caches that made them evict later."""
+
+    def __enter__(self):
+        global _KEEP
+        self._outer, _KEEP = _KEEP, []
+        return self
+
+    def __exit__(self, *exc):
+        global _KEEP
+        self.tensors, _KEEP = _KEEP, self._outer
+
+
+def keep_alive(*tensors):
+    if _KEEP is not None:
+        _KEEP.extend(t for t in tensors if t is not None)
+    return tensors[0] if len(tensors) == 1 else tensors
+
+
+_side_streams = {}
+
+
+def side_stream(device=None):
+    """ONE side stream per device for warm-up runs, captures and micro-replays: the split-K scratch is kept per (device,
+    stream) (linear_workspace), so every fresh torch.cuda.Stream() would cost another 256 MB of slabs."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _side_streams.get(idx)
+    if s is None:
+        s = _side_streams[idx] = torch.cuda.Stream(device=idx)
+    return s
+
+
 def replay_launch_us(key, iters=100):
     """Average duration (us) of one launch of a recorded kernel shape, inputs resident in HBM: `iters` launches
     captured into one hipGraph (no host in the loop: a Python-driven loop is launch-bound at ~10 us per call and
@@ -101,12 +139,12 @@ def replay_launch_us(key, iters=100):
                if flag else None)
         bm, bn, splits, _ = conv3x3_plan(B, side_len, hw // side_len, cin, cout, stride)
         y = torch.empty(B, cout, ho, wo, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
-        ws, tickets = splitk_workspace(dev, B * ho * wo, cout, bm, bn, splits)
         code = dtype_code(x)
 
         def fn():
             wp = wps[turn[0] % n_copies]
             turn[0] += 1
+            ws, tickets = splitk_workspace(dev, B * ho * wo, cout, bm, bn, splits)   # the scratch of the stream fn runs on
             check(lib.ga_conv3x3_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(tickets), _ptr(bias), _ptr(res), B, side_len,
                                       hw // side_len, cin, cout, stride, bm, bn, splits, code, stream_ptr()), "replay conv")
     elif kind in ("geglu_fwd", "geglu_bwd", "bias_residual_add", "add_layer_norm_fwd", "add_layer_norm_bwd"):
@@ -254,7 +292,7 @@ def replay_launch_us(key, iters=100):
                       "replay sa bwd")
     if fn is None:
         raise GaError(f"no replay recipe for kernel kind {kind!r}")
-    side = torch.cuda.Stream()
+    side = side_stream(dev)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(3):
@@ -582,13 +620,23 @@ class SmoothLoss(torch.autograd.Function):
         return dA, None, None, None, None
 
 
-_tickets = {}   # device index -> one zeroed 32-bit word (the arrival counter of the fused aggregate + loss launch)
+_tickets = {}   # (device index, stream) -> one zeroed 32-bit word (the arrival counter of the fused aggregate + loss launch)
+
+
+def _stream_key(device):
+    """Scratch that kernels hand data through (split-K slabs, arrival tickets) is only safe under stream order: one set per
+    (device, stream the launch goes to).  Launches captured into a hipGraph keep the set of their capture stream."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return (idx, torch.cuda.current_stream(idx).cuda_stream)
 
 
 def _ticket(device):
-    t = _tickets.get(device.index)
+    key = _stream_key(device)
+    t = _tickets.get(key)
     if t is None:
-        t = _tickets[device.index] = torch.zeros(1, dtype=torch.int32, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            raise GaError("the loss launch's ticket word must exist before a hipGraph capture (call ops.prepare_device first)")
+        t = _tickets[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return t
 
 
@@ -611,9 +659,10 @@ def aggregate_loss_fwd(maps, res, first, last, plan):
     terms = torch.empty((plan.T, _lib.GA_TERMS), dtype=torch.float32, device=dev)
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     _count(("aggregate_loss_fwd", plan.T, sum(m.shape[0] for m in maps), npix, Kt, maps[0].shape[0], False, str(maps[0].dtype)))
-    check(load().ga_aggregate_loss_fwd(ptrs, heads, n, res, Kt, first, last, plan.tokens, plan.T, ctypes.byref(plan.params),
-                                       _ptr(A), _ptr(terms), _ptr(loss), _ptr(_ticket(dev)), dtype_code(maps[0]),
-                                       stream_ptr()), "ga_aggregate_loss_fwd")
+    ticket = _ticket(dev)
+    _check_ticketed(load().ga_aggregate_loss_fwd(ptrs, heads, n, res, Kt, first, last, plan.tokens, plan.T,
+                                                 ctypes.byref(plan.params), _ptr(A), _ptr(terms), _ptr(loss), _ptr(ticket),
+                                                 dtype_code(maps[0]), stream_ptr()), "ga_aggregate_loss_fwd", ticket)
     return A, terms, loss
 
 
@@ -1014,7 +1063,7 @@ def conv3x3_packed_weights(weight, transpose_flip):
             for dead in [k for k, (ref, _) in _conv_pack_cache.items() if ref() is None]:
                 del _conv_pack_cache[dead]
         _conv_pack_cache[key] = (weakref.ref(weight), hit)
-    return hit
+    return keep_alive(hit)
 
 
 CONV_KC = 64   # channels per k-step of ga_conv3x3_nhwc (kKC in csrc/conv3x3.hip): Cin must be a multiple
@@ -1037,8 +1086,9 @@ def conv3x3_nhwc(x, wp, cout, stride=1, bias=None, residual=None, plan=None):
     if residual is not None:
         residual = _nhwc(residual)
     _count(("conv3x3", B, Cin, H * W, stride, cout, bias is not None or residual is not None, str(x.dtype)))
-    check(load().ga_conv3x3_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(tickets), _ptr(bias), _ptr(residual), B, H, W,
-                                 Cin, cout, stride, bm, bn, splits, dtype_code(x), stream_ptr()), "ga_conv3x3_nhwc")
+    _check_ticketed(load().ga_conv3x3_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(tickets), _ptr(bias), _ptr(residual), B,
+                                           H, W, Cin, cout, stride, bm, bn, splits, dtype_code(x), stream_ptr()),
+                    "ga_conv3x3_nhwc", tickets)
     return y
 
 
@@ -1063,7 +1113,7 @@ def conv3x3_up2x_nhwc(x, wp, cout, bias=None, plan=None):
     if rc == GA_ERR_SHAPE:
         _no_fused_upsample.add(key)
         return None
-    check(rc, "ga_conv3x3_up2x_nhwc")
+    _check_ticketed(rc, "ga_conv3x3_up2x_nhwc", tickets)
     _count(("conv3x3", B, Cin, 4 * H * W, 1, cout, bias is not None, str(x.dtype)))
     return y
 
@@ -1233,7 +1283,7 @@ def self_attention_supported(q, heads, channels=None):
 
 
 # --------------------------------------------------------------------------------------- Linear layers with folded neighbours
-_lin_ws = {}        # device index -> {"slabs": f32 tensor, "tickets": int32 tensor}; never freed (captured graphs hold the pointers)
+_lin_ws = {}        # (device index, stream) -> {"slabs": f32 tensor, "tickets": int32 tensor}; never freed (captured graphs hold the pointers)
 _lin_plan_cache = {}
 _lin_plan_table = None
 LIN_SLAB_FLOATS = 64 * 2 ** 20     # 256 MB of split-K slabs per device (of 288 GB), allocated once (outside any capture)
@@ -1241,13 +1291,36 @@ LIN_TICKETS = 1 << 16
 
 
 def linear_workspace(device):
-    ws = _lin_ws.get(device.index)
+    """The split-K scratch of the CURRENT stream on `device`: slices of one launch hand their partial tiles to the last arriver
+    through it, and two launches may only share it under stream order — so every stream that launches gets its own (the
+    header's "stream-ordered use" made structural: the default stream, the one side stream of warm-ups / captures / micro-replays,
+    a GUI thread's stream never meet in one slab or ticket array)."""
+    key = _stream_key(device)
+    ws = _lin_ws.get(key)
     if ws is None:
         if torch.cuda.is_current_stream_capturing():
             raise GaError("the Linear workspace must exist before a hipGraph capture (call ops.prepare_device first)")
-        ws = _lin_ws[device.index] = {"slabs": torch.empty(LIN_SLAB_FLOATS, dtype=torch.float32, device=device),
-                                      "tickets": torch.zeros(LIN_TICKETS, dtype=torch.int32, device=device)}
+        ws = _lin_ws[key] = {"slabs": torch.empty(LIN_SLAB_FLOATS, dtype=torch.float32, device=device),
+                             "tickets": torch.zeros(LIN_TICKETS, dtype=torch.int32, device=device)}
     return ws
+
+
+def _check_ticketed(rc, what, tickets):
+    """check() for a launch that takes arrival tickets: a launch that failed after some slices had arrived would leave its
+    ticket words non-zero, and every later launch on those tiles would never see a last arriver (Y silently unwritten) —
+    return them to zero before raising."""
+    if rc != 0 and tickets is not None and not torch.cuda.is_current_stream_capturing():
+        tickets.zero_()
+    check(rc, what)
+
+
+def tickets_are_zero(device=None):
+    """True when every arrival-ticket word of every stream's scratch on `device` is zero (what every completed launch leaves;
+    synchronises).  GraphRunner.release asserts it."""
+    torch.cuda.synchronize(device)
+    idx = torch.device(device).index if device is not None else torch.cuda.current_device()
+    words = [ws["tickets"] for (d, _), ws in _lin_ws.items() if d == idx] + [t for (d, _), t in _tickets.items() if d == idx]
+    return all(int(w.abs().sum().item()) == 0 for w in words)
 
 
 def splitk_workspace(device, M, N, bm, bn, splits):
@@ -1261,15 +1334,20 @@ def splitk_workspace(device, M, N, bm, bn, splits):
     return ws["slabs"], ws["tickets"]
 
 
-def prepare_device(device):
-    """Allocate the persistent per-device scratch of the kernels (split-K slabs, arrival tickets) — once, before any
-    hipGraph capture, so that captured launches and eager launches share the same, never-moving buffers."""
+def prepare_device(device, stream=None):
+    """Allocate the persistent scratch of the kernels (split-K slabs, arrival tickets) for the current stream (or `stream`) on
+    `device` — before any hipGraph capture on that stream: captured launches keep these never-moving buffers."""
     device = torch.device(device)
     if device.type == "cuda":
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        linear_workspace(device)
-        _ticket(device)
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                linear_workspace(device)
+                _ticket(device)
+        else:
+            linear_workspace(device)
+            _ticket(device)
 
 
 def _measured_linear_plans():
@@ -1384,7 +1462,7 @@ def linear_fused(x, weight, bias=None, residual=None, geglu=False, want_preact=F
         slabs, tickets = ws["slabs"], ws["tickets"]
     _count(("linear", M, K, 0, int(bool(geglu)) + 2 * int(ln is not None) + 4 * int(residual is not None), N, bias is not None,
             str(x.dtype)))
-    check(load().ga_linear_fused(_ptr(x), ldx, _ptr(weight), _ptr(y), y.stride(-2) if y.dim() > 1 else n_out,
-                                 ctypes.byref(ep), _ptr(slabs), _ptr(tickets), M, K, N, bm, bn, splits, stages,
-                                 dtype_code(x), stream_ptr()), "ga_linear_fused")
+    _check_ticketed(load().ga_linear_fused(_ptr(x), ldx, _ptr(weight), _ptr(y), y.stride(-2) if y.dim() > 1 else n_out,
+                                           ctypes.byref(ep), _ptr(slabs), _ptr(tickets), M, K, N, bm, bn, splits, stages,
+                                           dtype_code(x), stream_ptr()), "ga_linear_fused", tickets)
     return {"y": y, "preact": preact, "ln_stats": ln_stats, "row_partials": row_partials, "parts": parts}

@@ -23,7 +23,14 @@
 extern "C" {
 #endif
 
-#define GA_VERSION 120 /* 0.1.2: strict bbox mode, paint-with-words entry points */
+/* Bumped whenever an exported signature changes or an export is added; a binder checks ga_version() against the header it
+ * was written for BEFORE its first call (guided-attention_amd/_lib.py:load does) — a stale binding passes pointers in the
+ * wrong positions.  History:
+ *   120  0.1.2  strict bbox mode, paint-with-words entry points
+ *   130  0.1.3  (round 3, bumped late) ga_conv3x3_nhwc / ga_gemm_nt gained `tickets` behind `workspace`, ga_group_norm_bwd
+ *               gained `g_res` before `dx`; new: ga_aggregate_loss_fwd, ga_linear_fused, ga_linear_workspace,
+ *               ga_splitk_workspace_floats, ga_conv3x3_up2x_nhwc, ga_cat_channels, ga_conv3x3_packed_elems */
+#define GA_VERSION 130
 
 typedef void* ga_stream_t; /* hipStream_t */
 

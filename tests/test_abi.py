@@ -83,9 +83,21 @@ def test_hot_kernels_request_their_operands_in_batches(lib):
 def test_version_and_strerror(lib):
     m = re.search(r"#define GA_VERSION (\d+)", HEADER.read_text())
     assert lib.ga_version() == int(m.group(1))
+    from guided_attention_amd import _lib
+    assert _lib.GA_VERSION == int(m.group(1))        # the binding is written for the header's version (load() refuses otherwise)
     assert lib.ga_strerror(0) == b"ok"
     assert b"NULL" in lib.ga_strerror(-1)
     assert lib.ga_strerror(-999) == b"unknown status"
+
+
+def test_loader_refuses_a_library_of_another_abi_version(monkeypatch):
+    """Exported signatures changed between versions by pointers inserted in the middle of argument lists (round 3: `tickets`
+    behind `workspace`): a binding and a library of different versions must not meet."""
+    from guided_attention_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "GA_VERSION", _lib.GA_VERSION - 10)
+    with pytest.raises(_lib.GaError, match="ABI version"):
+        _lib.load()
 
 
 def test_struct_layout_matches_header(tmp_path):

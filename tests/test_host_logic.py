@@ -354,3 +354,41 @@ def test_no_gc_scope_restores_the_collector():
         assert not gc.isenabled()
     finally:
         gc.enable()
+
+
+def test_folded_layernorm_weights_are_evicted_only_when_dead_or_replaced_and_runners_keep_theirs():
+    """fused_linear._folded (round-4 ADVICE): the per-norm cache used to `clear()` once it held more than 8 entries, freeing
+    folded weights that captured hipGraphs read by raw pointer.  Now (a) only entries whose weight is gone, or that a newer
+    version of the same weight replaced, are dropped, and (b) whatever a capture was handed stays alive through
+    `ops.keepalive_scope`, whatever the cache does afterwards."""
+    import gc
+    from guided_attention_amd import fused_linear, ops
+    norm = torch.nn.LayerNorm(8)
+    lins = [torch.nn.Linear(8, 16) for _ in range(12)]
+    with ops.keepalive_scope() as keep:                 # what GraphRunner._capture wraps its captures in
+        first = fused_linear._folded(lins[0].weight, lins[0].bias, norm)
+    assert all(any(t is k for k in keep.tensors) for t in first)
+    for lin in lins[1:]:                                # more than 8 LIVE weights: nothing may be dropped
+        fused_linear._folded(lin.weight, lin.bias, norm)
+    cache = norm.__dict__["_ga_folded"]
+    assert len(cache) == 12 and fused_linear._folded(lins[0].weight, lins[0].bias, norm)[0] is first[0]
+    wg = first[0]
+    ref = (lins[0].weight.float() * norm.weight.float()[None, :])
+    assert torch.allclose(wg.float(), ref) and torch.allclose(first[1], ref.sum(1))
+    # dead weights go at the next insertion
+    del lins[4:], lin                                  # (the loop variable held the last one)
+    gc.collect()
+    extra = torch.nn.Linear(8, 16)
+    fused_linear._folded(extra.weight, extra.bias, norm)
+    assert len(cache) == 5
+    # a new version of a live weight replaces its older entry at the next eviction; the capture's copy is untouched
+    with torch.no_grad():
+        lins[0].weight.mul_(2.0)
+    second = fused_linear._folded(lins[0].weight, lins[0].bias, norm)
+    assert second[0] is not first[0] and torch.allclose(second[0].float(), 2 * ref)
+    more = [torch.nn.Linear(8, 16) for _ in range(6)]
+    for lin in more:
+        fused_linear._folded(lin.weight, lin.bias, norm)
+    assert sum(1 for k in cache if k[0] == lins[0].weight.data_ptr()) == 1
+    assert torch.allclose(keep.tensors[0].float(), ref)     # the runner's reference still holds the tensor it captured against
+    assert ops._KEEP is None

@@ -48,9 +48,8 @@ def main():
                     tiles = -(-M // bm) * -(-N // bn)
                     if tiles * sp > 4096 or (tiles * sp < 64 and sp < 8):
                         continue
-                    ws, tk = ops.splitk_workspace(x.device, M, N, bm, bn, sp)
-
                     def call():
+                        ws, tk = ops.splitk_workspace(x.device, M, N, bm, bn, sp)   # the scratch of the stream this runs on
                         rc = lib.ga_gemm_nt(P(x), P(w), P(y), P(ws), P(tk), P(bias), None, M, K, N, bm, bn, sp, dtype_code(x), stream_ptr())
                         assert rc == 0, rc
                     res[(bm, bn, sp)] = replay_us(call, iters=10)

@@ -28,7 +28,7 @@ TILES = ((128, 128, 3), (128, 128, 2), (128, 64, 4), (128, 64, 3), (64, 128, 4),
 
 
 def replay_us(fn, iters=20, reps=3):
-    side = torch.cuda.Stream()
+    side = ops.side_stream()
     side.wait_stream(torch.cuda.current_stream())
     best = None
     with torch.cuda.stream(side):
