@@ -392,3 +392,45 @@ def test_folded_layernorm_weights_are_evicted_only_when_dead_or_replaced_and_run
     assert sum(1 for k in cache if k[0] == lins[0].weight.data_ptr()) == 1
     assert torch.allclose(keep.tensors[0].float(), ref)     # the runner's reference still holds the tensor it captured against
     assert ops._KEEP is None
+
+
+def test_from_pretrained_loads_a_local_diffusers_folder(tmp_path):
+    """`GuidedAttention.from_pretrained(<local diffusers folder>)` (reference: run.py:18-29 loads
+    `CompVis/stable-diffusion-v1-4` that way; there is no network here, so the folder is written by the test): UNet weights by
+    their diffusers names from `unet/diffusion_pytorch_model.safetensors`, the VAE's decoder-side tensors from
+    `vae/diffusion_pytorch_model.safetensors` (encoder tensors ignored), `revision="fp16"` -> half precision, a mismatching
+    checkpoint refused, a missing folder refused unless random_init."""
+    from safetensors.torch import save_file
+    from guided_attention_amd.pipeline_guided_attention import GuidedAttention
+    from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig
+    cfg = UNetConfig.tiny(32, 48)
+    src = UNet2DConditionModel(cfg).init_weights_(seed=77)
+    sd = {k: v.detach().clone().contiguous() for k, v in src.state_dict().items()}
+    assert "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight" in sd and "conv_in.weight" in sd   # diffusers names
+    folder = tmp_path / "stable-diffusion-tiny"
+    (folder / "unet").mkdir(parents=True)
+    (folder / "vae").mkdir()
+    save_file(sd, str(folder / "unet" / "diffusion_pytorch_model.safetensors"))
+    pqc_w, pqc_b = torch.randn(4, 4, 1, 1), torch.randn(4)
+    save_file({"post_quant_conv.weight": pqc_w, "post_quant_conv.bias": pqc_b, "encoder.conv_in.weight": torch.randn(8, 3, 3, 3),
+               "quant_conv.weight": torch.randn(8, 8, 1, 1)}, str(folder / "vae" / "diffusion_pytorch_model.safetensors"))
+    pipe = GuidedAttention.from_pretrained(str(folder), unet_config=cfg)
+    got = pipe.unet.state_dict()
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    assert torch.equal(pipe.vae.post_quant_conv.weight, pqc_w) and torch.equal(pipe.vae.post_quant_conv.bias, pqc_b)
+    assert pipe.unet.dtype == torch.float32 and pipe.tokenizer is not None and pipe.text_encoder is not None
+    half = GuidedAttention.from_pretrained(str(folder), revision="fp16", unet_config=cfg)
+    assert half.unet.dtype == torch.float16
+    assert torch.equal(half.unet.conv_in.weight, sd["conv_in.weight"].half())
+    bare = GuidedAttention.from_pretrained(str(folder), unet_config=cfg, weights=False)     # ranks != 0 before the broadcast
+    assert set(bare.unet.state_dict()) == set(sd)
+    # a checkpoint of another architecture is refused, by name
+    bad = dict(sd)
+    bad.pop("conv_in.weight")
+    bad["conv_in.kernel"] = sd["conv_in.weight"]
+    save_file(bad, str(folder / "unet" / "diffusion_pytorch_model.safetensors"))
+    with pytest.raises(RuntimeError, match="checkpoint mismatch"):
+        GuidedAttention.from_pretrained(str(folder), unet_config=cfg)
+    with pytest.raises(FileNotFoundError):
+        GuidedAttention.from_pretrained("CompVis/stable-diffusion-v1-4")
+    GuidedAttention.from_pretrained("CompVis/stable-diffusion-v1-4", random_init=True, unet_config=cfg)

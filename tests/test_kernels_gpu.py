@@ -1066,3 +1066,136 @@ def test_linear_fused_strided_rows_and_errors(ops):
         ops.linear_fused(big[:, :100], w[:, :100].contiguous(), None)       # K not a multiple of 64
     with pytest.raises(ops.GaError):
         ops.linear_fused(big[:, :128].float(), w.float(), None)             # fp32 is not served
+
+
+def _gelu64(g):
+    return 0.5 * g * (1.0 + torch.erf(g / math.sqrt(2.0)))
+
+
+def _fold(w, bias, gamma, beta, T):
+    """What fused_linear._folded hands the kernel: (gamma o W rounded once, its f32 column sums, beta . W^T + bias)."""
+    wg = (w.float() * gamma.float()[None, :]).to(T).contiguous()
+    return wg, wg.float().sum(1).contiguous(), ((w.float() @ beta.float()) + bias.float()).contiguous()
+
+
+# The Linear shapes that lead the bench's roofline entry (BENCH_r03 `roofline.shapes`): the GEGLU feed-forward of every level at
+# the batch-3 joint pass and at batch 1, and the feed-forward output projections behind them — (M, C) per level.
+FF_LEVELS = [(12288, 320), (3072, 640), (768, 1280), (4096, 320), (1024, 640), (256, 1280)]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("level", FF_LEVELS, ids=lambda s: "x".join(map(str, s)))
+def test_linear_fused_benched_feed_forward_shapes(ops, level, dt):
+    """The feed-forward pair of a transformer block exactly as the pipeline runs it at the benched sizes, on the plans the
+    measured table gives (guided-attention_amd/linear_plans.json — until round 4 these (tile, split, ring) tuples only ever
+    ran inside bench.py): LayerNorm folded in front + GEGLU (M x C x 8C, the pre-activation kept for the backward), then the
+    output projection with bias + residual and row partial sums (M x 4C x C), each against fp64 on the CPU."""
+    M, C = level
+    T = DT[dt]
+    tol = TOL[dt] * 2
+    x0 = dev(hashrand.normalish((M, C), 90 + C) * 1.2 + 0.2, T)
+    w0 = dev(hashrand.normalish((C, C), 91) * C ** -0.5, T)
+    prod = ops.linear_fused(x0, w0, None, residual=x0, want_row_partials=True)          # the residual stream + its row partials
+    h = prod["y"]
+    gamma = dev(hashrand.normalish((C,), 92) * 0.2 + 1.0, T)
+    beta = dev(hashrand.normalish((C,), 93) * 0.2, T)
+    w1 = dev(hashrand.normalish((8 * C, C), 94) * C ** -0.5, T)
+    b1 = dev(hashrand.normalish((8 * C,), 95) * 0.3, T)
+    wg, colsum, shift = _fold(w1, b1, gamma, beta, T)
+    plan1 = ops.linear_plan(M, C, 8 * C, True)
+    out = ops.linear_fused(h, wg, None, geglu=True, want_preact=True, ln=(prod["row_partials"], colsum, shift, 1e-5),
+                           want_ln_stats=True)
+    hd = h.double().cpu()
+    mean, var = hd.mean(-1, keepdim=True), hd.var(-1, unbiased=False, keepdim=True)
+    ln = (hd - mean) / torch.sqrt(var + 1e-5) * gamma.double().cpu() + beta.double().cpu()
+    pre_ref = ln @ w1.double().cpu().T + b1.double().cpu()
+    close(out["preact"], pre_ref.numpy(), tol * 2, f"LayerNorm -> FF-in projection, plan {plan1}")
+    pre = out["preact"].double().cpu()                       # the gate sees the rounded projection
+    close(out["y"], (pre[:, :4 * C] * _gelu64(pre[:, 4 * C:])).numpy(), tol, f"GEGLU, plan {plan1}")
+    y_nograd = ops.linear_fused(h, wg, None, geglu=True, ln=(prod["row_partials"], colsum, shift, 1e-5))["y"]
+    assert torch.equal(y_nograd, out["y"])                   # the no-grad form (joint / CFG passes) writes the same values
+    ff = out["y"]
+    w2 = dev(hashrand.normalish((C, 4 * C), 96) * (4 * C) ** -0.5, T)
+    b2 = dev(hashrand.normalish((C,), 97) * 0.3, T)
+    plan2 = ops.linear_plan(M, 4 * C, C, False)
+    o2 = ops.linear_fused(ff, w2, b2, residual=h, want_row_partials=True)
+    ref2 = ff.double().cpu() @ w2.double().cpu().T + b2.double().cpu() + hd
+    close(o2["y"], ref2.numpy(), tol, f"FF-out + bias + residual, plan {plan2}")
+    yd = o2["y"].double().cpu()
+    close(o2["row_partials"][:, :, 0].sum(1), yd.sum(-1).numpy(), 1e-5, "row partial sums of the stored result")
+    if plan2[2] > 1:
+        assert torch.equal(o2["y"], ops.linear_fused(ff, w2, b2, residual=h, want_row_partials=True)["y"])
+    assert int(ops.linear_workspace(h.device)["tickets"].abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("case", ["offset4", "offset16", "outliers50", "offset16+outliers50"])
+def test_linear_fused_layernorm_fold_on_rows_real_checkpoints_have(ops, case, dt):
+    """The LayerNorm fold runs the GEMM on the RAW residual stream and normalises afterwards,
+    rstd * (x W'^T - mean * colsum) + shift with W' = gamma o W rounded to the activation type: the product's rounding error
+    scales with |x|, not with the normalised row.  Seeded random weights give benign rows (|mean| / std = 0.2 in
+    test_linear_fused); trained SD checkpoints carry rows with a large common offset and a few channels of 50x the typical
+    magnitude.  Those rows here, against fp64, at the per-kernel bar (2e-3 / 1.6e-2 of the result's maximum, x2 for the two
+    roundings of the folded form as in test_linear_fused) — with the statistics from one-pass (sum, sum of squares) partials."""
+    M, K, N = 512, 640, 1920
+    T = DT[dt]
+    z = hashrand.normalish((M, K), 130)
+    x = z * 1.0
+    if "offset4" in case:
+        x = x + 4.0
+    if "offset16" in case:
+        x = x + 16.0
+    if "outliers50" in case:
+        x[:, [3, 77, 200, 639]] *= 50.0
+    x = dev(x, T)
+    w0 = dev(np.eye(K, dtype=np.float32), T)
+    prod = ops.linear_fused(x, w0, None, want_row_partials=True, plan=(64, 64, 1))   # identity: h = x exactly, partials of x
+    h = prod["y"]
+    assert torch.equal(h, x)
+    gamma = dev(hashrand.normalish((K,), 131) * 0.3 + 1.0, T)
+    beta = dev(hashrand.normalish((K,), 132) * 0.2, T)
+    w = dev(hashrand.normalish((N, K), 133) * K ** -0.5, T)
+    bias = dev(hashrand.normalish((N,), 134) * 0.3, T)
+    wg, colsum, shift = _fold(w, bias, gamma, beta, T)
+    hd = h.double().cpu()
+    mean, var = hd.mean(-1, keepdim=True), hd.var(-1, unbiased=False, keepdim=True)
+    ratio = float((mean.abs() / var.sqrt()).median())
+    ln = (hd - mean) / torch.sqrt(var + 1e-5) * gamma.double().cpu() + beta.double().cpu()
+    ref = ln @ w.double().cpu().T + bias.double().cpu()
+    worst = 0.0
+    for plan in ((64, 64, 1), (128, 64, 1), (128, 128, 1), (64, 64, 2)):
+        out = ops.linear_fused(h, wg, None, ln=(prod["row_partials"], colsum, shift, 1e-5), want_ln_stats=True, plan=plan)
+        err = float((out["y"].double().cpu() - ref).abs().max() / ref.abs().max())
+        worst = max(worst, err)
+        close(out["ln_stats"][:, 0], mean[:, 0].numpy(), 1e-5, "mean")
+        close(out["ln_stats"][:, 1], (1.0 / torch.sqrt(var + 1e-5))[:, 0].numpy(), 2e-3, "rstd from one-pass sums")
+    # the unfolded form (LayerNorm kernel, then the plain Linear) on the same rows, for the record
+    y_sep = ops.linear_fused(ops.layer_norm(h, gamma, beta, 1e-5), w, bias, plan=(64, 64, 1))["y"]
+    err_sep = float((y_sep.double().cpu() - ref).abs().max() / ref.abs().max())
+    print(f"[measured] LayerNorm fold {case} {dt}: |mean|/std {ratio:.1f}  folded {worst:.2e}  separate {err_sep:.2e}  bar {TOL[dt] * 4:.1e}")
+    assert worst <= TOL[dt] * 4, (case, dt, worst)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("offset", [4.0, 16.0])
+@pytest.mark.parametrize("shape", [(1, 320, 64, 64), (2, 1280, 16, 16)])
+def test_group_norm_act_on_offset_groups(ops, shape, offset, dt):
+    """One-pass variance (sum, sum of squares in f32) on groups whose mean is 4 / 16 standard deviations from zero — what a
+    trained UNet's GroupNorm inputs look like, unlike the zero-centred rows of test_group_norm_act — forward and backward
+    against fp64, same bars."""
+    B, C, H, W = shape
+    x = dev(hashrand.normalish(shape, 140 + C) + offset, DT[dt]).contiguous(memory_format=torch.channels_last)
+    w = dev(hashrand.normalish((C,), 141) * 0.5 + 1.0, DT[dt])
+    b = dev(hashrand.normalish((C,), 142) * 0.2, DT[dt])
+    g = dev(hashrand.normalish(shape, 143), DT[dt]).contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(True)
+    y = ops.group_norm_act(xa, w, b, 32, 1e-5, True)
+    y.backward(g)
+    xr = x.double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.silu(torch.nn.functional.group_norm(xr, 32, w.double().cpu(), b.double().cpu(), 1e-5))
+    yr.backward(g.double().cpu())
+    ey = float((y.detach().double().cpu() - yr.detach()).abs().max() / yr.detach().abs().max())
+    eg = float((xa.grad.double().cpu() - xr.grad).abs().max() / xr.grad.abs().max())
+    print(f"[measured] GroupNorm offset {offset} {shape} {dt}: y {ey:.2e} dx {eg:.2e}")
+    close(y, yr.detach().numpy(), TOL[dt] * 2, "y")
+    close(xa.grad, xr.grad.numpy(), TOL[dt] * 3, "dx")
