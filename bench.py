@@ -53,6 +53,8 @@ def parse(argv=None):
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying hipGraphs")
     ap.add_argument("--no-joint-pass", action="store_true",
                     help="run the loss-only guidance forward and the CFG pair as two passes (B=1, B=2) instead of one B=3 pass")
+    ap.add_argument("--no-run-ahead", action="store_true",
+                    help="refinement loop reads each loss table back before it enqueues the backward / update / next evaluation")
     ap.add_argument("--two-pass-steps", type=int, default=1,
                     help="after the timed region, also time this many images with the two-pass form of the loss-only "
                          "steps and report it beside the headline (0 = skip)")
@@ -179,6 +181,7 @@ def build_pipeline(args, device, rank, world):
     pipe.skip_unused_guidance = args.skip_unused_guidance
     pipe.use_graphs = not args.eager
     pipe.batch_loss_only_guidance = not args.no_joint_pass
+    pipe.speculative_refinement = not args.no_run_ahead
     return pipe, cfg, {"messages": n_msgs, "seconds": round(bcast_s, 4), "bytes": nbytes,
                        "timed": "between two barriers" if world > 1 else "single rank: no collective"}
 
@@ -549,6 +552,12 @@ def main(argv=None):
                                            "guidance forward + CFG pair of a step without latent update batched as one "
                                            "B=3 pass (every evaluation performed)"),
                        "launch": "eager" if args.eager else "hipGraph replay of the UNet passes (captured in warm-up)",
+                       "refinement": ("enqueue, read the loss table, decide, enqueue" if args.eager or not pipe.speculative_refinement
+                                      else "run-ahead: an iteration's backward, latent update and the next guidance evaluation "
+                                           "are enqueued before its loss table is read (pinned asynchronous copy); same "
+                                           "launches and counters; an enqueued update is discarded and repeated only on a "
+                                           f"loss of exactly 0 — happened {pipe.discarded_speculations} times in this run, "
+                                           "never counted in unet_calls"),
                        "weights": "seeded random init (no checkpoint offline)",
                        "amortised_outside_the_clock": "done once in the warm-up image(s), reused by every timed image (same "
                                                       "prompt, same 50 timesteps): hipGraph capture, packed conv weights, "

@@ -20,7 +20,23 @@ from . import ops
 from .utils.ptp_utils import pin_context_projections, refresh_context_projections
 
 
+class PendingLossTable:
+    """The packed loss table of ONE captured evaluation on its way to the host: copied device -> pinned host memory right
+    behind the replay (asynchronously, on the replay's stream) with an event behind the copy.  `.cpu()` — what
+    GuidedAttention._loss_host calls on the table — waits for THAT event only, not for whatever the host has enqueued behind it
+    in the meantime (the speculative backward / update / next evaluation of the refinement loop)."""
+
+    def __init__(self, row, event):
+        self.row, self.event = row, event
+
+    def cpu(self):
+        self.event.synchronize()
+        return self.row.clone()
+
+
 class GraphRunner:
+    HOST_SLOTS = 4    # evaluations whose loss tables may be in flight to the host at once (the refinement loop keeps two)
+
     @classmethod
     def for_run(cls, pipe, store, prompt_embeds, latents, attention_res, smooth, sigma, ksize, normalize_eot):
         from .utils import shared_state as state
@@ -61,6 +77,10 @@ class GraphRunner:
         # timestep-only part of the UNet in every pass; `_set_t` refreshes them before a replay
         self.tp = {n: torch.empty_like(pipe.unet.time_projection(981, n)) for n in ((1, 2, 3) if self.joint else (1, 2))}
         self._capture(store)
+        # pinned landing slots for the loss tables + one event each (PendingLossTable)
+        self._host_rows = torch.empty((self.HOST_SLOTS, self.parts[4].numel()), dtype=self.parts[4].dtype).pin_memory()
+        self._host_events = [torch.cuda.Event() for _ in range(self.HOST_SLOTS)]
+        self._host_turn = 0
 
     def _set_t(self, t, *batches):
         self.t_dev.fill_(int(t))
@@ -178,13 +198,20 @@ class GraphRunner:
             store.cur_step += 1
 
     def evaluate(self, latents, t, store):
+        """-> (the latents leaf the captured loss depends on, loss parts).  The packed table of the parts is a
+        PendingLossTable: the replay overwrites the static device table at the next evaluation, the pinned copy taken right
+        behind this one does not, so the host may read it after enqueuing more work."""
         self._set_t(t, 1)
         with torch.no_grad():
             self.lat_g.copy_(latents)
         self.g_eval.replay()
         ops.add_census(self.launches["eval"])
         self._publish(store, self.store_eval)
-        return self.lat_g, self.parts
+        slot = self._host_turn % self.HOST_SLOTS
+        self._host_turn += 1
+        self._host_rows[slot].copy_(self.parts[4], non_blocking=True)
+        self._host_events[slot].record()
+        return self.lat_g, self.parts[:4] + (PendingLossTable(self._host_rows[slot], self._host_events[slot]),)
 
     def backward(self):
         self.g_grad.replay()

@@ -67,6 +67,12 @@ class GuidedAttention:
         # syncs and host I/O; hipGraph replay is bypassed for such a run).  config.diagnostic_level > 0 switches them on
         # as well.  Off by default, never inside a timed benchmark region.
         self.reference_side_effects = False
+        # With hipGraphs, inside the iterative refinement: enqueue an iteration's backward, latent update and the NEXT guidance
+        # evaluation before reading the iteration's loss table back.  Nothing is speculative about WHAT runs — the update is
+        # unconditional whenever the loss is not exactly 0 (reference :551), and whatever the threshold test says afterwards the
+        # next launch is an evaluation of the updated latents (the next iteration's, or the final one, :566) — only about the
+        # `loss != 0` test, whose other outcome discards and repeats (never counted).  False: enqueue, read, decide, enqueue.
+        self.speculative_refinement = True
         self._runner = None
         self._graph_cache = {}
         self.unet_calls = {"fwd_b1_grad": 0, "bwd": 0, "fwd_b2": 0, "loss_evals": 0, "joint_b3": 0}
@@ -506,28 +512,89 @@ class GuidedAttention:
         state.sub_iteration = iteration
         losses = None
         unscaled_losses = None
+        cond1 = text_embeddings[1].unsqueeze(0)
+        ev = (attention_store, attention_res, smooth_attentions, sigma, kernel_size, normalize_eot)
+        runner = self._runner
+        custom = getattr(state.config, "custom_loss", None)
+        if runner is not None and self.speculative_refinement and not custom and self._loss_plan(
+                smooth_attentions, sigma, kernel_size).T > 0:
+            return self._refine_run_ahead(latents, t, cond1, ev, step_size, max_refinement_steps)
         while losses is None or not self.meets_threshold(state.cur_time_step_iter, state.config.thresholds,
                                                          unscaled_losses):
             helpers.log(f"subiteration: {iteration}")
             iteration += 1
             state.sub_iteration = iteration
-            latents, losses_dict = self._guidance_eval(  # restarts the graph at the latents
-                latents, t, text_embeddings[1].unsqueeze(0), attention_store, attention_res, smooth_attentions, sigma,
-                kernel_size, normalize_eot)
+            latents, losses_dict = self._guidance_eval(latents, t, cond1, *ev)  # restarts the graph at the latents
             loss, losses, unscaled_losses = self._compute_loss(losses_dict, return_losses=True)
-            if losses_dict["_fused"]["host_total"].item() != 0:  # reference :551 `elif loss != 0`
+            if not self._loss_is_zero(losses_dict):  # reference :551 `elif loss != 0`
                 latents = self._update_latent(latents, loss, step_size)
             if iteration >= max_refinement_steps:
                 helpers.log(f"\t Exceeded max number of iterations ({max_refinement_steps})! ", self.verbose)
                 break
-        latents, max_attention_per_index = self._guidance_eval(
-            latents, t, text_embeddings[1].unsqueeze(0), attention_store, attention_res, smooth_attentions, sigma,
-            kernel_size, normalize_eot)
+        latents, max_attention_per_index = self._guidance_eval(latents, t, cond1, *ev)
         loss, losses, unscaled_losses = self._compute_loss(max_attention_per_index, return_losses=True)
         helpers.log(f"\t Finished with loss of: {max_attention_per_index['_fused']['host_total'].item()} "
                     f"iter: {iteration}", self.verbose)
         state.sub_iteration = 0
         return loss, latents, max_attention_per_index
+
+    def _refine_run_ahead(self, latents, t, cond1, ev, step_size, max_refinement_steps):
+        """The loop of _perform_iterative_refinement_step on the hipGraph runner with the host one evaluation BEHIND the GPU:
+        eval_k is enqueued, then — before its loss table is read — backward_k, the latent update and eval_k+1.  The GPU runs
+        eval -> backward -> update -> eval ... back to back; the device -> host copy of each table (pinned, asynchronous) and
+        the host's threshold logic overlap the next pass (round 3: 215 us + 129 us of idle GPU per iteration,
+        profiles/r3_gpu_idle_gaps.md).  Same launches, same order, same counters and log lines as the loop above; the one
+        speculated fact is `loss != 0` (reference :551): a loss of exactly 0 discards the enqueued update + evaluation,
+        takes their counts back and evaluates the unchanged latents again, as the reference would."""
+        runner = self._runner
+        iteration = 0
+        helpers.log(f"subiteration: {iteration}")
+        # the latents each evaluation starts from, as tensors of their own: the leaf an evaluation returns is the runner's ONE
+        # static buffer, which the evaluation enqueued ahead overwrites
+        current = latents.detach().clone()
+        pending = self._guidance_eval_enqueue(current, t, ev[0])
+        while True:
+            iteration += 1
+            state.sub_iteration = iteration
+            leaf, parts = pending
+            n_log = len(self._deferred_log)
+            updated = self._update_latent(leaf, runner.loss, step_size)          # enqueues backward_k + the axpy (a new tensor)
+            nxt = self._guidance_eval_enqueue(updated, t, ev[0])                 # enqueues eval_k+1 on the updated latents
+            losses_dict = self._loss_host(*parts)                                # waits for eval_k's table only
+            loss, losses, unscaled_losses = self._compute_loss(losses_dict, return_losses=True)
+            if self._loss_is_zero(losses_dict):                                  # reference :551: no update on a zero loss
+                del self._deferred_log[n_log:]
+                self.unet_calls["bwd"] -= 1
+                self.unet_calls["fwd_b1_grad"] -= 1
+                self.discarded_speculations += 1
+                nxt = self._guidance_eval_enqueue(current, t, ev[0])             # the unchanged latents, evaluated again
+            else:
+                current = updated
+            pending = nxt
+            if iteration >= max_refinement_steps:
+                helpers.log(f"\t Exceeded max number of iterations ({max_refinement_steps})! ", self.verbose)
+                break
+            if self.meets_threshold(state.cur_time_step_iter, state.config.thresholds, unscaled_losses):
+                break
+            helpers.log(f"subiteration: {iteration}")
+        latents, parts = pending                                                 # the final evaluation (:566-578)
+        max_attention_per_index = self._loss_host(*parts)
+        loss, losses, unscaled_losses = self._compute_loss(max_attention_per_index, return_losses=True)
+        helpers.log(f"\t Finished with loss of: {max_attention_per_index['_fused']['host_total'].item()} "
+                    f"iter: {iteration}", self.verbose)
+        state.sub_iteration = 0
+        return loss, latents, max_attention_per_index
+
+    @staticmethod
+    def _loss_is_zero(losses_dict):
+        return losses_dict["_fused"]["host_total"].item() == 0
+
+    discarded_speculations = 0   # evaluations enqueued ahead of a `loss != 0` test that came out the other way (never counted)
+
+    def _guidance_eval_enqueue(self, latents, t, attention_store):
+        """Enqueue one captured guidance evaluation; -> (latents leaf, loss parts with the table still on its way)."""
+        self.unet_calls["fwd_b1_grad"] += 1
+        return self._runner.evaluate(latents, t, attention_store)
 
     verbose = False
 

@@ -70,7 +70,7 @@ MAIN_CALLS = ("fwd_b1_grad", "bwd", "fwd_b2", "loss_evals")
 
 
 @pytest.mark.parametrize("variant", ["rerun", "reference-capture", "truncated", "skip-unused", "graphs", "graphs-truncated",
-                                     "graphs-two-pass", "two-launch-loss", "graphs-two-launch-loss"])
+                                     "graphs-two-pass", "two-launch-loss", "graphs-two-launch-loss", "graphs-no-run-ahead"])
 def test_variants_are_result_identical(variant):
     """capture='reference', the truncated guidance forward and the skipped log-only guidance passes must
     not change the latents.  Library conv/GEMM kernels may be chosen differently from call to call, so
@@ -100,8 +100,12 @@ def test_variants_are_result_identical(variant):
     elif variant.startswith("graphs"):
         mode = "truncated" if variant.endswith("truncated") else "full"
         joint = not variant.endswith("two-pass")
+        # default: the refinement loop enqueues backward / update / next evaluation before reading a loss table back;
+        # "no-run-ahead": enqueue, read, decide, enqueue — same launches, same counters, same latents
+        pipe.speculative_refinement = not variant.endswith("no-run-ahead")
         out, ctrl = run_product(pipe, meta, embeds, lat0, noise, thr, use_graphs=True, guidance_forward=mode,
                                 batch_loss_only_guidance=joint)
+        assert pipe.discarded_speculations == 0
         # every evaluation of the eager run is performed; with `joint`, the loss-only guidance forward and the CFG
         # pair of a step share one batch-3 pass
         assert {k: out.unet_calls[k] for k in MAIN_CALLS} == {k: base.unet_calls[k] for k in MAIN_CALLS}
@@ -117,6 +121,7 @@ def test_variants_are_result_identical(variant):
         out, _ = run_product(pipe, meta, embeds, lat0, noise, thr, skip_unused_guidance=True)
         assert out.unet_calls["fwd_b1_grad"] < base.unet_calls["fwd_b1_grad"]
     pipe.guidance_forward, pipe.skip_unused_guidance, pipe.use_graphs, pipe.batch_loss_only_guidance = "full", False, False, True
+    pipe.speculative_refinement = True
     assert out.unet_calls["bwd"] == base.unet_calls["bwd"] and out.unet_calls["fwd_b2"] == base.unet_calls["fwd_b2"]
     err = (out.latents - base.latents).abs().max().item() / base.latents.abs().max().item()
     assert err < 2e-4, err
@@ -172,6 +177,36 @@ def test_half_precision_pipeline_vs_oracle(dt, tol, mode):
     rms = float(np.sqrt(np.mean((out.latents.float().cpu().numpy() - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
     print(f"[measured] half-precision pipeline {dt} {mode}: latents max-rel {err:.3e} rms-rel {rms:.3e}")
     assert err < tol, err
+
+
+def test_run_ahead_refinement_discards_an_update_enqueued_ahead_of_a_zero_loss(monkeypatch):
+    """The refinement loop on the hipGraph runner enqueues backward_k, the update and eval_k+1 BEFORE it has read eval_k's loss
+    table; the only fact it assumes is `loss != 0` (reference :551 — on a loss of exactly 0 the latents are not updated).  A
+    zero loss is forced at the second refinement iteration of every refinement call: the run-ahead loop must take the enqueued
+    update back (latents, call counters, the deferred gradient-size log) and evaluate the unchanged latents again, i.e. end
+    with exactly the counters and latents of the loop that reads before it enqueues."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from guided_attention_amd.pipeline_guided_attention import GuidedAttention
+    meta = G9[0]
+    unet, embeds, lat0, noise, thr = g9_setup(meta)
+    pipe = build_product(unet, torch.float32)
+    seen = {"n": 0}
+
+    def zero_at_second(losses_dict):
+        from guided_attention_amd.utils import shared_state as state
+        seen["n"] += 1
+        return state.sub_iteration == 2
+    monkeypatch.setattr(GuidedAttention, "_loss_is_zero", staticmethod(zero_at_second))
+    pipe.speculative_refinement = False
+    base, _ = run_product(pipe, meta, embeds, lat0, noise, thr, use_graphs=True)
+    pipe.speculative_refinement, pipe.discarded_speculations = True, 0
+    out, _ = run_product(pipe, meta, embeds, lat0, noise, thr, use_graphs=True)
+    assert pipe.discarded_speculations == 3 and seen["n"] > 40          # once per refinement call (3 recurse passes at step 0)
+    assert base.unet_calls["bwd"] == meta["bwd"] - 3                     # the forced zero really skipped an update
+    assert {k: out.unet_calls[k] for k in MAIN_CALLS} == {k: base.unet_calls[k] for k in MAIN_CALLS}
+    err = (out.latents - base.latents).abs().max().item() / base.latents.abs().max().item()
+    assert err < 2e-4, err
 
 
 def test_attention_maps_match_oracle_fp16():
