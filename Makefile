@@ -21,7 +21,14 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/ga_hip.h
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--no-undefined -o $@ $(OBJS)
 
-clean:
-	rm -f $(OBJS) $(LIB)
+# Diagnostic library (never the product): linear.hip with in-kernel clock stamps at its phase boundaries, the other objects as
+# they are — tools/micro/lin_stamps.py loads it through GA_HIP_LIB.
+STAMPLIB := tools/micro/libga_stamps.so
+stamps: $(OBJS)
+	$(HIPCC) $(HIPFLAGS) -DGA_LIN_STAMPS -c $(CSRC)/linear.hip -o tools/micro/linear_stamps.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--no-undefined -o $(STAMPLIB) $(filter-out $(CSRC)/linear.o,$(OBJS)) tools/micro/linear_stamps.o
 
-.PHONY: all clean
+clean:
+	rm -f $(OBJS) $(LIB) $(STAMPLIB) tools/micro/linear_stamps.o
+
+.PHONY: all clean stamps

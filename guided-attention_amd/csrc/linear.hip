@@ -139,6 +139,42 @@ __device__ __forceinline__ void wait_lgkmcnt() {
 #endif
 }
 
+// ---- diagnostic build only (make stamps -> tools/micro/libga_stamps.so, tools/micro/lin_stamps.py): wave 0 of every workgroup
+// reads the shader clock at the phase boundaries of linear_kernel and leaves the values in a buffer of their own.  No stamp
+// executes in the product library (the macro is never defined there).
+#if defined(GA_LIN_STAMPS)
+__device__ unsigned long long* g_lin_stamps = nullptr;   // [workgroup][10]
+struct LinStamps {
+  unsigned long long t[10];
+  __device__ __forceinline__ void at(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long v;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    t[i] = v;
+#endif
+  }
+  __device__ __forceinline__ void real(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long v;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    t[i] = v;
+#endif
+  }
+  __device__ __forceinline__ void flush() {
+    if (threadIdx.x == 0 && g_lin_stamps != nullptr)
+      for (int i = 0; i < 10; ++i) g_lin_stamps[(size_t)blockIdx.x * 10 + i] = t[i];
+  }
+};
+#define GA_STAMP(st, i) (st).at(i)
+#else
+struct LinStamps {};
+#define GA_STAMP(st, i) ((void)0)
+#endif
+
 // gelu(g) = g/2 (1 + erf(g / sqrt 2)); erff() made the epilogue longer than the tile's matrix work (the 12288 x 320 x 2560
 // call: 58 us with erff).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -231,7 +267,8 @@ struct LinPrefetch {
 template <typename T, int BM, int BN, bool GEGLU, bool LN>
 __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T* Cs, T* __restrict__ Y, const LinArgs& a,
                                              const LinPtrs& p, int m0, int n0, int nt, const float (&ln_mean)[BM / 64],
-                                             const float (&ln_rstd)[BM / 64], const LinPrefetch<T, BM, BN, GEGLU, LN>& pre) {
+                                             const float (&ln_rstd)[BM / 64], const LinPrefetch<T, BM, BN, GEGLU, LN>& pre,
+                                             LinStamps& st) {
   constexpr int WM = BM / 2, WN = BN / 2, IM = WM / 32, JN = WN / 32;
   constexpr int LDC = BN + 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -273,6 +310,7 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
     }
   }
   __syncthreads();
+  GA_STAMP(st, 5);
   constexpr int OUTC = GEGLU ? BN / 2 : BN;       // columns of Y this tile writes
   constexpr int VPR = OUTC / 8;                   // 16-byte vectors per output row
   constexpr int NV = BM * VPR / kThreads;
@@ -338,6 +376,11 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 80 * 1024 ? 2
     const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ Y, int h_M, int h_ldx, unsigned h_kn, int h_tm,
     unsigned h_tn_splits, unsigned h_steps, unsigned h_dtm_m, unsigned h_dtn_m, LinArgs a_in, LinPtrs p) {
   const LinHead h{h_M, h_ldx, h_kn, h_tm, h_tn_splits, h_steps, h_dtm_m, h_dtn_m};
+  LinStamps st;
+#if defined(GA_LIN_STAMPS)
+  st.real(8);
+#endif
+  GA_STAMP(st, 0);
   // Everything in front of the first operand load comes from `X, W, Y, h`: 14 dwords of scalar arguments that the hardware
   // PRELOADS into SGPRs at wave launch (-amdgpu-kernarg-preload-count, Makefile) — the kernel's first instructions used to
   // be three dependent scalar loads of the argument block (one cache miss, two hits) in front of the tile mapping.  The
@@ -470,6 +513,7 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 80 * 1024 ? 2
     }
   }
 
+  GA_STAMP(st, 1);
   for (int it = 0; it < nsteps; ++it) {
     // my loads of step `it` have landed when at most the younger steps' instructions are outstanding
     const int younger = min(nsteps - 1 - it, PRE - 1);
@@ -478,6 +522,9 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 80 * 1024 ? 2
     else if (younger == 1) wait_vmcnt<IPS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's part of step `it` is in LDS; everyone is done reading step it - 1
+#if defined(GA_LIN_STAMPS)
+    if (it == 0) st.at(2);
+#endif
     if (it + PRE < nsteps) issue(it + PRE, (it + PRE) % NSTAGE);   // refills the slot step it - 1 occupied
     const unsigned slot_off = (unsigned)((it % NSTAGE) * kStage * (int)sizeof(T));
     // fragments of sub-step kk + 1 are requested before the MFMAs of kk; LDS returns in order, so "all but the reads just
@@ -511,6 +558,7 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 80 * 1024 ? 2
   static_assert(NSTAGE >= 2 && NSTAGE <= 5, "the counted waits above cover up to four k-steps in flight");
   wait_lgkmcnt<0>();
   __builtin_amdgcn_s_barrier();   // every wave's fragment reads are done: the ring memory is free for the epilogue
+  GA_STAMP(st, 3);
 
   // ---- split-K: publish, take a ticket; only the last slice of a tile goes on
   if (a.splits > 1) {
@@ -588,7 +636,15 @@ __global__ __launch_bounds__(kThreads, (BM + BN) * 128 * NSTAGE <= 80 * 1024 ? 2
     ln_m[i] = LN ? ln_mean[i] : 0.f;
     ln_r[i] = LN ? ln_rstd[i] : 1.f;
   }
-  lin_epilogue<T, BM, BN, GEGLU, LN>(acc, lds, Y, a, p, m0, n0, nt, ln_m, ln_r, pre);
+  GA_STAMP(st, 4);
+  lin_epilogue<T, BM, BN, GEGLU, LN>(acc, lds, Y, a, p, m0, n0, nt, ln_m, ln_r, pre, st);
+#if defined(GA_LIN_STAMPS)
+  st.at(6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  st.at(7);
+  st.real(9);
+  st.flush();
+#endif
 }
 
 template <typename T, int BM, int BN, int NSTAGE>
@@ -656,6 +712,13 @@ int lin_t(const void* X, const void* W, void* Y, const LinArgs& a, const LinPtrs
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+#if defined(GA_LIN_STAMPS)
+extern "C" int ga_lin_set_stamps(void* buffer) {   // [workgroups of the largest launch][10] u64, or NULL
+  unsigned long long* p = static_cast<unsigned long long*>(buffer);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_lin_stamps), &p, sizeof(p)) == hipSuccess ? GA_OK : GA_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int ga_linear_workspace(int64_t M, int N, int bm, int bn, int splits, int geglu, long long* slab_floats, int* tiles) {
   if (!slab_floats || !tiles) return GA_ERR_NULL;

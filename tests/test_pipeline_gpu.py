@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from types import SimpleNamespace
+
 import hashrand
 from conftest import load_json, load_npz
 from oracle import loss as oloss
@@ -143,11 +145,15 @@ def wide_setup(meta):
 
 # measured on the MI355X (the [measured] line): eager f16 5.7e-3 (rms 5.3e-3), bf16 4.8e-2 (rms 4.1e-2) in round 3; the graphs
 # rows (round 4) are the path bench.py times — hipGraph replay, the batch-3 joint pass, own Linear / convolution kernels
+_HALF_ORACLE = {}   # mode -> (setup, oracle latents, oracle call counters): one CPU oracle run (~28 s) serves both dtypes
+
+
 @pytest.mark.parametrize("mode", ["eager", "graphs"])
-@pytest.mark.parametrize("dt,tol", [("f16", 1.5e-2), ("bf16", 1.0e-1)])
+@pytest.mark.parametrize("dt,tol", [("f16", 1.25e-2), ("bf16", 1.0e-1)])
 def test_half_precision_pipeline_vs_oracle(dt, tol, mode):
     """The fast dtypes against the fp32 CPU oracle, case without threshold-driven branching near the limit
     (thresholds chosen so both sides take the same branches).  Stated tolerance: max |dlatent| / max |latent|.
+    Measured (round 4, MI355X): f16 eager 5.0e-3 / graphs 4.6e-3, bf16 eager 4.6e-2 / graphs 3.6e-2 (rms within 10 % of max).
     "eager": the g9 UNet, two passes per step.  "graphs": `use_graphs=True` with the batch-3 joint pass of the loss-only steps
     on a UNet whose widths are multiples of 64, i.e. the benched launch path — hipGraph replay of g_eval / g_grad / g_cfg /
     g_joint on ga_linear_fused and ga_conv3x3_nhwc at every level (asserted from the launch census) — after 4 denoising steps
@@ -158,13 +164,18 @@ def test_half_precision_pipeline_vs_oracle(dt, tol, mode):
     differences are common-mode (rms ~ max), not isolated spikes."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    meta = dict(G9[2], steps=4)
-    unet, embeds, lat0, noise, thr = (wide_setup if mode == "graphs" else g9_setup)(meta)
-    plan = oloss.TokenPlan(BASE_ENTRIES, meta["hyper"])
-    s = GuidedSampler(unet, plan, thresholds=thr, only_update_on_threshold_steps=meta["only_update_on_threshold_steps"],
-                      max_iter_to_alter=meta["max_iter_to_alter"], steps=meta["steps"], scale_factor=meta["scale_factor"])
-    ref = s.sample(lat0, embeds, noise).numpy()
     import copy
+    meta = dict(G9[2], steps=4)
+    if mode not in _HALF_ORACLE:
+        setup = (wide_setup if mode == "graphs" else g9_setup)(meta)
+        unet, embeds, lat0, noise, thr = setup
+        product_unet = copy.deepcopy(unet)          # before the oracle installs its processors
+        plan = oloss.TokenPlan(BASE_ENTRIES, meta["hyper"])
+        smp = GuidedSampler(unet, plan, thresholds=thr, only_update_on_threshold_steps=meta["only_update_on_threshold_steps"],
+                            max_iter_to_alter=meta["max_iter_to_alter"], steps=meta["steps"], scale_factor=meta["scale_factor"])
+        _HALF_ORACLE[mode] = ((product_unet,) + setup[1:], smp.sample(lat0, embeds, noise).numpy(), dict(smp.calls))
+    (unet, embeds, lat0, noise, thr), ref, calls = _HALF_ORACLE[mode]
+    s = SimpleNamespace(calls=calls)
     pipe = build_product(copy.deepcopy(unet), {"f16": torch.float16, "bf16": torch.bfloat16}[dt])
     flags = dict(use_graphs=True, batch_loss_only_guidance=True) if mode == "graphs" else {}
     out, _ = run_product(pipe, meta, embeds, lat0, noise, thr, **flags)
@@ -336,8 +347,10 @@ def test_pipeline_with_only_a_custom_loss():
     assert (out.latents - plain.latents).abs().max() > 1e-4  # the custom loss moved the latents
 
 
-# measured on the MI355X (the [measured] line): f32 maps 1e-6-class, grad < 3e-3; f16: see the line (round 4; bounds <= 2.5x)
-@pytest.mark.parametrize("dt,tol_maps,tol_loss,tol_grad", [("f32", 1e-4, 1e-4, 3e-3), ("f16", 1e-2, 5e-3, 1e-1)])
+# measured on the MI355X (round 4, the [measured] line): f32 maps 1.6e-6, loss 7.9e-8, grad 2.0e-6, cosine 1.00000;
+# f16 maps 1.6e-3, loss 5.7e-6, grad max-rel 5.7e-3, cosine 0.99993 — bounds <= 2.5x those, except the loss: its error is a
+# cancellation residue (box masses of a 24x24 mean whose per-pixel errors average out), a random draw of that size: 4x
+@pytest.mark.parametrize("dt,tol_maps,tol_loss,tol_grad", [("f32", 4e-6, 1e-6, 5e-6), ("f16", 4e-3, 2.5e-5, 1.4e-2)])
 def test_sd21_768_shapes_one_guidance_step(dt, tol_maps, tol_loss, tol_grad):
     """BASELINE config 4 shapes (no reference oracle exists: the reference hard-codes 16): SD-2.1 layout
     (linear projections, per-level head counts with head_dim 64, EOT-normalised text slice), 768^2 -> latent 96^2,
@@ -400,7 +413,7 @@ def test_sd21_768_shapes_one_guidance_step(dt, tol_maps, tol_loss, tol_grad):
     assert e_maps < tol_maps and e_loss < tol_loss, (e_maps, e_loss)
     np.testing.assert_allclose(terms[:, 5].cpu().numpy(), [float(v) for v in r["token_loss"]], rtol=2e-4 if dt == "f32" else 2e-2,
                                atol=1e-6 if dt == "f32" else 1e-4)
-    assert err < tol_grad and cos > (0.9999 if dt == "f32" else 0.995), (err, cos)
+    assert err < tol_grad and cos > (0.99999 if dt == "f32" else 0.9995), (err, cos)
 
 
 def test_execute_reuses_graphs_across_seeds_and_survives_eager_images(tmp_path):
@@ -558,48 +571,6 @@ def test_paint_with_words_pipeline_vs_oracle():
     assert err < 5e-3, err
 
 
-@pytest.mark.parametrize("batch", [1, 2, 3])   # 2 = the CFG pass: no measured plans, the rule of ga_conv3x3_plan
-def test_full_width_unet_own_convolutions_match_the_library(batch):
-    """The SD-1.x UNet at FULL width in fp16: one guidance-style forward + backward to the latents with the 3x3
-    convolutions on ga_conv3x3_nhwc (every real shape: measured plans, XCD-aware order, patch and per-tap variants,
-    split-K, bias + residual epilogue, the flipped pack in the backward) against the same UNet on the library
-    convolution.  Both accumulate in f32 and round once per layer: the results agree to fp16 rounding noise."""
-    from guided_attention_amd import ops
-    from guided_attention_amd.pipeline_guided_attention import GuidedAttention
-    from guided_attention_amd.unet import UNet2DConditionModel, UNetConfig
-    torch.manual_seed(0)
-    with torch.device("cuda"):
-        unet = UNet2DConditionModel(UNetConfig.sd15())
-    unet = unet.half().init_weights_(seed=11)
-    pipe = GuidedAttention(unet).to("cuda", torch.float16)
-    g = torch.Generator().manual_seed(5)
-    lat = torch.randn(batch, 4, 64, 64, generator=g).cuda().half()
-    ctx = torch.randn(batch, 77, 768, generator=g).cuda().half()
-    wgt = torch.randn(batch, 4, 64, 64, generator=g).cuda().half()
-
-    def run_once():
-        x = lat.clone().requires_grad_(True)
-        y = pipe.unet(x, 981, encoder_hidden_states=ctx).sample
-        (gx,) = torch.autograd.grad((y.float() * wgt.float()).sum(), [x])
-        return y.detach().float(), gx.float()
-
-    with ops.census_scope() as cs:
-        y_own, g_own = run_once()
-    assert sum(n for k, n in cs.launches.items() if k[0] == "conv3x3") > 80      # the HIP convolution really ran
-    pipe.unet.set_fused_impl(ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm), None)
-    bench_mode, torch.backends.cudnn.benchmark = torch.backends.cudnn.benchmark, False   # no exhaustive library search here
-    try:
-        with ops.census_scope() as cs:
-            y_lib, g_lib = run_once()
-    finally:
-        torch.backends.cudnn.benchmark = bench_mode
-    assert not any(k[0] == "conv3x3" for k in cs.launches)
-    assert torch.isfinite(y_own).all() and torch.isfinite(g_own).all()
-    ey = float((y_own - y_lib).abs().max() / y_lib.abs().max())
-    eg = float((g_own - g_lib).abs().max() / g_lib.abs().max())
-    assert ey < 2e-2 and eg < 5e-2, (ey, eg)
-
-
 @pytest.fixture(scope="module")
 def full_width():
     """The configuration bench.py times, built ONCE for the tests below: the full-width SD-1.x UNet (`UNetConfig.sd15()`, 860 M
@@ -675,7 +646,54 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max())
 
 
-# measured on the MI355X (round 4, the [measured] line; the bounds below are <= 2.5x these):
+@pytest.mark.parametrize("batch", [1, 2, 3])   # 2 = the CFG pass: no measured plans, the rule of ga_conv3x3_plan
+def test_full_width_unet_own_kernels_match_the_library(full_width, batch):
+    """The SD-1.x UNet at FULL width in fp16 (the shared full-width pipeline): one guidance-style forward + backward to the
+    latents with the 3x3 convolutions on ga_conv3x3_nhwc (every real shape: measured plans, XCD-aware order, patch and per-tap
+    variants, split-K, bias + residual epilogue, the flipped pack in the backward), the transformer blocks on ga_linear_fused and
+    the UpBlock concatenations on ga_cat_channels, against the SAME UNet with all three back on the library (MIOpen, hipBLASLt +
+    the separate LayerNorm / GEGLU / add kernels, torch.cat).  Both accumulate in f32 and round once per layer: the results
+    agree to fp16 rounding noise."""
+    from guided_attention_amd import fused_linear, ops
+    pipe = full_width.pipe
+    pipe._runner = None
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(batch, 4, 64, 64, generator=g).cuda().half()
+    ctx = torch.randn(batch, 77, 768, generator=g).cuda().half()
+    wgt = torch.randn(batch, 4, 64, 64, generator=g).cuda().half()
+
+    def run_once():
+        x = lat.clone().requires_grad_(True)
+        y = pipe.unet(x, 981, encoder_hidden_states=ctx).sample
+        (gx,) = torch.autograd.grad((y.float() * wgt.float()).sum(), [x])
+        return y.detach().float(), gx.float()
+
+    with ops.census_scope() as cs:
+        y_own, g_own = run_once()
+    assert sum(n for k, n in cs.launches.items() if k[0] == "conv3x3") > 80      # the HIP convolution really ran
+    assert sum(n for k, n in cs.launches.items() if k[0] == "linear") > 100      # and the fused Linear layers
+    elementwise = (ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm))
+    pipe.unet.set_fused_impl(*elementwise, None)
+    bench_mode, torch.backends.cudnn.benchmark = torch.backends.cudnn.benchmark, False   # no exhaustive library search here
+    try:
+        with ops.census_scope() as cs:
+            y_lib, g_lib = run_once()
+    finally:
+        torch.backends.cudnn.benchmark = bench_mode
+        pipe.unet.set_fused_impl(*elementwise, ops.conv3x3, fused_linear, ops.cat_channels)
+    assert not any(k[0] in ("conv3x3", "linear") for k in cs.launches)
+    assert torch.isfinite(y_own).all() and torch.isfinite(g_own).all()
+    ey = float((y_own - y_lib).abs().max() / y_lib.abs().max())
+    eg = float((g_own - g_lib).abs().max() / g_lib.abs().max())
+    print(f"[measured] full width own kernels vs library, batch {batch}: noise prediction {ey:.3e} latent gradient {eg:.3e}")
+    assert ey < 2e-2 and eg < 5e-2, (ey, eg)
+
+
+# measured on the MI355X (round 4, the [measured] line, eager == graphs to every printed digit): maps 2.2e-3, aggregate 8.2e-4,
+# loss 3.2e-6, latent gradient max-rel 1.03e-2 with cosine 0.99944, updated latents 5.2e-4.  The bounds below are <= 2.5x
+# these (round 3 carried 3e-2 / 1e-2 / 2e-2 / 1.5e-1 / 2e-3 without a measurement), except the loss (6x): its error is a
+# cancellation residue — O(1) box masses of a 40-map mean whose per-pixel errors average out — i.e. a random draw of order
+# 1e-5 that moves with the last bit of any library kernel upstream, not a systematic deviation.
 @pytest.mark.parametrize("graphs", [False, True], ids=["eager", "graphs"])
 def test_full_width_guidance_evaluation_vs_oracle_fp16(full_width, graphs):
     """ONE guidance evaluation in fp16 through the product path at the REAL width — capture kernels, aggregate, smoothed box
@@ -683,10 +701,10 @@ def test_full_width_guidance_evaluation_vs_oracle_fp16(full_width, graphs):
     prompt embedding (reference: pipeline_guided_attention.py:946-973, 456-470).
 
     Stated fp16 tolerances (max |difference| / max |oracle value| unless said otherwise), with the error budget behind
-    each: a stored 16x16 cross map passes through up to ~60 fp16-rounded layers (rel. 2^-11 each, random signs) before
-    its softmax: 3e-2; their 40-map mean: 1e-2; the loss is a sum of O(1) box masses of that mean: 2e-2 relative; the
-    latent gradient additionally runs the whole backward in fp16 (loss gradients ~1e-5 carried under power-of-two
-    scales); the updated latents are x - 20 g with |20 g| << |x|: 2e-3."""
+    each: a stored 16x16 cross map passes through up to ~60 fp16-rounded layers (rel. 2^-11 = 4.9e-4 each, random signs:
+    ~sqrt(60) x 2^-12 = 1e-3 before its softmax): 5e-3; their 40-map mean: 2e-3; the loss is a sum of O(1) box masses of that
+    mean: 2e-5 relative; the latent gradient additionally runs the whole backward in fp16 (loss gradients ~1e-5 carried under
+    power-of-two scales): 2.5e-2 of its maximum, cosine > 0.998; the updated latents are x - 20 g with |20 g| << |x|: 1.3e-3."""
     from guided_attention_amd.utils import ptp_utils
     fw, pipe = full_width, full_width.pipe
     ctrl = _activate_full_width(fw, graphs)
@@ -715,9 +733,9 @@ def test_full_width_guidance_evaluation_vs_oracle_fp16(full_width, graphs):
     cos = float((grad * fw.g_ref).sum() / (grad.norm() * fw.g_ref.norm()))
     print(f"[measured] full width {'graphs' if graphs else 'eager'} fp16 vs fp32 oracle: maps {e_map:.3e} aggregate {e_A:.3e} "
           f"loss {e_loss:.3e} grad max-rel {e_grad:.3e} cosine {cos:.5f} updated latents {e_lat:.3e}")
-    assert e_map < 3e-2 and e_A < 1e-2 and e_loss < 2e-2, (e_map, e_A, e_loss)
-    assert e_grad < 1.5e-1 and cos > 0.99, (e_grad, cos)
-    assert e_lat < 2e-3, e_lat
+    assert e_map < 5e-3 and e_A < 2e-3 and e_loss < 2e-5, (e_map, e_A, e_loss)
+    assert e_grad < 2.5e-2 and cos > 0.998, (e_grad, cos)
+    assert e_lat < 1.3e-3, e_lat
 
 
 def test_full_width_joint_pass_and_ddim_step_vs_oracle_fp16(full_width):
@@ -726,8 +744,10 @@ def test_full_width_joint_pass_and_ddim_step_vs_oracle_fp16(full_width):
     `ga_cfg_ddim_step` on its noise prediction — eps_uncond, eps_cond, the logged loss and x_prev against the fp32 CPU oracle
     (reference: pipeline_guided_attention.py:1010-1029; the guidance evaluation :946-973 whose loss such a step only logs).
     Also: the separate B=2 CFG graph (`g_cfg`) gives the same noise prediction as samples 1-2 of the joint pass.
-    Budget: the noise prediction is ~60 fp16-rounded layers deep: 2e-2 of its maximum; the CFG combine amplifies the
-    cond - uncond difference by 7.5, x_prev = c1 x + c2 eps with |c2| ~ 0.03 at t = 981: 2e-3 of max |x_prev|."""
+    Measured (round 4, MI355X): eps_uncond 1.7e-3, eps_cond 2.0e-3, loss 7.8e-6, x_prev 8.4e-4, B=2 graph vs joint samples
+    1.4e-3; bounds <= 2.5x (the loss: see the test above).  Budget: the noise prediction is ~60 fp16-rounded layers deep
+    (~sqrt(60) x 2^-12 per element, a few times that at the maximum): 5e-3 of its maximum; the CFG combine amplifies the
+    cond - uncond difference by 7.5 and x_prev = c1 x + c2 eps with |c2| ~ 0.03 at t = 981: 2e-3 of max |x_prev|."""
     from guided_attention_amd import ops
     from guided_attention_amd.scheduler import DDIMScheduler
     fw, pipe = full_width, full_width.pipe
@@ -758,7 +778,7 @@ def test_full_width_joint_pass_and_ddim_step_vs_oracle_fp16(full_width):
     e_two = _rel(noise_cfg.float().cpu(), noise.float().cpu())
     print(f"[measured] full width joint step fp16 vs fp32 oracle: eps_uncond {e_u:.3e} eps_cond {e_c:.3e} loss {e_loss:.3e} "
           f"x_prev {e_x:.3e}; B=2 CFG graph vs joint samples 1-2 {e_two:.3e}")
-    assert e_u < 2e-2 and e_c < 2e-2, (e_u, e_c)
-    assert e_loss < 2e-2, e_loss
+    assert e_u < 5e-3 and e_c < 5e-3, (e_u, e_c)
+    assert e_loss < 2e-5, e_loss
     assert e_x < 2e-3, e_x
-    assert e_two < 1e-2, e_two            # different batch -> different tiles / split-K plans: fp16 rounding noise only
+    assert e_two < 3.5e-3, e_two          # different batch -> different tiles / split-K plans: fp16 rounding noise only

@@ -96,8 +96,11 @@ print("survived", case, float(y.abs().sum()) > 0)
 def main():
     for case in ("control", "tensors", "graph", "runner"):
         r = subprocess.run([sys.executable, "-c", CHILD, case], capture_output=True, text=True, timeout=300)
-        tail = (r.stderr.strip().splitlines() or [""])[-1][:200]
-        print(f"{case:8s} exit {r.returncode:4d}  {'survived' if r.returncode == 0 else 'DIED'}  {r.stdout.strip()[-60:]}  {tail}", flush=True)
+        lines = r.stderr.strip().splitlines()
+        why = [ln.strip()[:220] for ln in lines if any(k in ln for k in ("what()", "rror", "HIP", "hip", "capture"))][:4]
+        print(f"{case:8s} exit {r.returncode:4d}  {'survived' if r.returncode == 0 else 'DIED'}  {r.stdout.strip()[-60:]}", flush=True)
+        for ln in (why if r.returncode != 0 else []):
+            print(f"         | {ln}", flush=True)
 
 
 if __name__ == "__main__":
