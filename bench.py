@@ -53,6 +53,8 @@ def parse(argv=None):
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying hipGraphs")
     ap.add_argument("--no-joint-pass", action="store_true",
                     help="run the loss-only guidance forward and the CFG pair as two passes (B=1, B=2) instead of one B=3 pass")
+    ap.add_argument("--miopen-search", action="store_true",
+                    help="A/B only: MIOpen's exhaustive solver search (cudnn.benchmark) for the few convolutions left on the library")
     ap.add_argument("--no-run-ahead", action="store_true",
                     help="refinement loop reads each loss table back before it enqueues the backward / update / next evaluation")
     ap.add_argument("--two-pass-steps", type=int, default=1,
@@ -182,6 +184,8 @@ def build_pipeline(args, device, rank, world):
     pipe.use_graphs = not args.eager
     pipe.batch_loss_only_guidance = not args.no_joint_pass
     pipe.speculative_refinement = not args.no_run_ahead
+    if args.miopen_search:
+        torch.backends.cudnn.benchmark = True
     return pipe, cfg, {"messages": n_msgs, "seconds": round(bcast_s, 4), "bytes": nbytes,
                        "timed": "between two barriers" if world > 1 else "single rank: no collective"}
 

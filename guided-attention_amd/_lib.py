@@ -13,8 +13,9 @@ import torch
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("GA_HIP_LIB", _HERE / "libga_hip.so"))
 
-GA_VERSION = 130   # the GA_VERSION of include/ga_hip.h these prototypes were written for (tests/test_abi.py compares the two)
+GA_VERSION = 140   # the GA_VERSION of include/ga_hip.h these prototypes were written for (tests/test_abi.py compares the two)
 GA_F16, GA_BF16, GA_F32 = 0, 1, 2
+GA_LINEAR_STREAM = 8   # `stages` of ga_linear_fused: the persistent one-workgroup-per-CU form (include/ga_hip.h)
 GA_TOK_COOR, GA_TOK_BOX = 0, 1
 GA_TERMS = 8
 DTYPE_CODE = {torch.float16: GA_F16, torch.bfloat16: GA_BF16, torch.float32: GA_F32}

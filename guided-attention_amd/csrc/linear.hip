@@ -709,6 +709,354 @@ int lin_t(const void* X, const void* W, void* Y, const LinArgs& a, const LinPtrs
   return GA_ERR_SHAPE;
 }
 
+// =====================================================================================================================
+// linear_stream_kernel — the same contraction, LayerNorm folded in front [+ GEGLU], for launches with MANY output tiles (the
+// feed-forward and QKV / to_q GEMMs of the batch-3 and batch-2 passes: 300 - 1900 tiles of 128 x 128) as ONE persistent
+// 512-thread workgroup per CU.  What the clock stamps of linear_kernel showed on these shapes (tools/micro/lin_stamps.py,
+// profiles/r4_linear_stamps_before.txt; 12288 x 320 x 2560 + GEGLU, 9.8 us per tile, two tiles per CU at a time): a third is
+// prologue (tile map, addresses, LayerNorm statistics, the first operand round trip), a third the five k-steps (ONE step in
+// flight in the 2-slot ring that fits twice per CU: every step pays a memory round trip; 8 LDS-DMA pieces per wave and step
+// cost more issue time than the step's 16 MFMAs), a third the epilogue (GEGLU through 16-bit LDS images).  Here:
+//  * one workgroup per CU takes the LDS: a 4-slot ring (3 k-steps = 96 KB in flight) that keeps STREAMING ACROSS TILE BOUNDARIES
+//    — while a tile's epilogue runs, the next tile's first steps are landing; per-tile set-up is a few address computations;
+//  * 8 waves (2 per SIMD), each 32 tokens x 64 columns: 4 LDS-DMA pieces per wave and step instead of 8, and a partner wave's
+//    MFMAs under every wave's DMA issue and epilogue arithmetic;
+//  * GEGLU in registers: a wave owns 32 h columns AND their 32 gate columns, so h * gelu(gate) is formed from the f32
+//    accumulators (the projection is never rounded to 16 bits in between; half the staging traffic);
+//  * EVERY memory operation of the loop is an LDS-DMA (operands, and per tile: the LayerNorm shift / colsum of its columns, the
+//    rows' partial sums), every LDS access inline asm: vmcnt retires in order, so one ordinary load waited for inside the loop
+//    would drain the ring (and hipcc waits vmcnt(0) in front of any LDS access it can see while an LDS-DMA is pending).  The
+//    per-tile constants are requested when the tile's FIRST k-step is consumed and read >= 3 steps later: the ring's own counted
+//    waits have covered them by then.
+// Serves: LayerNorm fold (always), optional GEGLU, no bias / residual / split-K / pre-activation copy / statistics output — the
+// no-grad passes' forms; K >= 320 (five k-steps: see the waits), 2 <= partial sums per row <= 20.
+constexpr int kSThreads = 512;
+constexpr int kSStage = 256 * kBK * 2;                 // bytes of one ring slot: 128 token rows + 128 weight rows of 128 bytes
+constexpr int kSNst = 4, kSPre = kSNst - 1;
+constexpr int kSOutStride = 144;                       // staging row: 64 outputs + one 16-byte vector (8-byte writes of 16
+                                                       // consecutive rows and 16-byte reads fall on distinct banks)
+constexpr int kSPartsMax = 20;
+constexpr int kSStageOff = kSNst * kSStage;            // output staging, overlaid by the rows' LayerNorm partial sums
+constexpr int kSStageBytes = 128 * 16 * (kSPartsMax / 2);   // 20480 >= 128 * kSOutStride
+constexpr int kSCstOff = kSStageOff + kSStageBytes;    // shift[128] | colsum[128] of the tile's columns (f32)
+constexpr int kSStatOff = kSCstOff + 1024;             // (mean, rstd)[128] of the tile's rows
+constexpr int kSLds = kSStatOff + 1024;
+static_assert(128 * kSOutStride <= kSStageBytes && kSLds <= 160 * 1024, "LDS map of linear_stream_kernel");
+
+__device__ __forceinline__ void lds_read64(f32x2& dst, unsigned byte_address) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(byte_address) : "memory");
+#else
+  dst = f32x2{(float)byte_address, 0.f};
+#endif
+}
+__device__ __forceinline__ void lds_read128f(f32x4& dst, unsigned byte_address) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(byte_address) : "memory");
+#else
+  dst = f32x4{(float)byte_address, 0.f, 0.f, 0.f};
+#endif
+}
+__device__ __forceinline__ void lds_write64(unsigned byte_address, f32x2 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_write_b64 %0, %1" ::"v"(byte_address), "v"(v) : "memory");
+#endif
+}
+
+template <typename T>
+__device__ __forceinline__ f32x2 pack4(float a, float b, float c, float d) {   // four results as 8 bytes of T
+  typename Traits<T>::frag f;
+  f[0] = Traits<T>::from_f32(a);
+  f[1] = Traits<T>::from_f32(b);
+  f[2] = Traits<T>::from_f32(c);
+  f[3] = Traits<T>::from_f32(d);
+  return __builtin_bit_cast(f32x2, f);
+}
+
+template <typename T, bool GEGLU>
+__global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
+    const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ Y, int h_M, int h_ldx, unsigned h_kn, int h_tm,
+    unsigned h_tn_splits, unsigned h_steps, unsigned h_dtm_m, unsigned h_dtn_m, LinArgs a_in, LinPtrs p) {
+  // the 14 preloaded scalar dwords of linear_kernel; `splits` carries the grid size (one workgroup per CU)
+  const int M = h_M, ldx = h_ldx, K = (int)(h_kn & 0xffffu), N = (int)(h_kn >> 16);
+  const int tm = h_tm, tn = (int)(h_tn_splits & 0xffffu), G = (int)(h_tn_splits >> 16);
+  const int steps = (int)(h_steps & 0xffffu);
+  const bool n_fastest = (h_steps >> 31) != 0;
+  const FastDiv d_tm{(unsigned)tm, h_dtm_m}, d_tn{(unsigned)tn, h_dtn_m};
+  const int F = GEGLU ? N / 2 : 0, n_out = GEGLU ? F : N;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[kSLds];   // the ONE LDS object of the kernel
+  const unsigned lds0 = (unsigned)(uintptr_t)GA_LDS_PTR(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  // ---- this workgroup's tiles: logical tile L = j * G + rb, rb = its place in an XCD-contiguous order of the G workgroups
+  // (workgroup ids equal mod 8 share an XCD: each XCD works on a contiguous run of every band of G tiles — shared operand panels
+  // meet in one L2)
+  const int total_tiles = tm * tn;
+  int rb;
+  {
+    const int q = G >> 3, r = G & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    rb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int my_tiles = rb < total_tiles ? (total_tiles - rb + G - 1) / G : 0;
+  const int total = my_tiles * steps;                       // k-steps this workgroup streams
+  auto tile_origin = [&](int j, int& m0, int& n0) {
+    const int L = j * G + rb;
+    int mt, nt;
+    if (n_fastest) {
+      mt = fdiv(L, d_tn);
+      nt = L - mt * tn;
+    } else {
+      nt = fdiv(L, d_tm);
+      mt = L - nt * tm;
+    }
+    m0 = mt * 128;
+    n0 = nt * (GEGLU ? 64 : 128);
+  };
+  // feature (row of W) behind tile column c (0 .. 127), clamped into the matrix: GEGLU tiles hold 64 h columns, then their gates
+  auto feature = [&](int n0, int c, int last) {
+    if (GEGLU) return c < 64 ? min(n0 + c, F - 1 - last) : F + min(n0 + c - 64, F - 1 - last);
+    return min(n0 + c, N - 1 - last);
+  };
+
+  // ---- operand stream: piece q of a wave fills rows 8 g .. 8 g + 7 of a slot, g = wave + 8 q (g < 16: tokens, else weights);
+  // lane l lands at row 8 g + (l >> 3), physical 16-byte column l & 7, and fetches logical column (l & 7) ^ swizzle(row)
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X), 0, (unsigned)(((M - 1) * ldx + K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W), 0, (unsigned)(N * K * 2), 0x00020000);
+  unsigned voff[4];
+  int ij = 0, ik = 0, gi = 0;                               // issue cursor: tile, k-step, steps issued
+  auto set_issue_tile = [&](int j) {
+    int m0, n0;
+    tile_origin(j, m0, n0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 8 * (wave + 8 * q) + (lane >> 3);
+      const int col = (lane & 7) ^ ((row >> 1) & 7);
+      if (q < 2) voff[q] = (unsigned)((min(m0 + row, M - 1) * ldx + 8 * col) * 2);
+      else voff[q] = (unsigned)((feature(n0, row - 128, 0) * K + 8 * col) * 2);
+    }
+  };
+  auto issue = [&]() {                                      // the next k-step of the stream into its ring slot
+    const unsigned koff = (unsigned)(ik * kBK * 2);
+    const int slot = gi & (kSNst - 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned char* dst = lds + slot * kSStage + (wave_u + 8 * q) * 1024;
+      if (q < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, GA_LDS_PTR(dst), 16, (int)voff[q], (int)koff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, GA_LDS_PTR(dst), 16, (int)voff[q], (int)koff, 0, 0);
+    }
+    ++gi;
+    if (++ik == steps) {
+      ik = 0;
+      if (++ij < my_tiles) set_issue_tile(ij);
+    }
+  };
+  // per-tile constants, by LDS-DMA with per-lane source addresses: wave 0 brings shift | colsum of the tile's 128 columns (one
+  // piece: lanes 0-31 shift, 32-63 colsum, four floats each), the partial sums of the 128 rows go out as pieces of 64 rows x
+  // two parts (a 16-byte load from an 8-byte aligned address), dealt over the waves.  With an odd part count the last piece
+  // starts one part early instead of reading past the row (the statistics below skip the part it repeats).
+  const int parts = a_in.ln_parts, chunks = (parts + 1) >> 1;
+  auto issue_constants = [&](int m0, int n0) {
+    if (wave_u == 0) {
+      const int c = 4 * (lane & 31);
+      const float* src = (lane < 32 ? p.ln_shift : p.ln_colsum) + feature(n0, c, 3);
+      __builtin_amdgcn_global_load_lds(src, GA_LDS_PTR(lds + kSCstOff), 16, 0, 0);
+    }
+    for (int pi = wave_u; pi < 2 * chunks; pi += 8) {
+      const int c = pi >> 1, rh = pi & 1;
+      const int m = min(m0 + 64 * rh + lane, M - 1);
+      const float* src = p.ln_partials + ((size_t)m * parts + min(2 * c, parts - 2)) * 2;
+      __builtin_amdgcn_global_load_lds(src, GA_LDS_PTR(lds + kSStageOff + (c * 128 + 64 * rh) * 16), 16, 0, 0);
+    }
+  };
+  // (mean, rstd) of the tile's rows from the partial sums, summed in part order (the order of linear_kernel: same bits)
+  auto row_statistics = [&]() {
+    if (tid < 128) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int c = 0; c < chunks; ++c) {
+        f32x4 v;
+        lds_read128f(v, lds0 + kSStageOff + (c * 128 + tid) * 16);
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool repeat = 2 * c + 1 >= parts;              // odd count, last piece: its first part was summed already
+        s1 += repeat ? 0.f : v[0];
+        s2 += repeat ? 0.f : v[1];
+        s1 += v[2];
+        s2 += v[3];
+      }
+      const float mean = s1 * a_in.ln_inv_k;
+      const float rstd = rsqrtf(fmaxf(s2 * a_in.ln_inv_k - mean * mean, 0.f) + a_in.ln_eps);
+      lds_write64(lds0 + kSStatOff + tid * 8, f32x2{mean, rstd});
+    }
+  };
+
+  // ---- fragment addresses inside slot 0 (see linear_kernel): tokens = B operand, weights = A operand
+  unsigned a_adr, a_sw, b_adr[2], b_sw[2];
+  {
+    const int row = wm * 32 + fr;
+    a_adr = lds0 + row * 128;
+    a_sw = (unsigned)(((row >> 1) & 7) ^ fh);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int wrow = 128 + j * 64 + wn * 32 + fr;
+      b_adr[j] = lds0 + wrow * 128;
+      b_sw[j] = (unsigned)(((wrow >> 1) & 7) ^ fh);
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  if (my_tiles > 0) set_issue_tile(0);
+#pragma unroll
+  for (int s = 0; s < kSPre; ++s)
+    if (gi < total) issue();
+  int cj = 0, ck = 0, m0c = 0, n0c = 0;                     // consume cursor
+  for (int g = 0; g < total; ++g) {
+    // my pieces of step g have landed when at most the younger steps' pieces are outstanding (the few constant pieces issued in
+    // between only make this wait for a little more than it needs)
+    const int younger = min(total - 1 - g, kSPre - 1);
+    if (younger >= 2) wait_vmcnt<8>();
+    else if (younger == 1) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // step g is in LDS for everyone; everyone is done with step g - 1 (and with the last epilogue)
+    if (ck == 0) {
+      tile_origin(cj, m0c, n0c);
+      issue_constants(m0c, n0c);
+    }
+    if (gi < total) issue();        // refills the slot step g - 1 occupied
+    if (ck == 3) row_statistics();  // the constants went out three steps ago, in front of a step this wave has now waited for
+    const unsigned slot_off = (unsigned)((g & (kSNst - 1)) * kSStage);
+    u32x4 fa[2], fb[2][2];
+    auto request = [&](int kk, int set) {
+      lds_read128(fa[set], a_adr + slot_off + 16u * ((2u * kk) ^ a_sw));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) lds_read128(fb[set][j], b_adr[j] + slot_off + 16u * ((2u * kk) ^ b_sw[j]));
+    };
+    request(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < kBK / 16; ++kk) {
+      if (kk + 1 < kBK / 16) {
+        request(kk + 1, (kk + 1) & 1);
+        wait_lgkmcnt<3>();
+      } else {
+        wait_lgkmcnt<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[j] = Mma32L<T>::run(__builtin_bit_cast(uint4, fb[kk & 1][j]), __builtin_bit_cast(uint4, fa[kk & 1]), acc[j]);
+    }
+    if (++ck < steps) continue;
+
+    // ---- epilogue of tile cj (the ring keeps landing the next tile meanwhile)
+    ck = 0;
+    ++cj;
+    f32x2 st;                                               // (mean, rstd) of this lane's token row
+    lds_read64(st, lds0 + kSStatOff + (wm * 32 + fr) * 8);
+    f32x4 sh[2][4], cs[2][4];                               // shift / colsum of this lane's columns: [h | gate or half][quad]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const unsigned c = (unsigned)(j * 64 + wn * 32 + 8 * qd + 4 * fh);
+        lds_read128f(sh[j][qd], lds0 + kSCstOff + 4u * c);
+        lds_read128f(cs[j][qd], lds0 + kSCstOff + 512u + 4u * c);
+      }
+    wait_lgkmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    const float mean = st[0], rstd = st[1];
+    const unsigned out_adr = lds0 + kSStageOff + (unsigned)((wm * 32 + fr) * kSOutStride + (wn * 32 + 4 * fh) * 2);
+    constexpr int PASSES = GEGLU ? 1 : 2;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+      if (pass > 0) {
+        __builtin_amdgcn_s_barrier();                       // the first half has left the staging rows
+      }
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (GEGLU) {
+            const float hv = rstd * (acc[0][4 * qd + r] - mean * cs[0][qd][r]) + sh[0][qd][r];
+            const float gv = rstd * (acc[1][4 * qd + r] - mean * cs[1][qd][r]) + sh[1][qd][r];
+            o[r] = gv;
+            acc[0][4 * qd + r] = hv;
+          } else {
+            o[r] = rstd * (acc[pass][4 * qd + r] - mean * cs[pass][qd][r]) + sh[pass][qd][r];
+          }
+        }
+        if constexpr (GEGLU) {
+          const f32x2 g01 = gelu_erf2(f32x2{o[0], o[1]}), g23 = gelu_erf2(f32x2{o[2], o[3]});
+          o[0] = acc[0][4 * qd] * g01.x;
+          o[1] = acc[0][4 * qd + 1] * g01.y;
+          o[2] = acc[0][4 * qd + 2] * g23.x;
+          o[3] = acc[0][4 * qd + 3] * g23.y;
+        }
+        lds_write64(out_adr + 16u * qd, pack4<T>(o[0], o[1], o[2], o[3]));
+      }
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int v = tid + k * kSThreads, r = v >> 3, cv = (v & 7) * 8;
+        u32x4 val;
+        lds_read128(val, lds0 + kSStageOff + (unsigned)(r * kSOutStride + cv * 2));
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        const int m = m0c + r, n = n0c + pass * 64 + cv;
+        if (m < M && n < n_out) *reinterpret_cast<u32x4*>(Y + (size_t)m * a_in.ldy + n) = val;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  }
+}
+
+template <typename T>
+int launch_stream(const T* X, const T* W, T* Y, LinArgs a, const LinPtrs& p, hipStream_t s) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+      return GA_ERR_LAUNCH;
+    cus = n;
+  }
+  const int outc = a.F ? 64 : 128, n_out = a.F ? a.F : a.N;
+  a.tm = (a.M + 127) / 128;
+  a.tn = (n_out + outc - 1) / outc;
+  a.steps = a.K / kBK;
+  const long long tiles = (long long)a.tm * a.tn;
+  if (tiles > 0x7fffffffLL / 256 || a.K > 0xffff || a.N > 0xffff || a.tn > 0xffff || a.steps > 0xffff) return GA_ERR_SHAPE;
+  const int G = tiles < cus ? (int)tiles : cus;
+  {
+    const double xb = (double)a.M * a.K, wb = (double)a.N * a.K;
+    const double m_first = wb + xb * (a.tn < 8 ? a.tn : 8), n_first = xb + wb * (a.tm < 8 ? a.tm : 8);
+    a.n_fastest = n_first < m_first ? 1 : 0;
+  }
+  bool ok = true;
+  const unsigned long long span = (unsigned long long)tiles + (unsigned long long)G;
+  a.d_tm = make_fastdiv(a.tm, span, ok);
+  a.d_tn = make_fastdiv(a.tn, span, ok);
+  if (!ok) return GA_ERR_SHAPE;
+  const LinHead h{a.M, a.ldx, (unsigned)a.K | ((unsigned)a.N << 16), a.tm, (unsigned)a.tn | ((unsigned)G << 16),
+                  (unsigned)a.steps | ((unsigned)(a.n_fastest != 0) << 31), a.d_tm.m, a.d_tn.m};
+  if (a.F)
+    hipLaunchKernelGGL((linear_stream_kernel<T, true>), dim3((unsigned)G), dim3(kSThreads), 0, s, X, W, Y, h.M, h.ldx, h.kn, h.tm,
+                       h.tn_splits, h.steps, h.dtm_m, h.dtn_m, a, p);
+  else
+    hipLaunchKernelGGL((linear_stream_kernel<T, false>), dim3((unsigned)G), dim3(kSThreads), 0, s, X, W, Y, h.M, h.ldx, h.kn, h.tm,
+                       h.tn_splits, h.steps, h.dtm_m, h.dtn_m, a, p);
+  return check_launch();
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -767,6 +1115,18 @@ extern "C" int ga_linear_fused(const void* X, int64_t ldx, const void* W, void* 
   p.ln_stats_out = ep->ln_stats_out; p.row_partials_out = ep->row_partials_out;
   p.slabs = slabs; p.tickets = tickets;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (stages == GA_LINEAR_STREAM) {
+    // the persistent one-workgroup-per-CU form (linear_stream_kernel): what it serves, it serves with the 128 x 128 tile only
+    if (bm != 128 || bn != 128 || splits != 1 || !ep->ln_partials || ep->bias || ep->residual || ep->preact || ep->ln_stats_out ||
+        ep->row_partials_out || K / kBK < 5 || ep->ln_parts < 2 || ep->ln_parts > kSPartsMax || ldy > 0x7fffffff)
+      return GA_ERR_UNSUPPORTED;
+    if ((long long)M * ep->ln_parts * 8 >= (1LL << 31)) return GA_ERR_SHAPE;
+    switch (dtype) {
+      case GA_F16: return launch_stream<_Float16>((const _Float16*)X, (const _Float16*)W, (_Float16*)Y, a, p, s);
+      case GA_BF16: return launch_stream<bf16_t>((const bf16_t*)X, (const bf16_t*)W, (bf16_t*)Y, a, p, s);
+      default: return GA_ERR_DTYPE;
+    }
+  }
   switch (dtype) {
     case GA_F16: return lin_t<_Float16>(X, W, Y, a, p, bm, bn, stages, s);
     case GA_BF16: return lin_t<bf16_t>(X, W, Y, a, p, bm, bn, stages, s);

@@ -1370,10 +1370,23 @@ def library_block(M, C):
     return bool(_measured_linear_plans().get((int(M), int(C), -1, -1), (0,))[0])
 
 
-def linear_plan(M, K, N, geglu=False):
-    """(bm, bn, splits) for Y[M][N or N/2] = X[M][K] W[N][K]^T: the measured table (tools/linear_tune.py) or a rule:
-    about one workgroup per CU and more; the depth is split when the tiles alone leave most of the chip idle."""
+LINEAR_STREAM = _lib.GA_LINEAR_STREAM     # `stages` value of the persistent one-workgroup-per-CU form (csrc/linear.hip)
+LINEAR_STREAM_PLAN = (128, 128, 1, LINEAR_STREAM)
+
+
+def linear_stream_serves(K, parts, ln, bias, residual, want_preact, want_ln_stats, want_row_partials):
+    """What linear_stream_kernel takes: the LayerNorm-folded no-grad forms (optionally GEGLU) at K >= 320."""
+    return (ln is not None and bias is None and residual is None and not want_preact and not want_ln_stats
+            and not want_row_partials and K // 64 >= 5 and 2 <= parts <= 20)
+
+
+def linear_plan(M, K, N, geglu=False, stream_ok=False):
+    """(bm, bn, splits[, stages]) for Y[M][N or N/2] = X[M][K] W[N][K]^T: the measured table (tools/linear_tune.py) or a rule:
+    about one workgroup per CU and more; the depth is split when the tiles alone leave most of the chip idle.  stream_ok: the
+    call is one linear_stream_kernel serves — the table's "M,K,N,geglu,8" entry says whether that form measured faster."""
     key = (int(M), int(K), int(N), int(bool(geglu)))
+    if stream_ok and _measured_linear_plans().get(key + (LINEAR_STREAM,), (0,))[0]:
+        return LINEAR_STREAM_PLAN
     plan = _lin_plan_cache.get(key)
     if plan is None:
         plan = _measured_linear_plans().get(key)
@@ -1419,7 +1432,11 @@ def linear_fused(x, weight, bias=None, residual=None, geglu=False, want_preact=F
         ldx = K
     N = weight.shape[0]
     n_out = N // 2 if geglu else N
-    plan = tuple(plan or linear_plan(M, K, N, geglu))
+    if plan is None:
+        stream_ok = ln is not None and linear_stream_serves(K, ln[0].shape[1], ln, bias, residual, want_preact, want_ln_stats,
+                                                            want_row_partials)
+        plan = linear_plan(M, K, N, geglu, stream_ok)
+    plan = tuple(plan)
     bm, bn, splits = plan[:3]
     stages = plan[3] if len(plan) > 3 else 0
     y = out if out is not None else torch.empty(lead + (n_out,), dtype=x.dtype, device=x.device)

@@ -144,10 +144,14 @@ class GuidedAttention:
             ops.prepare_device(self.unet.device)   # split-K slabs / tickets exist before any hipGraph capture
             cat = ops.cat_channels if os.environ.get("GA_LIBRARY_CAT", "0") != "1" else None   # GA_LIBRARY_CAT=1: torch.cat (A/B runs)
             self.unet.set_fused_impl(ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm), conv, linear, cat)
-            # MIOpen: time the candidate conv kernels once per shape — for the 16-bit production dtypes only.  In
-            # fp32 (parity runs) the library's default choice is kept: the exhaustive search executes every
-            # candidate solver, and the fp32 96x96 backward-data search was seen to abort the process once.
-            torch.backends.cudnn.benchmark = self.unet.dtype in (torch.float16, torch.bfloat16)
+            # MIOpen's exhaustive search (cudnn.benchmark) stays OFF.  It executes every candidate solver once per shape, and a
+            # candidate of the backward-data search for conv_in (4 <- 64 channels, 32 x 32, fp16) reads past its operands: a GPU
+            # memory access fault that killed the process whenever the tensors happened to sit at the end of a mapped segment
+            # (round 4, deterministic in `pytest tests/test_pipeline_gpu.py`, the worker thread in a native autograd node:
+            # profiles/r4_fault_half_precision_graphs_wide.log; round 3 had seen "the fp32 96x96 backward-data search abort
+            # the process once").  Only conv_in / conv_out and the three stride-2 backward convolutions are still on the
+            # library (< 3 % of a pass): its default choice costs nothing measurable (profiles/r4_ab_miopen_search.txt).
+            torch.backends.cudnn.benchmark = False
         return self
 
     @property

@@ -27,10 +27,11 @@ extern "C" {
  * was written for BEFORE its first call (guided-attention_amd/_lib.py:load does) — a stale binding passes pointers in the
  * wrong positions.  History:
  *   120  0.1.2  strict bbox mode, paint-with-words entry points
+ *   140  0.1.4  ga_linear_fused: stages = GA_LINEAR_STREAM (persistent form); no signature changed
  *   130  0.1.3  (round 3, bumped late) ga_conv3x3_nhwc / ga_gemm_nt gained `tickets` behind `workspace`, ga_group_norm_bwd
  *               gained `g_res` before `dx`; new: ga_aggregate_loss_fwd, ga_linear_fused, ga_linear_workspace,
  *               ga_splitk_workspace_floats, ga_conv3x3_up2x_nhwc, ga_cat_channels, ga_conv3x3_packed_elems */
-#define GA_VERSION 130
+#define GA_VERSION 140
 
 typedef void* ga_stream_t; /* hipStream_t */
 
@@ -332,7 +333,12 @@ int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspace, unsigned
  * (bitwise reproducible) and runs the epilogue — one launch.  ga_linear_workspace gives the sizes: `slabs` f32
  * [slab_floats], `tickets` [tiles] 32-bit words that are ZERO on entry (the kernel leaves them zero); launches that
  * share them must be stream-ordered.  `stages` = k-steps of the LDS ring (0: the tile's default; 128x128: 2 or 3,
- * 128x64 / 64x128: 3 or 4, 64x64: 4 or 5): shallow rings fit two workgroups per CU.  K % 64 == 0, N % 8 == 0, 16-bit dtypes. */
+ * 128x64 / 64x128: 3 or 4, 64x64: 4 or 5): shallow rings fit two workgroups per CU.  K % 64 == 0, N % 8 == 0, 16-bit dtypes.
+ * `stages` = GA_LINEAR_STREAM with the 128x128 tile: the PERSISTENT form for launches with many output tiles — one 512-thread
+ * workgroup per CU streams its tiles through a 4-slot ring that stays full across tile boundaries, GEGLU formed in registers
+ * from the f32 accumulators.  It serves the no-grad forms only: ln_partials required (2 <= ln_parts <= 20), no bias / residual /
+ * preact / ln_stats_out / row_partials_out, splits = 1, K >= 320; anything else returns GA_ERR_UNSUPPORTED. */
+#define GA_LINEAR_STREAM 8
 typedef struct {
   const void* bias;
   const void* residual;

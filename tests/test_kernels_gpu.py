@@ -1199,3 +1199,52 @@ def test_group_norm_act_on_offset_groups(ops, shape, offset, dt):
     print(f"[measured] GroupNorm offset {offset} {shape} {dt}: y {ey:.2e} dx {eg:.2e}")
     close(y, yr.detach().numpy(), TOL[dt] * 2, "y")
     close(xa.grad, xr.grad.numpy(), TOL[dt] * 3, "dx")
+
+
+# M, K, N, producer tile (its column tile sets the number of partial sums per row), GEGLU
+STREAM_CASES = [(12288, 320, 2560, (128, 64), True), (3072, 640, 5120, (128, 64), True), (768, 1280, 10240, (128, 64), True),
+                (4096, 320, 960, (128, 128), False), (12288, 320, 320, (128, 64), False), (1000, 320, 1008, (64, 64), True),
+                (130, 384, 264, (128, 128), False), (260, 640, 72, (64, 128), False), (4096, 320, 2560, (128, 128), True)]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("case", STREAM_CASES, ids=lambda c: "x".join(map(str, c[:3])) + ("-geglu" if c[4] else ""))
+def test_linear_stream_form(ops, case, dt):
+    """linear_stream_kernel (stages = GA_LINEAR_STREAM: one persistent 512-thread workgroup per CU, the LDS ring streaming across
+    tile boundaries, per-tile constants by LDS-DMA, GEGLU formed in registers) against fp64 on the CPU: the benched feed-forward
+    and QKV shapes (7 - 8 tiles per workgroup at M = 12288), ragged M and N, one tile per workgroup, odd / even / 2 / 20 partial
+    sums per row.  The LayerNorm-only form must also agree with the per-tile kernel to the last bit or two (same accumulation
+    order, same epilogue expression)."""
+    M, K, N, ptile, geglu = case
+    T = DT[dt]
+    x0 = dev(hashrand.normalish((M, K), 150 + M) * 1.3 + 0.4, T)
+    w0 = dev(hashrand.normalish((K, K), 151) * K ** -0.5, T)
+    prod = ops.linear_fused(x0, w0, None, residual=x0, want_row_partials=True, plan=ptile + (1,))
+    h, partials = prod["y"], prod["row_partials"]
+    parts = partials.shape[1]
+    assert ops.linear_stream_serves(K, parts, True, None, None, False, False, False), (K, parts)
+    gamma = dev(hashrand.normalish((K,), 152) * 0.2 + 1.0, T)
+    beta = dev(hashrand.normalish((K,), 153) * 0.2, T)
+    w = dev(hashrand.normalish((N, K), 154) * K ** -0.5, T)
+    bias = dev(hashrand.normalish((N,), 155) * 0.3, T)
+    wg, colsum, shift = _fold(w, bias, gamma, beta, T)
+    hd = h.double().cpu()
+    mean, var = hd.mean(-1, keepdim=True), hd.var(-1, unbiased=False, keepdim=True)
+    ln = (hd - mean) / torch.sqrt(var + 1e-5) * gamma.double().cpu() + beta.double().cpu()
+    pre = ln @ w.double().cpu().T + bias.double().cpu()
+    ref = pre[:, :N // 2] * _gelu64(pre[:, N // 2:]) if geglu else pre
+    y = torch.full((M, ref.shape[1]), float("nan"), device="cuda", dtype=T)      # every element must be written
+    out = ops.linear_fused(h, wg, None, geglu=geglu, ln=(partials, colsum, shift, 1e-5), plan=ops.LINEAR_STREAM_PLAN, out=y)
+    assert out["y"] is y and bool(torch.isfinite(y).all())
+    close(y, ref.numpy(), TOL[dt] * 4, f"stream form, {parts} partial sums per row")
+    again = ops.linear_fused(h, wg, None, geglu=geglu, ln=(partials, colsum, shift, 1e-5), plan=ops.LINEAR_STREAM_PLAN)["y"]
+    assert torch.equal(again, y)                                             # no ordering inside the launch can show in the result
+    tile = ops.linear_fused(h, wg, None, geglu=geglu, ln=(partials, colsum, shift, 1e-5), plan=(128, 128, 1, 3))["y"]
+    if not geglu:    # same products in the same order, same epilogue expression: a rounding step of the result type at most
+        assert float((y.float() - tile.float()).abs().max()) <= 2.0 ** (-9 if dt == "f16" else -6) * float(tile.float().abs().max())
+    else:            # the per-tile kernel rounds the projection to 16 bits in front of the gate, this one does not
+        close(y, tile.double().cpu().numpy(), TOL[dt] * 2, "stream vs per-tile GEGLU")
+    with pytest.raises(ops.GaError):     # forms it does not serve are refused, not mis-served
+        ops.linear_fused(h, wg, None, geglu=geglu, ln=(partials, colsum, shift, 1e-5), want_ln_stats=True, plan=ops.LINEAR_STREAM_PLAN)
+    with pytest.raises(ops.GaError):
+        ops.linear_fused(h, w, bias, plan=ops.LINEAR_STREAM_PLAN)
