@@ -150,8 +150,10 @@ class GuidedAttention:
             # (round 4, deterministic in `pytest tests/test_pipeline_gpu.py`, the worker thread in a native autograd node:
             # profiles/r4_fault_half_precision_graphs_wide.log; round 3 had seen "the fp32 96x96 backward-data search abort
             # the process once").  Only conv_in / conv_out and the three stride-2 backward convolutions are still on the
-            # library (< 3 % of a pass): its default choice costs nothing measurable (profiles/r4_ab_miopen_search.txt).
+            # library; the search stays on for the two FORWARD ones only, scoped to their calls (unet._edge_conv): with it off
+            # everywhere the bench lost 1 % (522.8 against 517.9 ms per image, same box: profiles/r4_ab_miopen_search.txt).
             torch.backends.cudnn.benchmark = False
+            self.unet.search_edge_convs = self.unet.dtype in (torch.float16, torch.bfloat16)
         return self
 
     @property
