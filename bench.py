@@ -588,6 +588,22 @@ def main(argv=None):
             line["end_to_end"] = {"tflop_per_image": round(tf, 1),
                                   "achieved_tflops_per_gpu": round(tf * args.steps / elapsed, 1),
                                   "frac_of_2.5PF_dense_fp16": round(tf * args.steps / elapsed / 2500.0, 4)}
+            # SURVEY's formula counts a backward as one full forward (0.803 TFLOP); the backward only covers the sub-graph below
+            # the last 16 x 16 cross-attention map.  Beside it: the flops the captured passes really issue on the matrix cores,
+            # from the launch census of each hipGraph (hand-written MFMA kernels only: the library's conv_in / conv_out / text
+            # K/V GEMMs, < 1 % of a pass, are not in the census), times the run-time call counters.
+            runner = getattr(pipe, "_runner", None)
+            if runner is not None and not args.eager:
+                per_pass = {name: sum(kernel_work(k)[1] * n for k, n in cen.items() if kernel_work(k)[0] == "mfma") / 1e12
+                            for name, cen in runner.launches.items()}
+                joint = calls.get("joint_b3", 0) if "joint" in per_pass else 0
+                tf_c = (per_pass["eval"] * (calls["fwd_b1_grad"] - joint) + per_pass["grad"] * calls["bwd"] +
+                        per_pass["cfg"] * (calls["fwd_b2"] - joint) + per_pass.get("joint", 0.0) * joint)
+                line["end_to_end"].update({
+                    "mfma_tflop_per_pass_from_census": {k: round(v, 3) for k, v in per_pass.items()},
+                    "tflop_per_image_from_census": round(tf_c, 1),
+                    "achieved_tflops_per_gpu_from_census": round(tf_c * args.steps / elapsed, 1),
+                    "frac_of_2.5PF_from_census": round(tf_c * args.steps / elapsed / 2500.0, 4)})
         line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, cfg, calls, rc)

@@ -915,11 +915,24 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+#if defined(GA_LIN_STAMPS)
+  LinStamps stm;   // [0] start [1] prologue done [2..5] SUMS over the stream: wait + barrier, k-step bodies, statistics, epilogues [7] end
+  unsigned long long acc_t[4] = {0, 0, 0, 0}, tp;
+  stm.real(8);
+  stm.at(0);
+#define GA_SSTAMP(i) do { stm.at(6); acc_t[i] += stm.t[6] - tp; tp = stm.t[6]; } while (0)
+#else
+#define GA_SSTAMP(i) ((void)0)
+#endif
   if (my_tiles > 0) set_issue_tile(0);
 #pragma unroll
   for (int s = 0; s < kSPre; ++s)
     if (gi < total) issue();
   int cj = 0, ck = 0, m0c = 0, n0c = 0;                     // consume cursor
+#if defined(GA_LIN_STAMPS)
+  stm.at(1);
+  tp = stm.t[1];
+#endif
   for (int g = 0; g < total; ++g) {
     // my pieces of step g have landed when at most the younger steps' pieces are outstanding (the few constant pieces issued in
     // between only make this wait for a little more than it needs)
@@ -928,6 +941,7 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
     else if (younger == 1) wait_vmcnt<4>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // step g is in LDS for everyone; everyone is done with step g - 1 (and with the last epilogue)
+    GA_SSTAMP(0);
     if (ck == 0) {
       tile_origin(cj, m0c, n0c);
       issue_constants(m0c, n0c);
@@ -937,6 +951,7 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
     // took the sum of the two (the first form of this kernel: 41 us on 12288 x 320 x 2560 against 44 for the per-tile kernel).
     const bool refill = gi < total;
     if (ck == 3) row_statistics();  // the constants went out three steps ago, in front of a step this wave has now waited for
+    GA_SSTAMP(2);
     const unsigned slot_off = (unsigned)((g & (kSNst - 1)) * kSStage);
     u32x4 fa[2], fb[2][2];
     auto request = [&](int kk, int set) {
@@ -960,6 +975,7 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
       if (refill) issue_piece(kk);
     }
     if (refill) advance();
+    GA_SSTAMP(1);
     if (++ck < steps) continue;
 
     // ---- epilogue of tile cj (the ring keeps landing the next tile meanwhile)
@@ -1026,7 +1042,16 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    GA_SSTAMP(3);
   }
+#if defined(GA_LIN_STAMPS)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stm.at(7);
+  stm.real(9);
+  for (int i = 0; i < 4; ++i) stm.t[2 + i] = acc_t[i];
+  stm.t[6] = (unsigned long long)my_tiles;
+  stm.flush();
+#endif
 }
 
 template <typename T>

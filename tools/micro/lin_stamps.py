@@ -31,6 +31,26 @@ PHASES = ["prologue: tile map, addresses, first ring issues, epilogue prefetch, 
           "drain: stores retired"]
 
 
+def report_stream(t, M, K, N, flags, plan, wgs):
+    """linear_stream_kernel: [0] start [1] prologue done [2..5] sums over the workgroup's stream (waits + barriers, k-step bodies,
+    row statistics, epilogues) [6] tiles of the workgroup [7] end."""
+    clk_mhz = np.median((t[:, 7] - t[:, 0]) / np.maximum(t[:, 9] - t[:, 8], 1)) * 100.0
+    us = lambda cyc: cyc / clk_mhz                                                         # noqa: E731
+    life = us(t[:, 7] - t[:, 0])
+    tiles = np.maximum(t[:, 6], 1)
+    print(f"shape M={M} K={K} N={N} flags={flags} stream form: {wgs} workgroups, {np.median(tiles):.0f} tiles each (median), stamp clock {clk_mhz:.0f} MHz")
+    rows = [("prologue (tile map, first three k-steps issued)", us(t[:, 1] - t[:, 0])),
+            ("waits for the ring + k-step barriers, per tile", us(t[:, 2]) / tiles),
+            ("k-step bodies (fragment reads, MFMAs, refill pieces), per tile", us(t[:, 3]) / tiles),
+            ("constants issue + row statistics, per tile", us(t[:, 4]) / tiles),
+            ("epilogues, per tile", us(t[:, 5]) / tiles)]
+    for name, d in rows:
+        print(f"  {np.median(d):7.2f} us  (p10 {np.percentile(d, 10):6.2f}, p90 {np.percentile(d, 90):6.2f})  {name}")
+    print(f"  {np.median(life):7.2f} us  workgroup lifetime (median; p90 {np.percentile(life, 90):.2f}) = {np.median(life / tiles):.2f} us per tile")
+    start = (t[:, 8] - t[:, 8].min()) / 100.0
+    print(f"  workgroup starts: last {start.max():.2f} us after the first; span first start -> last end {((t[:, 9] - t[:, 8].min()) / 100.0).max():.2f} us")
+
+
 def main():
     nums = [int(a) for a in sys.argv[1:]]
     M, K, N, flags = nums[:4]
@@ -46,6 +66,9 @@ def main():
     outc = bn // 2 if geglu else bn
     n_out = N // 2 if geglu else N
     wgs = -(-M // bm) * -(-n_out // outc) * splits
+    stream = len(plan) > 3 and plan[3] == ops.LINEAR_STREAM
+    if stream:
+        wgs = min(-(-M // 128) * -(-n_out // (64 if geglu else 128)), torch.cuda.get_device_properties(0).multi_processor_count)
     stamps = torch.zeros(wgs, 10, dtype=torch.int64, device=dev)
     assert lib.ga_lin_set_stamps(ctypes.c_void_p(stamps.data_ptr())) == 0
     x = torch.randn(M, K, device=dev, dtype=torch.half)
@@ -54,12 +77,15 @@ def main():
     bias = torch.randn(N, device=dev, dtype=torch.half)
     res = torch.randn(M, n_out, device=dev, dtype=torch.half) if res_ else None
     ln = (torch.rand(M, 5, 2, device=dev) * K, torch.randn(N, device=dev), torch.randn(N, device=dev), 1e-5) if ln_ else None
+    want_partials = res_ and not stream
     ops.prepare_device(dev)
     for i in range(reps):
-        ops.linear_fused(x, ws[i % n_copies], None if ln_ else bias, residual=res, geglu=geglu, ln=ln, want_row_partials=res_,
+        ops.linear_fused(x, ws[i % n_copies], None if ln_ else bias, residual=res, geglu=geglu, ln=ln, want_row_partials=want_partials,
                          plan=plan)
     torch.cuda.synchronize()
     t = stamps.cpu().numpy().astype(np.float64)
+    if stream:
+        return report_stream(t, M, K, N, flags, plan, wgs)
     real0, real1 = t[:, 8], t[:, 9]
     clk_mhz = np.median((t[:, 7] - t[:, 0]) / np.maximum(real1 - real0, 1)) * 100.0      # s_memrealtime ticks at 100 MHz
     us = lambda cyc: cyc / clk_mhz                                                         # noqa: E731
@@ -78,7 +104,7 @@ def main():
     def fn():
         turn[0] += 1
         ops.linear_fused(x, ws[turn[0] % n_copies], None if ln_ else bias, residual=res, geglu=geglu, ln=ln,
-                         want_row_partials=res_, plan=plan)
+                         want_row_partials=want_partials, plan=plan)
     side = ops.side_stream(dev)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
