@@ -1377,7 +1377,7 @@ LINEAR_STREAM_PLAN = (128, 128, 1, LINEAR_STREAM)
 def linear_stream_serves(K, parts, ln, bias, residual, want_preact, want_ln_stats, want_row_partials):
     """What linear_stream_kernel takes: the LayerNorm-folded no-grad forms (optionally GEGLU) at K >= 320."""
     return (ln is not None and bias is None and residual is None and not want_preact and not want_ln_stats
-            and not want_row_partials and K // 64 >= 5 and 2 <= parts <= 20)
+            and not want_row_partials and K // 64 >= 5 and 2 <= parts <= 10)
 
 
 def linear_plan(M, K, N, geglu=False, stream_ok=False):

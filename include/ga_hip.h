@@ -336,7 +336,7 @@ int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspace, unsigned
  * 128x64 / 64x128: 3 or 4, 64x64: 4 or 5): shallow rings fit two workgroups per CU.  K % 64 == 0, N % 8 == 0, 16-bit dtypes.
  * `stages` = GA_LINEAR_STREAM with the 128x128 tile: the PERSISTENT form for launches with many output tiles — one 512-thread
  * workgroup per CU streams its tiles through a 4-slot ring that stays full across tile boundaries, GEGLU formed in registers
- * from the f32 accumulators.  It serves the no-grad forms only: ln_partials required (2 <= ln_parts <= 20), no bias / residual /
+ * from the f32 accumulators.  It serves the no-grad forms only: ln_partials required (2 <= ln_parts <= 10), no bias / residual /
  * preact / ln_stats_out / row_partials_out, splits = 1, K >= 320; anything else returns GA_ERR_UNSUPPORTED. */
 #define GA_LINEAR_STREAM 8
 typedef struct {

@@ -1202,7 +1202,7 @@ def test_group_norm_act_on_offset_groups(ops, shape, offset, dt):
 
 
 # M, K, N, producer tile (its column tile sets the number of partial sums per row), GEGLU
-STREAM_CASES = [(12288, 320, 2560, (128, 64), True), (3072, 640, 5120, (128, 64), True), (768, 1280, 10240, (128, 64), True),
+STREAM_CASES = [(12288, 320, 2560, (128, 64), True), (3072, 640, 5120, (128, 64), True), (768, 1280, 10240, (128, 128), True),
                 (4096, 320, 960, (128, 128), False), (12288, 320, 320, (128, 64), False), (1000, 320, 1008, (64, 64), True),
                 (130, 384, 264, (128, 128), False), (260, 640, 72, (64, 128), False), (4096, 320, 2560, (128, 128), True)]
 
@@ -1212,8 +1212,8 @@ STREAM_CASES = [(12288, 320, 2560, (128, 64), True), (3072, 640, 5120, (128, 64)
 def test_linear_stream_form(ops, case, dt):
     """linear_stream_kernel (stages = GA_LINEAR_STREAM: one persistent 512-thread workgroup per CU, the LDS ring streaming across
     tile boundaries, per-tile constants by LDS-DMA, GEGLU formed in registers) against fp64 on the CPU: the benched feed-forward
-    and QKV shapes (7 - 8 tiles per workgroup at M = 12288), ragged M and N, one tile per workgroup, odd / even / 2 / 20 partial
-    sums per row.  The LayerNorm-only form must also agree with the per-tile kernel to the last bit or two (same accumulation
+    and QKV shapes (7 - 8 tiles per workgroup at M = 12288), ragged M and N, one tile per workgroup, odd / even / 3 / 10 partial
+    sums per row (the form takes 2 - 10).  The LayerNorm-only form must also agree with the per-tile kernel to the last bit or two (same accumulation
     order, same epilogue expression)."""
     M, K, N, ptile, geglu = case
     T = DT[dt]
