@@ -13,7 +13,7 @@ import torch
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("GA_HIP_LIB", _HERE / "libga_hip.so"))
 
-GA_VERSION = 140   # the GA_VERSION of include/ga_hip.h these prototypes were written for (tests/test_abi.py compares the two)
+GA_VERSION = 150   # the GA_VERSION of include/ga_hip.h these prototypes were written for (tests/test_abi.py compares the two)
 GA_F16, GA_BF16, GA_F32 = 0, 1, 2
 GA_LINEAR_STREAM = 8   # `stages` of ga_linear_fused: the persistent one-workgroup-per-CU form (include/ga_hip.h)
 GA_TOK_COOR, GA_TOK_BOX = 0, 1
@@ -80,6 +80,10 @@ PROTOTYPES = {
                         ctypes.POINTER(ctypes.c_longlong)],
     "ga_splitk_workspace_floats": [_i64, _i, _i, _i, _i],
     "ga_conv3x3_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ga_conv3x3_gn_blocks": [_i, _i, _i, _i, _i, _i],
+    "ga_conv3x3_nhwc_gn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i],
+    "ga_group_norm_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ga_group_norm_two_launch": [_i, _i, _i, _i],
     "ga_conv3x3_up2x_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ga_gemm_nt": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
     "ga_linear_workspace": [_i64, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(_i)],

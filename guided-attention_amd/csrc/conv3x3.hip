@@ -99,6 +99,13 @@ struct ConvArgs {
   int up;           // 1: X is [B][H/2][W/2][Cin] and the convolution runs on its nearest-neighbour 2x up-sampling (H, W are the
                     // up-sampled sizes): only the patch gather of conv3x3_patch_dma_kernel changes — pixel (iy, ix) of the
                     // patch is read from (iy >> 1, ix >> 1) — and the [B][H][W][Cin] intermediate is never written
+  // Optional GroupNorm statistics of the STORED result for the norm layer that consumes it (ga_conv3x3_nhwc_gn): per (image,
+  // m tile, group) partial (sum, sum of squares) in the layout ga_group_norm_apply folds — the consumer's statistics launch
+  // (a full read of the tensor by its own kernel) disappears.  gn_cbias: the per-(image, channel) term that norm adds to its
+  // input (the ResnetBlock's time embedding): the sums are those of result + term, the stored result is unchanged.
+  float* gn_partials;      // [B][2 * gn_tpi][gn_G][2] or null
+  const void* gn_cbias;    // [B][Cout] T or null
+  int gn_cg, gn_G, gn_tpi; // channels per group, groups, m tiles per image (tiles never straddle images: Ho * Wo % BM == 0)
 };
 
 // All of the argument block in SGPRs at this point: an empty asm that "reads" every field makes the compiler fetch them in
@@ -184,10 +191,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T
   constexpr int NV = BM * VPR / kThreads;          // output vectors per thread; kThreads % VPR == 0: one column run per thread
   static_assert(BM * VPR % kThreads == 0 && kThreads % VPR == 0, "output vector map");
   const int cv = (tid % VPR) * 8, r0 = tid / VPR;
-  u32x4 bvec = {0u, 0u, 0u, 0u}, rvec[NV];
+  u32x4 bvec = {0u, 0u, 0u, 0u}, rvec[NV], gvec = {0u, 0u, 0u, 0u};
+  const bool gn = a.gn_partials != nullptr;
+  const int gn_b = gn ? sdiv(m0, a.d_howo) : 0;      // the tile's image (gn: whole tiles of one image)
   auto prefetch = [&]() {
     const int nc = min(n0 + cv, a.Cout - 8);
     if (bias != nullptr) bvec = *reinterpret_cast<const u32x4*>(bias + nc);
+    if (gn && a.gn_cbias != nullptr) gvec = *reinterpret_cast<const u32x4*>(static_cast<const T*>(a.gn_cbias) + (size_t)gn_b * a.Cout + nc);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       rvec[k] = u32x4{0u, 0u, 0u, 0u};
@@ -269,6 +279,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T
   {
     constexpr int LDC = BN + 8;
     T* Cs = lds;
+    float gsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gsq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < IM; ++i)
 #pragma unroll
@@ -295,6 +306,60 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T
           e[q] = Traits<T>::from_f32(Traits<T>::to_f32(e[q]) + Traits<T>::to_f32(be[q]) + Traits<T>::to_f32(re[q]));
       }
       if (m < a.M && n < a.Cout) *reinterpret_cast<uint4*>(Y + (size_t)m * a.Cout + n) = val;
+      if (gn && m < a.M && n < a.Cout) {   // sums of the values AS STORED (+ the consumer's per-channel term)
+        const T* e = reinterpret_cast<const T*>(&val);
+        const T* ge = reinterpret_cast<const T*>(&gvec);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float x = Traits<T>::to_f32(e[q]) + Traits<T>::to_f32(ge[q]);
+          gsum[q] += x;
+          gsq[q] += x * x;
+        }
+      }
+    }
+    if (gn) {
+      // this thread's 8 channels lie in at most two groups (8 <= channels per group): gA takes the first `split` of them
+      const int c_abs = n0 + cv, gA = c_abs / a.gn_cg, split = min(8, (gA + 1) * a.gn_cg - c_abs);
+      float4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (q < split) {
+          r.x += gsum[q];
+          r.y += gsq[q];
+        } else {
+          r.z += gsum[q];
+          r.w += gsq[q];
+        }
+      }
+      __syncthreads();                                   // every thread has read its rows of the staging tile
+      float4* lds4 = reinterpret_cast<float4*>(lds);
+      lds4[tid] = r;
+      __syncthreads();
+      const int n_end = min(n0 + BN, a.Cout);
+      const int g_first = n0 / a.gn_cg, g_last = (n_end - 1) / a.gn_cg;
+      const int g = g_first + tid;
+      if (g <= g_last) {
+        const int c_lo = max(g * a.gn_cg, n0), c_hi = min((g + 1) * a.gn_cg, n_end);      // this tile's channels of group g
+        float sa = 0.f, sq = 0.f;
+        for (int v = (c_lo - n0) >> 3; v <= (c_hi - 1 - n0) >> 3; ++v) {
+          const bool first = (n0 + 8 * v) / a.gn_cg == g;   // g is this vector's gA, otherwise its gA + 1
+          for (int pr = 0; pr < kThreads / VPR; ++pr) {   // fixed order: the same bits whoever runs first
+            const float4 e = lds4[pr * VPR + v];
+            sa += first ? e.x : e.z;
+            sq += first ? e.y : e.w;
+          }
+        }
+        // slot 2 t of m tile t: the n tile a group STARTS in; slot 2 t + 1: the n tile it continues into (zero when it does not)
+        const int t = (m0 - gn_b * (a.Ho * a.Wo)) / BM;
+        float2* out = reinterpret_cast<float2*>(a.gn_partials) + ((size_t)gn_b * 2 * a.gn_tpi + 2 * t) * a.gn_G + g;
+        const bool starts = g * a.gn_cg >= n0, ends = (g + 1) * a.gn_cg <= n_end;
+        if (starts) {
+          out[0] = float2{sa, sq};
+          if (ends) out[a.gn_G] = float2{0.f, 0.f};
+        } else {
+          out[a.gn_G] = float2{sa, sq};
+        }
+      }
     }
   }
 }
@@ -1223,15 +1288,49 @@ extern "C" int ga_conv3x3_pack_weights(const void* W, void* Wp, int Cout, int Ci
   return check_launch();
 }
 
+extern "C" int ga_conv3x3_gn_blocks(int H, int W, int Cout, int groups, int bm, int bn) {
+  // partial blocks per image ga_conv3x3_nhwc_gn writes (0: it does not serve the shape): whole m tiles per image, 8 <= channels
+  // per group <= bn, at most 128 blocks (what ga_group_norm_apply folds)
+  if (H < 1 || W < 1 || groups < 1 || Cout % groups != 0 || (bm != 64 && bm != 128) || (bn != 64 && bn != 128)) return 0;
+  const int hw = H * W, cg = Cout / groups;
+  if (hw % bm != 0 || cg < 8 || cg > bn || 2 * (hw / bm) > 128) return 0;
+  return 2 * (hw / bm);
+}
+
+static int conv3x3_nhwc_impl(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets, const void* bias,
+                             const void* residual, int B, int H, int W, int Cin, int Cout, int stride, int bm, int bn,
+                             int splits, int dtype, ga_stream_t stream, float* gn_partials, const void* gn_chan_bias,
+                             int gn_groups);
+
 extern "C" int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets, const void* bias,
                                const void* residual, int B, int H, int W, int Cin, int Cout, int stride, int bm, int bn,
                                int splits, int dtype, ga_stream_t stream) {
+  return conv3x3_nhwc_impl(X, Wp, Y, workspace, tickets, bias, residual, B, H, W, Cin, Cout, stride, bm, bn, splits, dtype, stream,
+                           nullptr, nullptr, 0);
+}
+
+extern "C" int ga_conv3x3_nhwc_gn(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets, const void* bias,
+                                  const void* residual, int B, int H, int W, int Cin, int Cout, int bm, int bn, int splits,
+                                  int dtype, ga_stream_t stream, float* gn_partials, const void* gn_chan_bias, int gn_groups) {
+  if (!gn_partials) return GA_ERR_NULL;
+  if (ga_conv3x3_gn_blocks(H, W, Cout, gn_groups, bm, bn) == 0) return GA_ERR_UNSUPPORTED;
+  if (gn_chan_bias && !al16(gn_chan_bias)) return GA_ERR_ALIGN;
+  return conv3x3_nhwc_impl(X, Wp, Y, workspace, tickets, bias, residual, B, H, W, Cin, Cout, 1, bm, bn, splits, dtype, stream,
+                           gn_partials, gn_chan_bias, gn_groups);
+}
+
+static int conv3x3_nhwc_impl(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets, const void* bias,
+                             const void* residual, int B, int H, int W, int Cin, int Cout, int stride, int bm, int bn,
+                             int splits, int dtype, ga_stream_t stream, float* gn_partials, const void* gn_chan_bias,
+                             int gn_groups) {
   if (!X || !Wp || !Y) return GA_ERR_NULL;
   if (B < 1 || H < 1 || W < 1 || Cin < kKC || Cin % kKC != 0 || Cout < 8 || Cout % 8 != 0 || (stride != 1 && stride != 2))
     return GA_ERR_SHAPE;
   if (splits < 1 || splits > 64 || (splits > 1 && (!workspace || !tickets))) return GA_ERR_SHAPE;
   if (!al16(X) || !al16(Wp) || !al16(Y) || (bias && !al16(bias)) || (residual && !al16(residual))) return GA_ERR_ALIGN;
   ConvArgs a;
+  a.gn_partials = gn_partials; a.gn_cbias = gn_chan_bias;
+  a.gn_G = gn_groups; a.gn_cg = gn_groups ? Cout / gn_groups : 0; a.gn_tpi = gn_groups ? H * W / bm : 0;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stride = stride;
   a.Ho = (H - 1) / stride + 1;
   a.Wo = (W - 1) / stride + 1;
@@ -1259,6 +1358,7 @@ extern "C" int ga_conv3x3_up2x_nhwc(const void* X, const void* Wp, void* Y, floa
   if (splits < 1 || splits > 64 || (splits > 1 && (!workspace || !tickets))) return GA_ERR_SHAPE;
   if (!al16(X) || !al16(Wp) || !al16(Y) || (bias && !al16(bias)) || (residual && !al16(residual))) return GA_ERR_ALIGN;
   ConvArgs a;
+  a.gn_partials = nullptr; a.gn_cbias = nullptr; a.gn_cg = a.gn_G = a.gn_tpi = 0;
   a.B = B; a.H = 2 * H; a.W = 2 * W; a.Cin = Cin; a.Cout = Cout; a.stride = 1;
   a.Ho = a.H; a.Wo = a.W;
   a.M = B * a.Ho * a.Wo;
@@ -1289,6 +1389,7 @@ extern "C" int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspac
   const long long xb = (long long)M * K * 2, wb = (long long)N * K * 2;
   if (xb >= (1LL << 31) || wb >= (1LL << 31) || (long long)M * N >= (1LL << 31)) return GA_ERR_SHAPE;
   ConvArgs a;
+  a.gn_partials = nullptr; a.gn_cbias = nullptr; a.gn_cg = a.gn_G = a.gn_tpi = 0;
   a.B = 1; a.H = (int)M; a.W = 1; a.Cin = K; a.Cout = N; a.stride = 1;
   a.Ho = (int)M; a.Wo = 1; a.M = (int)M;
   a.pad = 0;

@@ -1135,6 +1135,43 @@ extern "C" int ga_group_norm_fwd(const void* x, const void* chan_bias, const voi
   }
 }
 
+extern "C" int ga_group_norm_apply(const void* x, const void* chan_bias, const void* gamma, const void* beta, void* y,
+                                   float* stats, const float* partials, int blocks, int B, int HW, int C, int G, float eps,
+                                   int act_silu, int dtype, ga_stream_t stream) {
+  // The second launch of the large-level forward alone, on partial sums somebody else took: the epilogue of the convolution
+  // that PRODUCED x (ga_conv3x3_nhwc_gn).  Same kernel, same fold (fixed order) — only the statistics launch is gone.
+  if (!x || !gamma || !beta || !y || !stats || !partials) return GA_ERR_NULL;
+  Geom g;
+  int rc = geometry(B, HW, C, G, g);
+  if (rc != GA_OK) return rc;
+  if (blocks < 1 || blocks > kMaxStatsNB) return GA_ERR_SHAPE;
+  if (dtype == GA_F32 || !wide_ok(C, G, 2)) return GA_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const WideGeom wg(HW, C);
+  const float inv_n = 1.0f / ((float)HW * (float)(C / G));
+#define GA_GN_APPLY(T, ACT)                                                                                                   \
+  hipLaunchKernelGGL((gn_wide_apply_kernel<T, ACT>), dim3(wg.NBa, B), dim3(kThreads), 0, s, (const T*)x, (const T*)chan_bias, \
+                     (const T*)gamma, (const T*)beta, (T*)y, partials, blocks, inv_n, eps, stats, HW, C, G, wg.PBa)
+  if (dtype == GA_F16) {
+    if (act_silu) GA_GN_APPLY(_Float16, true);
+    else GA_GN_APPLY(_Float16, false);
+  } else if (dtype == GA_BF16) {
+    if (act_silu) GA_GN_APPLY(bf16_t, true);
+    else GA_GN_APPLY(bf16_t, false);
+  } else {
+    return GA_ERR_DTYPE;
+  }
+#undef GA_GN_APPLY
+  return check_launch();
+}
+
+extern "C" int ga_group_norm_two_launch(int HW, int C, int G, int dtype) {
+  /* 1 when ga_group_norm_fwd takes the two-launch (statistics + apply) path for this shape in a 16-bit type — the norms for
+   * which a producer's partial sums (ga_conv3x3_nhwc_gn + ga_group_norm_apply) save a launch */
+  if (dtype == GA_F32 || HW < 1 || C < 1 || G < 1 || C % G != 0) return 0;
+  return !small_path(HW, C, G, sizeof(float)) && wide_ok(C, G, 2) ? 1 : 0;
+}
+
 extern "C" int ga_group_norm_bwd(const void* x, const void* chan_bias, const void* dy, const void* gamma,
                                  const void* beta, const float* stats, const void* g_res, void* dx, float* workspace, int B,
                                  int HW, int C, int G, int act_silu, int dtype, ga_stream_t stream) {

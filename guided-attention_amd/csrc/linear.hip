@@ -719,35 +719,33 @@ int lin_t(const void* X, const void* W, void* Y, const LinArgs& a, const LinPtrs
 // cost more issue time than the step's 16 MFMAs), a third the epilogue (GEGLU through 16-bit LDS images).  Here:
 //  * one workgroup per CU takes the LDS: a 4-slot ring (3 k-steps = 96 KB in flight) that keeps STREAMING ACROSS TILE BOUNDARIES
 //    — while a tile's epilogue runs, the next tile's first steps are landing; per-tile set-up is a few address computations;
-//  * 8 waves (2 per SIMD), each 32 tokens x 64 columns: 4 LDS-DMA pieces per wave and step instead of 8, issued BETWEEN the
-//    step's MFMAs (the waves leave every barrier together: issuing first and computing afterwards took the sum of the two);
+//  * 8 waves (2 per SIMD), each 32 tokens x 64 columns: 4 LDS-DMA pieces per wave and step instead of 8, and a partner wave's
+//    MFMAs under every wave's DMA issue and epilogue arithmetic;
 //  * GEGLU in registers: a wave owns 32 h columns AND their 32 gate columns, so h * gelu(gate) is formed from the f32
 //    accumulators (the projection is never rounded to 16 bits in between; half the staging traffic);
-//  * the GEGLU epilogue of tile j runs INSIDE tile j + 1's k-steps, from a second accumulator set: one quarter of the tile's
-//    columns per step (LayerNorm algebra, gelu, 16-bit pack, staging write), the global stores in the fifth step — and the two
-//    waves of a SIMD take turns: waves 4-7 run their quarter BEFORE the step's MFMAs, waves 0-3 behind them, so one partner's
-//    gelu arithmetic sits under the other's matrix work (stamps of the first form of this kernel, all eight waves in lockstep
-//    with the epilogue between two tiles: 1.4 us of 5.3 us per tile were epilogue, profiles/r4_linear_stream_stamps.txt);
 //  * EVERY memory operation of the loop is an LDS-DMA (operands, and per tile: the LayerNorm shift / colsum of its columns, the
 //    rows' partial sums), every LDS access inline asm: vmcnt retires in order, so one ordinary load waited for inside the loop
 //    would drain the ring (and hipcc waits vmcnt(0) in front of any LDS access it can see while an LDS-DMA is pending).  The
 //    per-tile constants are requested when the tile's FIRST k-step is consumed and read >= 3 steps later: the ring's own counted
 //    waits have covered them by then.
+// Built, measured and removed (profiles/r4_linear_stream_stamps_deferred_epilogue.txt): the GEGLU epilogue of tile j deferred into
+// tile j + 1's k-steps from a second accumulator set, the two waves of a SIMD taking turns (one's gelu arithmetic under the other's
+// MFMAs) — 41.9 against 37.3 us on 12288 x 320 x 2560: per k-step the kernel waits 1200 cycles for its 32 KB of operands (27 bytes
+// per clock and CU from L2) whatever sits beside the MFMAs; the epilogue was never the bound, the operand stream is.
 // Serves: LayerNorm fold (always), optional GEGLU, no bias / residual / split-K / pre-activation copy / statistics output — the
-// no-grad passes' forms; K >= 320 (five k-steps: the waits and the deferred epilogue's five phases), 2 <= partial sums per
-// row <= 10.
+// no-grad passes' forms; K >= 320 (five k-steps: see the waits), 2 <= partial sums per row <= 20.
 constexpr int kSThreads = 512;
 constexpr int kSStage = 256 * kBK * 2;                 // bytes of one ring slot: 128 token rows + 128 weight rows of 128 bytes
 constexpr int kSNst = 4, kSPre = kSNst - 1;
 constexpr int kSOutStride = 144;                       // staging row: 64 outputs + one 16-byte vector (8-byte writes of 16
                                                        // consecutive rows and 16-byte reads fall on distinct banks)
-constexpr int kSPartsMax = 10;
-constexpr int kSStageOff = kSNst * kSStage;            // output staging [128][144 bytes]
-constexpr int kSPartOff = kSStageOff + 128 * kSOutStride;        // the rows' LayerNorm partial sums: [chunk][row] 16 bytes
-constexpr int kSCstOff = kSPartOff + 128 * 16 * (kSPartsMax / 2);   // shift[128] | colsum[128] (f32) of the tile's columns, x 2 (tile parity)
-constexpr int kSStatOff = kSCstOff + 2048;             // (mean, rstd)[128] of the tile's rows, x 2 (tile parity)
-constexpr int kSLds = kSStatOff + 2048;
-static_assert(kSLds <= 160 * 1024, "LDS map of linear_stream_kernel");
+constexpr int kSPartsMax = 20;
+constexpr int kSStageOff = kSNst * kSStage;            // output staging, overlaid by the rows' LayerNorm partial sums
+constexpr int kSStageBytes = 128 * 16 * (kSPartsMax / 2);   // 20480 >= 128 * kSOutStride
+constexpr int kSCstOff = kSStageOff + kSStageBytes;    // shift[128] | colsum[128] of the tile's columns (f32)
+constexpr int kSStatOff = kSCstOff + 1024;             // (mean, rstd)[128] of the tile's rows
+constexpr int kSLds = kSStatOff + 1024;
+static_assert(128 * kSOutStride <= kSStageBytes && kSLds <= 160 * 1024, "LDS map of linear_stream_kernel");
 
 __device__ __forceinline__ void lds_read64(f32x2& dst, unsigned byte_address) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -768,7 +766,8 @@ __device__ __forceinline__ void lds_write64(unsigned byte_address, f32x2 v) {
   asm volatile("ds_write_b64 %0, %1" ::"v"(byte_address), "v"(v) : "memory");
 #endif
 }
-// x + (x of the lane whose id differs in bit 0 / bit 1): DPP quad permutes, no LDS traffic
+
+// x + (x of the lanes whose id differs in bit 0, then bit 1): DPP quad permutes, no LDS traffic
 __device__ __forceinline__ float quad_sum(float x) {
   x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));   // [1,0,3,2]
   x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));   // [2,3,0,1]
@@ -783,44 +782,6 @@ __device__ __forceinline__ f32x2 pack4(float a, float b, float c, float d) {   /
   f[2] = Traits<T>::from_f32(c);
   f[3] = Traits<T>::from_f32(d);
   return __builtin_bit_cast(f32x2, f);
-}
-
-// One quarter (QD: 8 of the wave's 32 output columns, this lane's four of them) of a tile's epilogue from the accumulators
-// `src`: LayerNorm algebra with the tile's constants (LDS image `cst` of this tile's parity), GEGLU or plain, 16-bit pack, one
-// 8-byte staging write.  PASS selects the 64-column half of a plain tile.  `col` = wn * 32 + 4 * fh.
-template <typename T, bool GEGLU, int QD, int PASS>
-__device__ __forceinline__ void stream_chunk(const f32x16 (&src)[2], unsigned cst, unsigned out_adr, int col, float mean, float rstd) {
-  const unsigned c = (unsigned)(col + 8 * QD);
-  float o[4];
-  if constexpr (GEGLU) {
-    f32x4 sh_h, sh_g, cs_h, cs_g;
-    lds_read128f(sh_h, cst + 4u * c);
-    lds_read128f(sh_g, cst + 4u * (64u + c));
-    lds_read128f(cs_h, cst + 512u + 4u * c);
-    lds_read128f(cs_g, cst + 512u + 4u * (64u + c));
-    wait_lgkmcnt<0>();
-    __builtin_amdgcn_sched_barrier(0);
-    float hv[4], gv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      hv[r] = rstd * (src[0][4 * QD + r] - mean * cs_h[r]) + sh_h[r];
-      gv[r] = rstd * (src[1][4 * QD + r] - mean * cs_g[r]) + sh_g[r];
-    }
-    const f32x2 g01 = gelu_erf2(f32x2{gv[0], gv[1]}), g23 = gelu_erf2(f32x2{gv[2], gv[3]});
-    o[0] = hv[0] * g01.x;
-    o[1] = hv[1] * g01.y;
-    o[2] = hv[2] * g23.x;
-    o[3] = hv[3] * g23.y;
-  } else {
-    f32x4 sh, cs;
-    lds_read128f(sh, cst + 4u * (64u * PASS + c));
-    lds_read128f(cs, cst + 512u + 4u * (64u * PASS + c));
-    wait_lgkmcnt<0>();
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = rstd * (src[PASS][4 * QD + r] - mean * cs[r]) + sh[r];
-  }
-  lds_write64(out_adr + 16u * QD, pack4<T>(o[0], o[1], o[2], o[3]));
 }
 
 template <typename T, bool GEGLU>
@@ -839,7 +800,6 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const bool late = wave_u >= 4;   // waves w and w + 4 share a SIMD: this half runs its deferred epilogue quarter BEFORE the MFMAs
 
   // ---- this workgroup's tiles: logical tile L = j * G + rb, rb = its place in an XCD-contiguous order of the G workgroups
   // (workgroup ids equal mod 8 share an XCD: each XCD works on a contiguous run of every band of G tiles — shared operand panels
@@ -903,36 +863,42 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
       if (++ij < my_tiles) set_issue_tile(ij);
     }
   };
-  // per-tile constants, by LDS-DMA with per-lane source addresses: the partial sums of the 128 rows go out as pieces of 64 rows x
-  // two parts (a 16-byte load from an 8-byte aligned address), one per wave; the next wave brings shift | colsum of the tile's
-  // 128 columns (one piece: lanes 0-31 shift, 32-63 colsum, four floats each).  With an odd part count the last piece starts
-  // one part early instead of reading past the row (the statistics below skip the part it repeats).
+  auto issue = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_piece(q);
+    advance();
+  };
+  // per-tile constants, by LDS-DMA with per-lane source addresses: wave 0 brings shift | colsum of the tile's 128 columns (one
+  // piece: lanes 0-31 shift, 32-63 colsum, four floats each), the partial sums of the 128 rows go out as pieces of 64 rows x
+  // two parts (a 16-byte load from an 8-byte aligned address), dealt over the waves.  With an odd part count the last piece
+  // starts one part early instead of reading past the row (the statistics below skip the part it repeats).
   const int parts = a_in.ln_parts, chunks = (parts + 1) >> 1;
-  auto issue_constants = [&](int m0, int n0, int par) {
-    if (wave_u == ((2 * chunks) & 7)) {
+  auto issue_constants = [&](int m0, int n0) {
+    if (wave_u == ((2 * chunks) & 7)) {   // the wave behind the ones that carry the partial pieces
       const int c = 4 * (lane & 31);
       const float* src = (lane < 32 ? p.ln_shift : p.ln_colsum) + feature(n0, c, 3);
-      __builtin_amdgcn_global_load_lds(src, GA_LDS_PTR(lds + kSCstOff + par * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src, GA_LDS_PTR(lds + kSCstOff), 16, 0, 0);
     }
     for (int pi = wave_u; pi < 2 * chunks; pi += 8) {
       const int c = pi >> 1, rh = pi & 1;
       const int m = min(m0 + 64 * rh + lane, M - 1);
       const float* src = p.ln_partials + ((size_t)m * parts + min(2 * c, parts - 2)) * 2;
-      __builtin_amdgcn_global_load_lds(src, GA_LDS_PTR(lds + kSPartOff + (c * 128 + 64 * rh) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src, GA_LDS_PTR(lds + kSStageOff + (c * 128 + 64 * rh) * 16), 16, 0, 0);
     }
   };
-  // (mean, rstd) of the tile's rows from the partial sums: every wave takes 16 rows, four lanes a row (each lane the chunks
-  // equal to its index mod 4), the four are added by quad permutes
-  auto row_statistics = [&](int par) {
+  // (mean, rstd) of the tile's rows from the partial sums: every wave takes 16 rows, four lanes a row (each lane the pieces
+  // equal to its index mod 4), the four are added by quad permutes.  (The first form — threads 0 .. 127 a row each, piece by
+  // piece — kept two of the eight waves busy for 0.85 us per tile while the other six waited at the next barrier.)
+  auto row_statistics = [&]() {
     const int row = 16 * wave + (lane >> 2), sub = lane & 3;
-    f32x4 v[2];
+    f32x4 v[3];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) lds_read128f(v[u], lds0 + kSPartOff + (unsigned)((min(sub + 4 * u, chunks - 1) * 128 + row) * 16));
+    for (int u = 0; u < 3; ++u) lds_read128f(v[u], lds0 + kSStageOff + (unsigned)((min(sub + 4 * u, chunks - 1) * 128 + row) * 16));
     wait_lgkmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < 3; ++u) {
       const int c = sub + 4 * u;
       const bool in = c < chunks, first = in && 2 * c + 1 < parts;   // odd count, last piece: its first part belongs to the piece before
       s1 += (first ? v[u][0] : 0.f) + (in ? v[u][2] : 0.f);
@@ -942,7 +908,7 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
     s2 = quad_sum(s2);
     const float mean = s1 * a_in.ln_inv_k;
     const float rstd = rsqrtf(fmaxf(s2 * a_in.ln_inv_k - mean * mean, 0.f) + a_in.ln_eps);
-    if (sub == 0) lds_write64(lds0 + kSStatOff + (unsigned)(par * 1024 + row * 8), f32x2{mean, rstd});
+    if (sub == 0) lds_write64(lds0 + kSStatOff + (unsigned)(row * 8), f32x2{mean, rstd});
   };
 
   // ---- fragment addresses inside slot 0 (see linear_kernel): tokens = B operand, weights = A operand
@@ -958,49 +924,11 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
       b_sw[j] = (unsigned)(((wrow >> 1) & 7) ^ fh);
     }
   }
-  const int col = wn * 32 + 4 * fh;
-  const unsigned out_adr = lds0 + kSStageOff + (unsigned)((wm * 32 + fr) * kSOutStride + col * 2);
-  // the staged 128 x 64 outputs of a (half) tile to Y: two 16-byte row pieces per thread
-  auto stream_store = [&](int m0, int n0) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int v = tid + k * kSThreads, r = v >> 3, cv = (v & 7) * 8;
-      u32x4 val;
-      lds_read128(val, lds0 + kSStageOff + (unsigned)(r * kSOutStride + cv * 2));
-      wait_lgkmcnt<0>();
-      __builtin_amdgcn_sched_barrier(0);
-      const int m = m0 + r, n = n0 + cv;
-      if (m < M && n < n_out) *reinterpret_cast<u32x4*>(Y + (size_t)m * a_in.ldy + n) = val;
-    }
-  };
-  f32x16 acc[2], accp[2];                                   // this tile's accumulators; the previous tile's (deferred GEGLU epilogue)
+  f32x16 acc[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = accp[j][r] = 0.f;
-  bool havep = false;
-  int m0p = 0, n0p = 0, parp = 0;
-  f32x2 stp = {0.f, 1.f};                                   // (mean, rstd) of this lane's row of the previous tile
-  // phase `ph` (0 .. 4) of the previous tile's epilogue: four column quarters, then the stores (the staging writes of phase 3 are
-  // one k-step barrier older than the reads of phase 4)
-  auto deferred = [&](int ph) {
-    if (!havep) return;
-    const unsigned cst = lds0 + kSCstOff + (unsigned)(parp * 1024);
-    if (ph == 0) {
-      lds_read64(stp, lds0 + kSStatOff + (unsigned)(parp * 1024 + (wm * 32 + fr) * 8));
-      wait_lgkmcnt<0>();            // (waited for here: nothing may touch the pair — not even a register copy — before it is back)
-      __builtin_amdgcn_sched_barrier(0);
-      stream_chunk<T, GEGLU, 0, 0>(accp, cst, out_adr, col, stp[0], stp[1]);
-    } else if (ph == 1) {
-      stream_chunk<T, GEGLU, 1, 0>(accp, cst, out_adr, col, stp[0], stp[1]);
-    } else if (ph == 2) {
-      stream_chunk<T, GEGLU, 2, 0>(accp, cst, out_adr, col, stp[0], stp[1]);
-    } else if (ph == 3) {
-      stream_chunk<T, GEGLU, 3, 0>(accp, cst, out_adr, col, stp[0], stp[1]);
-    } else if (ph == 4) {
-      stream_store(m0p, n0p);
-    }
-  };
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
 #if defined(GA_LIN_STAMPS)
   LinStamps stm;   // [0] start [1] prologue done [2..5] SUMS over the stream: wait + barrier, k-step bodies, statistics, epilogues [7] end
@@ -1014,33 +942,30 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
   if (my_tiles > 0) set_issue_tile(0);
 #pragma unroll
   for (int s = 0; s < kSPre; ++s)
-    if (gi < total) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) issue_piece(q);
-      advance();
-    }
+    if (gi < total) issue();
   int cj = 0, ck = 0, m0c = 0, n0c = 0;                     // consume cursor
 #if defined(GA_LIN_STAMPS)
   stm.at(1);
   tp = stm.t[1];
 #endif
   for (int g = 0; g < total; ++g) {
-    // my pieces of step g have landed when at most the younger steps' pieces are outstanding (the few constant pieces and
-    // stores issued in between only make this wait for a little more than it needs)
+    // my pieces of step g have landed when at most the younger steps' pieces are outstanding (the few constant pieces issued in
+    // between only make this wait for a little more than it needs)
     const int younger = min(total - 1 - g, kSPre - 1);
     if (younger >= 2) wait_vmcnt<8>();
     else if (younger == 1) wait_vmcnt<4>();
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();   // step g is in LDS for everyone; everyone is done with step g - 1
+    __builtin_amdgcn_s_barrier();   // step g is in LDS for everyone; everyone is done with step g - 1 (and with the last epilogue)
     GA_SSTAMP(0);
-    const int par = cj & 1;
     if (ck == 0) {
       tile_origin(cj, m0c, n0c);
-      issue_constants(m0c, n0c, par);
+      issue_constants(m0c, n0c);
     }
-    // The refill of the slot step g - 1 occupied goes out BETWEEN this step's MFMAs, one piece behind each of the four sub-steps
+    // The refill of the slot step g - 1 occupied goes out BETWEEN this step's MFMAs, one piece behind each of the four
+    // sub-steps: the eight waves leave the barrier together, and eight waves issuing 32 pieces at once, then computing at once,
+    // took the sum of the two (the first form of this kernel: 41 us on 12288 x 320 x 2560 against 44 for the per-tile kernel).
     const bool refill = gi < total;
-    if (ck == 3) row_statistics(par);   // the constants went out three steps ago, in front of a step this wave has now waited for
+    if (ck == 3) row_statistics();  // the constants went out three steps ago, in front of a step this wave has now waited for
     GA_SSTAMP(2);
     const unsigned slot_off = (unsigned)((g & (kSNst - 1)) * kSStage);
     u32x4 fa[2], fb[2][2];
@@ -1050,9 +975,6 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
       for (int j = 0; j < 2; ++j) lds_read128(fb[set][j], b_adr[j] + slot_off + 16u * ((2u * kk) ^ b_sw[j]));
     };
     request(0, 0);
-    if constexpr (GEGLU) {
-      if (late) deferred(ck);       // (leaves at most its staging write pending: LDS returns in order, the counts below hold)
-    }
 #pragma unroll
     for (int kk = 0; kk < kBK / 16; ++kk) {
       if (kk + 1 < kBK / 16) {
@@ -1069,61 +991,73 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
     }
     if (refill) advance();
     GA_SSTAMP(1);
-    if constexpr (GEGLU) {
-      if (!late) deferred(ck);
-      GA_SSTAMP(3);
-    }
     if (++ck < steps) continue;
 
-    // ---- the tile is complete
+    // ---- epilogue of tile cj (the ring keeps landing the next tile meanwhile)
     ck = 0;
-    if constexpr (GEGLU) {          // its epilogue runs inside the next tile's steps (or behind the loop), from the second set
-#pragma unroll
-      for (int j = 0; j < 2; ++j) accp[j] = acc[j];
-      m0p = m0c;
-      n0p = n0c;
-      parp = par;
-      havep = true;
-    } else {                        // plain tile (two 64-column halves through the one staging image): here and now
-      f32x2 st;
-      lds_read64(st, lds0 + kSStatOff + (unsigned)(par * 1024 + (wm * 32 + fr) * 8));
-      const unsigned cst = lds0 + kSCstOff + (unsigned)(par * 1024);
-      wait_lgkmcnt<0>();
-      __builtin_amdgcn_sched_barrier(0);
-      stream_chunk<T, false, 0, 0>(acc, cst, out_adr, col, st[0], st[1]);
-      stream_chunk<T, false, 1, 0>(acc, cst, out_adr, col, st[0], st[1]);
-      stream_chunk<T, false, 2, 0>(acc, cst, out_adr, col, st[0], st[1]);
-      stream_chunk<T, false, 3, 0>(acc, cst, out_adr, col, st[0], st[1]);
-      wait_lgkmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      stream_store(m0c, n0c);
-      __builtin_amdgcn_s_barrier();                         // the first half has left the staging rows
-      stream_chunk<T, false, 0, 1>(acc, cst, out_adr, col, st[0], st[1]);
-      stream_chunk<T, false, 1, 1>(acc, cst, out_adr, col, st[0], st[1]);
-      stream_chunk<T, false, 2, 1>(acc, cst, out_adr, col, st[0], st[1]);
-      stream_chunk<T, false, 3, 1>(acc, cst, out_adr, col, st[0], st[1]);
-      wait_lgkmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      stream_store(m0c, n0c + 64);
-      GA_SSTAMP(3);
-    }
     ++cj;
+    f32x2 st;                                               // (mean, rstd) of this lane's token row
+    lds_read64(st, lds0 + kSStatOff + (wm * 32 + fr) * 8);
+    f32x4 sh[2][4], cs[2][4];                               // shift / colsum of this lane's columns: [h | gate or half][quad]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const unsigned c = (unsigned)(j * 64 + wn * 32 + 8 * qd + 4 * fh);
+        lds_read128f(sh[j][qd], lds0 + kSCstOff + 4u * c);
+        lds_read128f(cs[j][qd], lds0 + kSCstOff + 512u + 4u * c);
+      }
+    wait_lgkmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    const float mean = st[0], rstd = st[1];
+    const unsigned out_adr = lds0 + kSStageOff + (unsigned)((wm * 32 + fr) * kSOutStride + (wn * 32 + 4 * fh) * 2);
+    constexpr int PASSES = GEGLU ? 1 : 2;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+      if (pass > 0) {
+        __builtin_amdgcn_s_barrier();                       // the first half has left the staging rows
+      }
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (GEGLU) {
+            const float hv = rstd * (acc[0][4 * qd + r] - mean * cs[0][qd][r]) + sh[0][qd][r];
+            const float gv = rstd * (acc[1][4 * qd + r] - mean * cs[1][qd][r]) + sh[1][qd][r];
+            o[r] = gv;
+            acc[0][4 * qd + r] = hv;
+          } else {
+            o[r] = rstd * (acc[pass][4 * qd + r] - mean * cs[pass][qd][r]) + sh[pass][qd][r];
+          }
+        }
+        if constexpr (GEGLU) {
+          const f32x2 g01 = gelu_erf2(f32x2{o[0], o[1]}), g23 = gelu_erf2(f32x2{o[2], o[3]});
+          o[0] = acc[0][4 * qd] * g01.x;
+          o[1] = acc[0][4 * qd + 1] * g01.y;
+          o[2] = acc[0][4 * qd + 2] * g23.x;
+          o[3] = acc[0][4 * qd + 3] * g23.y;
+        }
+        lds_write64(out_adr + 16u * qd, pack4<T>(o[0], o[1], o[2], o[3]));
+      }
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int v = tid + k * kSThreads, r = v >> 3, cv = (v & 7) * 8;
+        u32x4 val;
+        lds_read128(val, lds0 + kSStageOff + (unsigned)(r * kSOutStride + cv * 2));
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        const int m = m0c + r, n = n0c + pass * 64 + cv;
+        if (m < M && n < n_out) *reinterpret_cast<u32x4*>(Y + (size_t)m * a_in.ldy + n) = val;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  }
-  if constexpr (GEGLU) {            // the last tile's epilogue has no next tile to hide in
-    if (havep) {
-      __builtin_amdgcn_s_barrier();   // the store phase of the tile before (this iteration, for five-step tiles) has left the staging rows
-      deferred(0);
-      deferred(1);
-      deferred(2);
-      deferred(3);
-      wait_lgkmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      deferred(4);
-    }
+    GA_SSTAMP(3);
   }
 #if defined(GA_LIN_STAMPS)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -744,7 +744,9 @@ class GroupNormAct(torch.autograd.Function):
     accumulation would be one more launch per block (23 per guidance backward of the SD-1.x UNet)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, act, chan_bias, with_alias=False):
+    def forward(ctx, x, weight, bias, groups, eps, act, chan_bias, with_alias=False, produced=None):
+        """produced = (partials (B, blocks, groups, 2) f32, blocks) from the epilogue of the convolution that made x
+        (conv3x3_nhwc(..., gn=...)): the large-level forward is then ONE launch (ga_group_norm_apply) instead of two."""
         require_cuda(x, weight, bias, chan_bias)
         if x.dim() != 4:
             raise GaError("GroupNormAct expects a (B, C, H, W) tensor")
@@ -758,11 +760,18 @@ class GroupNormAct(torch.autograd.Function):
                 raise GaError(f"chan_bias must be (B, C) = {(B, C)}, got {tuple(chan_bias.shape)}")
         y = torch.empty_like(x, memory_format=torch.channels_last)
         stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
-        ws = torch.empty((B * 257 * groups * 2,), dtype=torch.float32, device=x.device)
-        _count(("group_norm_fwd", B, groups, H * W, 0, C, bool(act), str(x.dtype)))
-        check(load().ga_group_norm_fwd(_ptr(x), _ptr(chan_bias), _ptr(weight), _ptr(bias), _ptr(y), _ptr(stats), _ptr(ws),
-                                       B, H * W, C, groups, float(eps), int(bool(act)), dtype_code(x), stream_ptr()),
-              "ga_group_norm_fwd")
+        if produced is not None:
+            partials, blocks = produced
+            _count(("group_norm_apply", B, groups, H * W, blocks, C, bool(act), str(x.dtype)))
+            check(load().ga_group_norm_apply(_ptr(x), _ptr(chan_bias), _ptr(weight), _ptr(bias), _ptr(y), _ptr(stats),
+                                             _ptr(partials), blocks, B, H * W, C, groups, float(eps), int(bool(act)),
+                                             dtype_code(x), stream_ptr()), "ga_group_norm_apply")
+        else:
+            ws = torch.empty((B * 257 * groups * 2,), dtype=torch.float32, device=x.device)
+            _count(("group_norm_fwd", B, groups, H * W, 0, C, bool(act), str(x.dtype)))
+            check(load().ga_group_norm_fwd(_ptr(x), _ptr(chan_bias), _ptr(weight), _ptr(bias), _ptr(y), _ptr(stats), _ptr(ws),
+                                           B, H * W, C, groups, float(eps), int(bool(act)), dtype_code(x), stream_ptr()),
+                  "ga_group_norm_fwd")
         ctx.save_for_backward(x, weight, bias, stats, chan_bias)
         ctx.meta = (groups, bool(act))
         if with_alias:
@@ -775,7 +784,7 @@ class GroupNormAct(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise GaError("GroupNorm weight gradients are not part of the guided-attention path (frozen UNet)")
         if dy is None:           # only the alias was differentiated
-            return g_alias, None, None, None, None, None, None, None
+            return g_alias, None, None, None, None, None, None, None, None
         x, weight, bias, stats, chan_bias = ctx.saved_tensors
         groups, act = ctx.meta
         B, C, H, W = x.shape
@@ -789,12 +798,24 @@ class GroupNormAct(torch.autograd.Function):
                                        _ptr(g_alias), _ptr(dx), _ptr(ws), B, H * W, C, groups, int(act), dtype_code(x),
                                        stream_ptr()),
               "ga_group_norm_bwd")
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
 def group_norm_act(x, weight, bias, groups, eps, act, chan_bias=None, with_alias=False):
-    """-> y, or (y, x) with with_alias (use that x for the skip connection: see GroupNormAct)."""
-    return GroupNormAct.apply(x, weight, bias, groups, eps, act, chan_bias, with_alias)
+    """-> y, or (y, x) with with_alias (use that x for the skip connection: see GroupNormAct).
+    When x came out of conv3x3(..., gn_for=(groups, chan_bias)) — the convolution's epilogue took the statistics this norm
+    needs (same group count, the SAME channel-bias tensor) — the statistics launch is skipped."""
+    pre = getattr(x, "_ga_gn", None)
+    produced = None
+    if pre is not None and pre["groups"] == groups and pre["chan_bias"] is chan_bias and pre["shape"] == tuple(x.shape):
+        produced = (pre["partials"], pre["blocks"])
+    return GroupNormAct.apply(x, weight, bias, groups, eps, act, chan_bias, with_alias, produced)
+
+
+def gn_two_launch(HW, C, groups, dtype):
+    """True when ga_group_norm_fwd takes two launches for the shape (a producer's partial sums then save one)."""
+    code = _lib.DTYPE_CODE.get(dtype)
+    return code is not None and bool(load().ga_group_norm_two_launch(HW, C, groups, code))
 
 
 # --------------------------------------------------------------------------------------- feed-forward / residual epilogues
@@ -1074,8 +1095,10 @@ def conv3x3_supported(x, weight, stride=1):
             weight.shape[1] % CONV_KC == 0 and weight.shape[0] % CONV_KC == 0 and stride in (1, 2))   # both ways round: backward
 
 
-def conv3x3_nhwc(x, wp, cout, stride=1, bias=None, residual=None, plan=None):
-    """x (B, Cin, H, W) channels-last, wp the [9][Cout][Cin] pack -> y (B, Cout, Ho, Wo) channels-last."""
+def conv3x3_nhwc(x, wp, cout, stride=1, bias=None, residual=None, plan=None, gn=None):
+    """x (B, Cin, H, W) channels-last, wp the [9][Cout][Cin] pack -> y (B, Cout, Ho, Wo) channels-last.
+    gn = (groups, chan_bias (B, Cout) or None): the epilogue also leaves the GroupNorm statistics of y (+ chan_bias) for the
+    norm layer that consumes it -> (y, (partials, blocks)) — or (y, None) where the shape is not one that saves a launch."""
     require_cuda(x, wp, bias, residual)
     x = _nhwc(x)
     B, Cin, H, W = x.shape
@@ -1086,10 +1109,25 @@ def conv3x3_nhwc(x, wp, cout, stride=1, bias=None, residual=None, plan=None):
     if residual is not None:
         residual = _nhwc(residual)
     _count(("conv3x3", B, Cin, H * W, stride, cout, bias is not None or residual is not None, str(x.dtype)))
+    if gn is not None:
+        groups, cb = gn
+        blocks = int(load().ga_conv3x3_gn_blocks(H, W, cout, groups, bm, bn)) if stride == 1 else 0
+        if blocks and gn_two_launch(H * W, cout, groups, x.dtype):
+            if cb is not None:
+                require_cuda(cb)
+                cb = cb.to(x.dtype).contiguous()
+                if tuple(cb.shape) != (B, cout):
+                    raise GaError(f"chan_bias must be (B, C) = {(B, cout)}, got {tuple(cb.shape)}")
+            partials = torch.empty((B, blocks, groups, 2), dtype=torch.float32, device=x.device)
+            _check_ticketed(load().ga_conv3x3_nhwc_gn(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(tickets), _ptr(bias),
+                                                      _ptr(residual), B, H, W, Cin, cout, bm, bn, splits, dtype_code(x),
+                                                      stream_ptr(), _ptr(partials), _ptr(cb), groups),
+                            "ga_conv3x3_nhwc_gn", tickets)
+            return y, (partials, blocks)
     _check_ticketed(load().ga_conv3x3_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(tickets), _ptr(bias), _ptr(residual), B,
                                            H, W, Cin, cout, stride, bm, bn, splits, dtype_code(x), stream_ptr()),
                     "ga_conv3x3_nhwc", tickets)
-    return y
+    return (y, None) if gn is not None else y
 
 
 GA_ERR_SHAPE = -2   # include/ga_hip.h
@@ -1153,13 +1191,18 @@ class Conv3x3(torch.autograd.Function):
     are frozen on this path."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride):
+    def forward(ctx, x, weight, bias, residual, stride, gn=None):
+        """gn (see conv3x3_nhwc): the second output then holds (partials, blocks) for the consuming norm, as a Python attribute
+        of the first (`_ga_gn_out`): forward-only side data, no gradient."""
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise GaError("convolution weight gradients are not part of the guided-attention path (frozen UNet)")
         wp = conv3x3_packed_weights(weight, False)
-        y = conv3x3_nhwc(x, wp, weight.shape[0], stride, bias, residual)
         ctx.weight, ctx.stride, ctx.in_shape = weight, stride, tuple(x.shape)
         ctx.has_res = residual is not None
+        if gn is None:
+            return conv3x3_nhwc(x, wp, weight.shape[0], stride, bias, residual)
+        y, made = conv3x3_nhwc(x, wp, weight.shape[0], stride, bias, residual, gn=gn)
+        ctx.gn_made = made
         return y
 
     @staticmethod
@@ -1177,8 +1220,37 @@ class Conv3x3(torch.autograd.Function):
         return gx, None, None, (gy if ctx.has_res else None), None
 
 
-def conv3x3(x, weight, bias=None, residual=None, stride=1):
-    return Conv3x3.apply(x, weight, bias, residual, stride)
+def conv3x3(x, weight, bias=None, residual=None, stride=1, gn_for=None):
+    """gn_for = (groups, chan_bias or None) of the GroupNorm that consumes the result: where that norm would take two launches
+    the convolution's epilogue takes its statistics, and the result carries them (`_ga_gn`, read by group_norm_act)."""
+    if gn_for is None:
+        return Conv3x3.apply(x, weight, bias, residual, stride)
+    groups, cb = gn_for
+    B, _, H, W = x.shape
+    cout = weight.shape[0]
+    if stride != 1 or not gn_two_launch(H * W, cout, groups, x.dtype):
+        return Conv3x3.apply(x, weight, bias, residual, stride)
+    box = []
+    y = _Conv3x3Gn.apply(x, weight, bias, residual, (groups, cb), box)
+    if box and box[0] is not None:
+        partials, blocks = box[0]
+        y._ga_gn = {"partials": partials, "blocks": blocks, "groups": groups, "chan_bias": cb, "shape": tuple(y.shape)}
+    return y
+
+
+class _Conv3x3Gn(Conv3x3):
+    """Conv3x3 (stride 1) whose epilogue also takes the consuming GroupNorm's statistics; what it took leaves through `box` (a
+    Function's outputs are tensors; this is forward-only side data without a gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, gn, box):
+        y = Conv3x3.forward(ctx, x, weight, bias, residual, 1, gn)
+        box.append(ctx.gn_made)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return Conv3x3.backward(ctx, gy) + (None,)
 
 
 conv3x3.supported = conv3x3_supported
@@ -1377,7 +1449,7 @@ LINEAR_STREAM_PLAN = (128, 128, 1, LINEAR_STREAM)
 def linear_stream_serves(K, parts, ln, bias, residual, want_preact, want_ln_stats, want_row_partials):
     """What linear_stream_kernel takes: the LayerNorm-folded no-grad forms (optionally GEGLU) at K >= 320."""
     return (ln is not None and bias is None and residual is None and not want_preact and not want_ln_stats
-            and not want_row_partials and K // 64 >= 5 and 2 <= parts <= 10)
+            and not want_row_partials and K // 64 >= 5 and 2 <= parts <= 20)
 
 
 def linear_plan(M, K, N, geglu=False, stream_ok=False):

@@ -161,12 +161,15 @@ class GroupNormAct(nn.GroupNorm):
         return (y, x_in) if with_alias else y
 
 
-def conv3x3(x, conv, impl, residual=None, with_bias=True):
+def conv3x3(x, conv, impl, residual=None, with_bias=True, gn_for=None):
     """A 3x3 Conv2d (padding 1) of the UNet, optionally with its bias and a residual added in the same pass.  `impl` is
     the implicit-GEMM HIP kernel (ops.conv3x3, installed by the GPU pipeline for the 16-bit dtypes) or None = the library
-    convolution (what the CPU oracle and the fp32 parity runs use)."""
+    convolution (what the CPU oracle and the fp32 parity runs use).  gn_for = (groups, chan_bias) of the GroupNorm that
+    consumes the result: the HIP kernel's epilogue then takes that norm's statistics (ops.conv3x3)."""
     bias = conv.bias if with_bias else None
     if impl is not None and impl.supported(x, conv.weight, conv.stride[0]):
+        if gn_for is not None:
+            return impl(x, conv.weight, bias, residual, conv.stride[0], gn_for=gn_for)
         return impl(x, conv.weight, bias, residual, conv.stride[0])
     y = F.conv2d(x, conv.weight, bias, stride=conv.stride, padding=1)
     return y if residual is None else y + residual
@@ -320,11 +323,14 @@ class ResnetBlock2D(nn.Module):
         # norm1 / norm2 carry the SiLU.  conv1's bias rides on the time projection (one add instead of two): the
         # UNet's batched projection already contains it; the stand-alone path adds it here
         h, x = self.norm1(x, with_alias=True)   # x: the skip connection's view of the input (see GroupNormAct.forward)
-        h = conv3x3(h, self.conv1, self.conv_impl, with_bias=False)
         if isinstance(temb_act, dict):
             tproj = temb_act[id(self)]
         else:
             tproj = self.time_emb_proj(temb_act) + self.conv1.bias
+        # conv1's epilogue takes norm2's statistics (of its result + the time term) where norm2 would need a launch for them;
+        # conv2's does the same for whatever norm reads this block's output next (the attention's GroupNorm, conv_norm_out)
+        gn = self.norm2.impl is not None
+        h = conv3x3(h, self.conv1, self.conv_impl, with_bias=False, gn_for=(self.norm2.num_groups, tproj) if gn else None)
         h = self.norm2(h, chan_bias=tproj)  # the time term is added inside the norm's loads
         if self.conv_shortcut is not None:
             _, _, hh, ww = x.shape
@@ -336,7 +342,10 @@ class ResnetBlock2D(nn.Module):
                 xt = pointwise_conv_tokens(xt, sc)
             x = tokens_to_nchw(xt, hh, ww)
         if self.conv_impl is not None and self.conv_impl.supported(h, self.conv2.weight, 1):
-            return self.conv_impl(h, self.conv2.weight, self.conv2.bias, x, 1)   # bias + skip connection in the epilogue
+            # bias + skip connection in the epilogue
+            if gn:
+                return self.conv_impl(h, self.conv2.weight, self.conv2.bias, x, 1, gn_for=(self.norm2.num_groups, None))
+            return self.conv_impl(h, self.conv2.weight, self.conv2.bias, x, 1)
         if self.add_impl is not None and self.conv2.out_channels % 8 == 0:
             # conv2's bias and the skip connection in one pass (the library conv adds its bias as a separate kernel)
             return self.add_impl(F.conv2d(h, self.conv2.weight, None, padding=1), self.conv2.bias, x)

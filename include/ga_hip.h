@@ -27,11 +27,12 @@ extern "C" {
  * was written for BEFORE its first call (guided-attention_amd/_lib.py:load does) — a stale binding passes pointers in the
  * wrong positions.  History:
  *   120  0.1.2  strict bbox mode, paint-with-words entry points
+ *   150  0.1.5  new: ga_conv3x3_nhwc_gn, ga_conv3x3_gn_blocks, ga_group_norm_apply, ga_group_norm_two_launch
  *   140  0.1.4  ga_linear_fused: stages = GA_LINEAR_STREAM (persistent form); no signature changed
  *   130  0.1.3  (round 3, bumped late) ga_conv3x3_nhwc / ga_gemm_nt gained `tickets` behind `workspace`, ga_group_norm_bwd
  *               gained `g_res` before `dx`; new: ga_aggregate_loss_fwd, ga_linear_fused, ga_linear_workspace,
  *               ga_splitk_workspace_floats, ga_conv3x3_up2x_nhwc, ga_cat_channels, ga_conv3x3_packed_elems */
-#define GA_VERSION 140
+#define GA_VERSION 150
 
 typedef void* ga_stream_t; /* hipStream_t */
 
@@ -232,6 +233,13 @@ int ga_self_attn_bwd(const void* Q, const void* K, const void* V, const void* O,
 int ga_group_norm_fwd(const void* x, const void* chan_bias, const void* gamma, const void* beta, void* y, float* stats,
                       float* workspace, int B, int HW, int C, int G, float eps, int act_silu, int dtype,
                       ga_stream_t stream);
+/* The apply launch of the large-level forward on partial sums taken elsewhere (`partials` [B][blocks][G][2] f32, blocks <= 128:
+ * what ga_conv3x3_nhwc_gn leaves): y, stats as ga_group_norm_fwd.  16-bit types, C % 8 == 0, C / G >= 8.
+ * ga_group_norm_two_launch: 1 when ga_group_norm_fwd would take two launches for the shape (where the pair above saves one). */
+int ga_group_norm_apply(const void* x, const void* chan_bias, const void* gamma, const void* beta, void* y, float* stats,
+                        const float* partials, int blocks, int B, int HW, int C, int G, float eps, int act_silu, int dtype,
+                        ga_stream_t stream);
+int ga_group_norm_two_launch(int HW, int C, int G, int dtype);
 int ga_group_norm_bwd(const void* x, const void* chan_bias, const void* dy, const void* gamma, const void* beta,
                       const float* stats, const void* g_res, void* dx, float* workspace, int B, int HW, int C, int G,
                       int act_silu, int dtype, ga_stream_t stream);
@@ -295,6 +303,17 @@ int ga_conv3x3_plan(int B, int H, int W, int Cin, int Cout, int stride, int* bm,
 int ga_conv3x3_nhwc(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets, const void* bias,
                     const void* residual, int B, int H, int W, int Cin, int Cout, int stride, int bm, int bn, int splits,
                     int dtype, ga_stream_t stream);
+/* The same convolution (stride 1) that ALSO leaves the GroupNorm statistics of its stored result for the norm layer that consumes
+ * it: per (image, m tile, group) partial (sum, sum of squares) [B][blocks][groups][2] f32, blocks = ga_conv3x3_gn_blocks(...)
+ * (0: shape not served — m tiles must not straddle images, 8 <= Cout / groups <= bn), written by the epilogue in a fixed order.
+ * gn_chan_bias (optional [B][Cout] T): the term that norm adds to its input (the ResnetBlock's time embedding, diffusers
+ * ResnetBlock2D: `hidden_states + temb` in front of norm2) — the sums are those of result + term; Y is unchanged.
+ * ga_group_norm_apply(x = Y, ..., partials, blocks) then normalises without the statistics launch of ga_group_norm_fwd. */
+int ga_conv3x3_gn_blocks(int H, int W, int Cout, int groups, int bm, int bn);
+int ga_conv3x3_nhwc_gn(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets, const void* bias,
+                       const void* residual, int B, int H, int W, int Cin, int Cout, int bm, int bn, int splits, int dtype,
+                       ga_stream_t stream, float* gn_partials, const void* gn_chan_bias, int gn_groups);
+
 int ga_conv3x3_up2x_nhwc(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets, const void* bias,
                          const void* residual, int B, int H, int W, int Cin, int Cout, int bm, int bn, int splits, int dtype,
                          ga_stream_t stream);
@@ -336,7 +355,7 @@ int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspace, unsigned
  * 128x64 / 64x128: 3 or 4, 64x64: 4 or 5): shallow rings fit two workgroups per CU.  K % 64 == 0, N % 8 == 0, 16-bit dtypes.
  * `stages` = GA_LINEAR_STREAM with the 128x128 tile: the PERSISTENT form for launches with many output tiles — one 512-thread
  * workgroup per CU streams its tiles through a 4-slot ring that stays full across tile boundaries, GEGLU formed in registers
- * from the f32 accumulators.  It serves the no-grad forms only: ln_partials required (2 <= ln_parts <= 10), no bias / residual /
+ * from the f32 accumulators.  It serves the no-grad forms only: ln_partials required (2 <= ln_parts <= 20), no bias / residual /
  * preact / ln_stats_out / row_partials_out, splits = 1, K >= 320; anything else returns GA_ERR_UNSUPPORTED. */
 #define GA_LINEAR_STREAM 8
 typedef struct {

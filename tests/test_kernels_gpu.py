@@ -1209,7 +1209,7 @@ def test_group_norm_act_on_offset_groups(ops, shape, offset, dt):
 
 
 # M, K, N, producer tile (its column tile sets the number of partial sums per row), GEGLU
-STREAM_CASES = [(12288, 320, 2560, (128, 64), True), (3072, 640, 5120, (128, 64), True), (768, 1280, 10240, (128, 128), True),
+STREAM_CASES = [(12288, 320, 2560, (128, 64), True), (3072, 640, 5120, (128, 64), True), (768, 1280, 10240, (128, 64), True),
                 (4096, 320, 960, (128, 128), False), (12288, 320, 320, (128, 64), False), (1000, 320, 1008, (64, 64), True),
                 (130, 384, 264, (128, 128), False), (260, 640, 72, (64, 128), False), (4096, 320, 2560, (128, 128), True)]
 
@@ -1219,8 +1219,8 @@ STREAM_CASES = [(12288, 320, 2560, (128, 64), True), (3072, 640, 5120, (128, 64)
 def test_linear_stream_form(ops, case, dt):
     """linear_stream_kernel (stages = GA_LINEAR_STREAM: one persistent 512-thread workgroup per CU, the LDS ring streaming across
     tile boundaries, per-tile constants by LDS-DMA, GEGLU formed in registers) against fp64 on the CPU: the benched feed-forward
-    and QKV shapes (7 - 8 tiles per workgroup at M = 12288), ragged M and N, one tile per workgroup, odd / even / 3 / 10 partial
-    sums per row (the form takes 2 - 10).  The LayerNorm-only form must also agree with the per-tile kernel to the last bit or two (same accumulation
+    and QKV shapes (7 - 8 tiles per workgroup at M = 12288), ragged M and N, one tile per workgroup, odd / even / 3 / 20 partial
+    sums per row (the form takes 2 - 20).  The LayerNorm-only form must also agree with the per-tile kernel to the last bit or two (same accumulation
     order, same epilogue expression)."""
     M, K, N, ptile, geglu = case
     T = DT[dt]
@@ -1255,3 +1255,72 @@ def test_linear_stream_form(ops, case, dt):
         ops.linear_fused(h, wg, None, geglu=geglu, ln=(partials, colsum, shift, 1e-5), want_ln_stats=True, plan=ops.LINEAR_STREAM_PLAN)
     with pytest.raises(ops.GaError):
         ops.linear_fused(h, w, bias, plan=ops.LINEAR_STREAM_PLAN)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("case", [(1, 320, 320, 64, 64, True), (3, 320, 320, 64, 64, False), (2, 640, 320, 64, 64, True),
+                                  (1, 960, 320, 64, 64, False), (2, 128, 256, 32, 32, True), (1, 64, 64, 16, 16, False)],
+                         ids=lambda c: "x".join(map(str, c[:5])) + ("-cb" if c[5] else ""))
+def test_conv3x3_epilogue_takes_the_consuming_group_norm_statistics(ops, case, dt):
+    """ga_conv3x3_nhwc_gn + ga_group_norm_apply: the convolution's epilogue leaves the per-(image, m tile, group) partial sums of
+    its STORED result (+ the time-embedding term the norm adds) and the norm's large-level forward runs as ONE launch on them —
+    against fp64 on the CPU, against the two-launch ga_group_norm_fwd on the same tensor (the partial sums are grouped
+    differently: statistics equal to f32 rounding), through the autograd wrappers (ops.conv3x3(gn_for=...) ->
+    ops.group_norm_act) with the launch census, for every tile / split-K plan; shapes the pair does not serve (16 x 16 maps:
+    the norm is one launch anyway) fall back without a trace."""
+    B, Cin, Cout, H, W, with_cb = case
+    T = DT[dt]
+    groups = 32
+    x = dev(hashrand.normalish((B, Cin, H, W), 160 + Cin), T).contiguous(memory_format=torch.channels_last)
+    w = dev(hashrand.normalish((Cout, Cin, 3, 3), 161) * (1.0 / math.sqrt(9 * Cin)), T)
+    bias = dev(hashrand.normalish((Cout,), 162) * 0.3, T)
+    res = dev(hashrand.normalish((B, Cout, H, W), 163), T).contiguous(memory_format=torch.channels_last)
+    cb = dev(hashrand.normalish((B, Cout), 164) * 0.7, T) if with_cb else None
+    gamma = dev(hashrand.normalish((Cout,), 165) * 0.3 + 1.0, T)
+    beta = dev(hashrand.normalish((Cout,), 166) * 0.2, T)
+    wide = ops.gn_two_launch(H * W, Cout, groups, T)
+    assert wide == (H * W * (Cout // groups) > 20480)
+    wp = ops.conv3x3_packed_weights(w, False)
+    steps = 9 * Cin // ops.CONV_KC
+    y_plain = ops.conv3x3_nhwc(x, wp, Cout, 1, bias, res)
+    yd = y_plain.double().cpu() + (cb.double().cpu()[:, :, None, None] if with_cb else 0.0)
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(yd, groups, gamma.double().cpu(), beta.double().cpu(), 1e-5))
+    two = ops.group_norm_act(y_plain, gamma, beta, groups, 1e-5, True, cb)
+    for bm, bn in ((128, 128), (128, 64), (64, 64)):
+        for splits in (1, 3):
+            if splits > steps:
+                continue
+            plan = (bm, bn, splits, splits * B * H * W * Cout if splits > 1 else 0)
+            y, made = ops.conv3x3_nhwc(x, wp, Cout, 1, bias, res, plan=plan, gn=(groups, cb))
+            assert torch.equal(y, ops.conv3x3_nhwc(x, wp, Cout, 1, bias, res, plan=plan))       # the result itself is untouched
+            if not wide:
+                assert made is None
+                continue
+            partials, blocks = made
+            assert blocks == 2 * (H * W // bm) and tuple(partials.shape) == (B, blocks, groups, 2)
+            # the partial sums add up to the sums of the stored tensor (+ term), per (image, group)
+            yg = (y.double().cpu() + (cb.double().cpu()[:, :, None, None] if with_cb else 0.0)).reshape(B, groups, -1)
+            close(partials[..., 0].sum(1), yg.sum(-1).numpy(), 2e-5, f"sum {plan}")
+            close(partials[..., 1].sum(1), (yg * yg).sum(-1).numpy(), 2e-5, f"sum of squares {plan}")
+            out = ops.GroupNormAct.apply(y, gamma, beta, groups, 1e-5, True, cb, False, made)
+            close(out, ref.numpy(), TOL[dt] * 2, f"one-launch norm {plan}")
+            close(out, two.double().cpu().numpy(), TOL[dt], f"one launch vs two {plan}")
+    # the autograd wrappers: producer -> consumer, census, gradient to the convolution's input
+    xa = x.clone().requires_grad_(True)
+    with ops.census_scope() as cs:
+        ya = ops.conv3x3(xa, w, bias, res, 1, gn_for=(groups, cb))
+        za = ops.group_norm_act(ya, gamma, beta, groups, 1e-5, True, cb)
+    kinds = {k[0]: n for k, n in cs.launches.items()}
+    assert kinds.get("group_norm_apply", 0) == (1 if wide else 0) and kinds.get("group_norm_fwd", 0) == (0 if wide else 1)
+    close(za, ref.numpy(), TOL[dt] * 2, "wrapper forward")
+    g = dev(hashrand.normalish((B, Cout, H, W), 167), T).contiguous(memory_format=torch.channels_last)
+    za.backward(g)
+    xb = x.clone().requires_grad_(True)
+    zb = ops.group_norm_act(ops.conv3x3(xb, w, bias, res, 1), gamma, beta, groups, 1e-5, True, cb)
+    zb.backward(g)
+    close(xa.grad, xb.grad.double().cpu().numpy(), TOL[dt], "gradient through the pair")
+    # another channel-bias tensor (or group count) than the producer was told: the statistics are not used
+    other = dev(hashrand.normalish((B, Cout), 168), T)
+    with ops.census_scope() as cs:
+        ops.group_norm_act(ya, gamma, beta, groups, 1e-5, True, other)
+    assert not any(k[0] == "group_norm_apply" for k in cs.launches)
