@@ -284,7 +284,7 @@ def kernel_work(key):
         return "hbm", (5 if flag else 4) * esz * N
     if kind.startswith("group_norm"):
         elems = B * N * D  # here H = groups, N = pixels, D = channels
-        return "hbm", esz * elems * (2 if kind == "group_norm_fwd" else 3)
+        return "hbm", esz * elems * (3 if kind == "group_norm_bwd" else 2)   # _fwd and _apply (statistics from the producer): x in, y out
     C = H * D
     if kind == "attn_capture_fwd":
         return "hbm", esz * (2 * B * N * C + 2 * B * Kt * C + (B * H * N * Kt if flag else 0))

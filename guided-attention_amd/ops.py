@@ -249,6 +249,12 @@ def replay_launch_us(key, iters=100):
             def fn():
                 check(lib.ga_group_norm_fwd(_ptr(x), None, _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(ws), B, HW, C,
                                             groups, 1e-5, int(flag), code, stream_ptr()), "replay gn fwd")
+        elif kind == "group_norm_apply":   # Kt = partial blocks per image (the producing convolution's epilogue left them)
+            partials = torch.rand(B, Kt, groups, 2, device=dev) * (HW * C // groups) / Kt
+
+            def fn():
+                check(lib.ga_group_norm_apply(_ptr(x), None, _ptr(w), _ptr(b_), _ptr(y), _ptr(stats), _ptr(partials), Kt, B, HW,
+                                              C, groups, 1e-5, int(flag), code, stream_ptr()), "replay gn apply")
         else:
             def fn():
                 check(lib.ga_group_norm_bwd(_ptr(x), None, _ptr(dy), _ptr(w), _ptr(b_), _ptr(stats), None, _ptr(y), _ptr(ws), B,

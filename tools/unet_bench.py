@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """GPU time of the three captured passes of the guided-attention loop for the SD-1.x UNet (hipGraph replay,
 so host launch cost is excluded): guidance forward + loss (B=1, autograd), its backward to the latents, and
-the CFG forward (B=2), the batch-3 joint pass.  usage: unet_bench.py [truncated] [nhwc-off] [benchmark] [only=eval|grad|cfg|joint]"""
+the CFG forward (B=2), the batch-3 joint pass.  usage: unet_bench.py [truncated] [nhwc-off] [benchmark] [only=eval|grad|cfg|joint]
+A/B arms (same box, one call): [no-gn-producer] the convolutions' epilogues leave no GroupNorm statistics (every large-level norm
+takes its own statistics launch, as before round 4); [no-stream] the Linear layers never take the persistent stream form."""
 import sys
 from pathlib import Path
 
@@ -30,6 +32,11 @@ def replay_ms(graph, n=10):
 
 
 def main():
+    from guided_attention_amd import ops
+    if "no-gn-producer" in sys.argv:
+        ops.gn_two_launch = lambda *a, **k: False
+    if "no-stream" in sys.argv:
+        ops.linear_stream_serves = lambda *a, **k: False
     if "benchmark" in sys.argv:
         torch.backends.cudnn.benchmark = True  # MIOpen: exhaustive find instead of the default heuristic pick
     with torch.device("cuda"):
