@@ -299,7 +299,7 @@ def pmc_traffic(kernel, model, shape):
     (profiles/r2_pmc_traffic_<model>.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes with
     the gfx950 corrections of MI355X_MICROARCH.md applied by tools/pmc_summary.py).  None when no PMC profile of that
     kernel AND shape is committed — the field is never filled from another model's or another shape's run."""
-    for rnd in ("r3", "r2"):      # this round's PMC run; round 2's for kernels that have not changed since
+    for rnd in ("r4", "r3", "r2"):      # this round's PMC run; earlier rounds' for kernels that have not changed since
         try:
             doc = json.loads((ROOT / "profiles" / f"{rnd}_pmc_traffic_{model}.json").read_text())
             for k in doc["kernels"]:

@@ -73,7 +73,7 @@ elif kind == "lin":
     ops.prepare_device(torch.device(dev, torch.cuda.current_device()))
     torch.cuda.synchronize()
     for _ in range(reps):
-        ops.linear_fused(x, w, bias, residual=res, geglu=bool(flags & 1), ln=ln)
+        ops.linear_fused(x, w, None if ln is not None else bias, residual=res, geglu=bool(flags & 1), ln=ln)   # (the fold's shift carries the bias)
 else:
     raise SystemExit(f"unknown kernel kind {kind}")
 torch.cuda.synchronize()

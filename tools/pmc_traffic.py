@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HBM traffic per launch of the hand-written kernels at the benched model's dominant shapes ->
-gpurun_out/r3_pmc_traffic_<model>.json (copy to profiles/; bench.py's roofline.traffic reads it).
+gpurun_out/r4_pmc_traffic_<model>.json (copy to profiles/; bench.py's roofline.traffic reads it).
 
 For every (kernel, shape) two rocprofv3 runs of tools/kernel_once.py — FETCH_SIZE and WRITE_SIZE cannot share a pass —
 each with --kernel-trace only and the program directly after `--`.  This driver never touches the GPU itself (plain
@@ -52,9 +52,9 @@ CASES = {
         ("ga_conv3x3", ["conv", 3, 640, 1024, 1, 640], dict(B=3, H=640, N=1024, D=640), conv_bytes(3, 640, 1024, 1, 640), "conv"),
         ("ga_conv3x3", ["conv", 3, 320, 4096, 1, 320], dict(B=3, H=320, N=4096, D=320), conv_bytes(3, 320, 4096, 1, 320), "conv"),
         ("ga_conv3x3", ["conv", 1, 1280, 64, 1, 1280], dict(B=1, H=1280, N=64, D=1280), conv_bytes(1, 1280, 64, 1, 1280), "conv"),
-        ("ga_linear", ["lin", 12288, 320, 2560, 3], dict(B=12288, H=320, N=0, D=2560), lin_bytes(12288, 320, 2560, 3), "linear_kernel"),
-        ("ga_linear", ["lin", 4096, 320, 960, 2], dict(B=4096, H=320, N=0, D=960), lin_bytes(4096, 320, 960, 2), "linear_kernel"),
-        ("ga_linear", ["lin", 256, 5120, 1280, 4], dict(B=256, H=5120, N=0, D=1280), lin_bytes(256, 5120, 1280, 4), "linear_kernel"),
+        ("ga_linear", ["lin", 12288, 320, 2560, 3], dict(B=12288, H=320, N=0, D=2560), lin_bytes(12288, 320, 2560, 3), "linear_"),
+        ("ga_linear", ["lin", 4096, 320, 960, 2], dict(B=4096, H=320, N=0, D=960), lin_bytes(4096, 320, 960, 2), "linear_"),
+        ("ga_linear", ["lin", 256, 5120, 1280, 4], dict(B=256, H=5120, N=0, D=1280), lin_bytes(256, 5120, 1280, 4), "linear_"),
         ("ga_self_attn_fwd", ["sa_fwd", 3, 8, 4096, 40], dict(B=3, H=8, N=4096, D=40), sa_bytes(3, 8, 4096, 40, False), "self_attn_fwd"),
         ("ga_self_attn_fwd", ["sa_fwd", 1, 8, 4096, 40], dict(B=1, H=8, N=4096, D=40), sa_bytes(1, 8, 4096, 40, False), "self_attn_fwd"),
         ("ga_self_attn_bwd", ["sa_bwd", 1, 8, 4096, 40], dict(B=1, H=8, N=4096, D=40), sa_bytes(1, 8, 4096, 40, True), "self_attn_bwd"),
@@ -123,7 +123,7 @@ def main():
                                "hbm_bytes_corrected": hbm, "ratio_to_algorithmic": round(hbm / alg, 2),
                                "per_symbol_KB": {"fetch": vals["FETCH_SIZE_kernels"], "write": vals["WRITE_SIZE_kernels"]}})
         print(entry, shape, "alg", alg, "measured", hbm, f"x{hbm / alg:.2f}", flush=True)
-    dst = ROOT / "gpurun_out" / f"r3_pmc_traffic_{model}.json"
+    dst = ROOT / "gpurun_out" / f"r4_pmc_traffic_{model}.json"
     dst.parent.mkdir(exist_ok=True)
     dst.write_text(json.dumps(doc, indent=1))
     print("wrote", dst)
