@@ -457,29 +457,11 @@ __device__ __forceinline__ void store_colsT(T* __restrict__ base, size_t row_str
 // at batch 1 this is the old head-fastest order (one head per XCD); with 5 / 10 / 20 heads (SD-2.x, SDXL) it replaces
 // an order that smeared every head over all eight L2s (PMC: 9x the algorithmic bytes fetched past L2).  Placement is a
 // speed matter only: nothing depends on which XCD a workgroup really lands on.
-// Round 4: ADJACENT HEADS SHARE AN XCD.  With head size 40 a head's slice of a row is 80 bytes: the 8 heads of a 640-byte row
-// touch 1 + 2 + 1 + 2 + 2 + 1 + 2 + 1 = 12 cache lines of 128 bytes where the row has 5 — with one head per XCD every L2 fetched
-// its head's lines whole, 2.4 x the bytes of each swept operand (the 3.13 x of the backward pair and 2.10 x of the forward in
-// profiles/r3_pmc_traffic_sd15.json).  A group of g adjacent heads (g = 2, 4: as many as keep the group's K and V inside half an
-// L2) now shares g XCDs, each XCD taking 1 / g of EVERY head's tiles: the lines two neighbours share are fetched once per L2
-// (8 lines per row at g = 2, 6 at g = 4).  The pair-major work list is re-ordered (group, tile chunk, head in group, tile in
-// chunk); XCD x still takes the contiguous range [x * W/8, (x+1) * W/8) of it.
-__device__ __forceinline__ int heads_per_l2(int H, int N, int D, int ntile, int esz) {
-  int g = 1;
-  while (g < 4 && (g * D * esz) % 128 != 0 && H % (2 * g) == 0 && ntile % (2 * g) == 0 &&
-         (long long)(2 * g) * 2 * N * D * esz <= (2LL << 20))
-    g *= 2;
-  return g;
-}
-__device__ __forceinline__ void decode_block(int H, int ntile, int& b, int& head, int& tile, int N = 0, int D = 0, int esz = 2) {
+__device__ __forceinline__ void decode_block(int H, int ntile, int& b, int& head, int& tile) {
   const unsigned W = gridDim.x, bid = blockIdx.x, cpx = W >> 3;
   const unsigned j = bid < (cpx << 3) ? (bid & 7u) * cpx + (bid >> 3) : bid;
-  const unsigned g = N > 0 ? (unsigned)heads_per_l2(H, N, D, ntile, esz) : 1u;
-  const unsigned per_group = g * (unsigned)ntile, grp = j / per_group, r = j - grp * per_group;
-  const unsigned tc = (unsigned)ntile / g;                  // tiles per chunk
-  const unsigned chunk = r / (unsigned)ntile, r2 = r - chunk * (unsigned)ntile, hin = r2 / tc;
-  tile = (int)(chunk * tc + (r2 - hin * tc));
-  const unsigned pair = grp * g + hin;
+  const unsigned pair = j / (unsigned)ntile;
+  tile = (int)(j - pair * (unsigned)ntile);
   head = (int)(pair % (unsigned)H);
   b = (int)(pair / (unsigned)H);
 }
@@ -547,7 +529,7 @@ __global__ __launch_bounds__(64 * NW) void self_attn_fwd_kernel(const T* __restr
   T* const lds = reinterpret_cast<T*>(smem);
 
   int b, head, qt;
-  decode_block(H, nqt, b, head, qt, N, D, (int)sizeof(T));
+  decode_block(H, nqt, b, head, qt);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq;     // row stride of Q / K / V (H*D, or 3*H*D when they are slices of a fused QKV)
   const size_t rso = (size_t)H * D;  // row stride of O
@@ -742,7 +724,7 @@ __global__ __launch_bounds__(64 * NW) void self_attn_fwd_pipe_kernel(const T* __
   T* const vring = kring + 2 * kKimg;            // [2][kVimg]
 
   int b, head, qt;
-  decode_block(H, nqt, b, head, qt, N, D, (int)sizeof(T));
+  decode_block(H, nqt, b, head, qt);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq, rso = (size_t)H * D;
   const T* Qb = Q + (size_t)b * N * rs + (size_t)head * D;
@@ -974,7 +956,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dq_kernel(const T* __r
   constexpr int kVoff = row_img<T, NK, KT>(), kToff = 2 * row_img<T, NK, KT>();
   constexpr int kBuf = NBUF == 2 ? 2 * row_img<T, NK, KT>() + col_img<T, NK, KT>() : 0;
   int b, head, qt;
-  decode_block(H, nqt, b, head, qt, N, D, (int)sizeof(T));
+  decode_block(H, nqt, b, head, qt);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq, rso = (size_t)H * D;
   const size_t off = (size_t)b * N * rs + (size_t)head * D;    // into Q / K / V / dQ
@@ -1160,7 +1142,7 @@ __global__ __launch_bounds__(kThreads) void self_attn_bwd_dkdv_kernel(const T* _
   float* const stats = reinterpret_cast<float*>(lds + NBUF * kOne);  // [2][2][KT]: (LSE, delta) per buffer
   constexpr int kSbuf = 2 * KT;
   int b, head, ktile;
-  decode_block(H, nkt, b, head, ktile, N, D, (int)sizeof(T));
+  decode_block(H, nkt, b, head, ktile);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const size_t rs = (size_t)ldq, rso = (size_t)H * D;
   const size_t off = (size_t)b * N * rs + (size_t)head * D;    // into Q / K / V / dK / dV

@@ -22,7 +22,7 @@ echo "[2] bench under rocprofv3 --kernel-trace (3 timed images)"
 rm -rf /tmp/ev_trace
 rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_trace -o b -- python3 bench.py --steps 3 --warmup 1 --no-roofline --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err || exit 1
 trace=$(find /tmp/ev_trace -name "*kernel_trace.csv" | head -1)
-python tools/trace_window_stats.py $trace 1 3 52 $out/kernel_stats_top.md "Round 3 - python bench.py --steps 3 --warmup 1 (1x MI355X, fp16): kernel time inside the three TIMED images only" > $out/trace_window.log 2>&1 || { tail -5 $out/trace_window.log; exit 1; }
+python tools/trace_window_stats.py $trace 1 3 52 $out/kernel_stats_top.md "Round 4 - python bench.py --steps 3 --warmup 1 (1x MI355X, fp16): kernel time inside the three TIMED images only" > $out/trace_window.log 2>&1 || { tail -5 $out/trace_window.log; exit 1; }
 python tools/gap_report.py $trace between=cfg_ddim,53,208 > $out/gap_report.txt 2>&1 || true
 head -12 $out/kernel_stats_top.md
 fi
@@ -48,6 +48,6 @@ for m in ("sd21_768", "sdxl"):
 PY
 fi
 if want pmc; then
-echo "[6] PMC traffic"; for m in sd15 sd21 sdxl; do python tools/pmc_traffic.py $m > $out/pmc_traffic_$m.log 2>&1 && cp gpurun_out/r3_pmc_traffic_$m.json $out/ || tail -3 $out/pmc_traffic_$m.log; echo "   $m done"; done
+echo "[6] PMC traffic"; for m in sd15 sd21 sdxl; do python tools/pmc_traffic.py $m > $out/pmc_traffic_$m.log 2>&1 && cp gpurun_out/r4_pmc_traffic_$m.json $out/ || tail -3 $out/pmc_traffic_$m.log; echo "   $m done"; done
 fi
 echo done
