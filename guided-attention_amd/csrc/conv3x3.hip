@@ -1078,32 +1078,23 @@ Plan choose_plan(int M, int N, int steps, int H, int W, int stride) {
   return best;
 }
 
-// GA_CONV_DMA=0 in the environment keeps the register-staged weight path of the patch kernel (A/B runs)
-inline bool use_dma() {
-  static const bool v = [] {
-    const char* e = getenv("GA_CONV_DMA");
-    return e == nullptr || e[0] != '0';
-  }();
-  return v;
-}
-
-// GA_CONV_DEEP=0: never the 64 KB weight ring (A/B runs)
-inline bool deep_ring() {
-  static const bool v = [] {
-    const char* e = getenv("GA_CONV_DEEP");
-    return e == nullptr || e[0] != '0';
-  }();
-  return v;
-}
-
-// GA_CONV_V1=1 in the environment keeps every shape on the per-tap staging kernel (A/B runs of tools/conv_tune.py)
-inline bool force_v1() {
-  static const bool v = [] {
-    const char* e = getenv("GA_CONV_V1");
-    return e != nullptr && e[0] == '1';
-  }();
-  return v;
-}
+// Build-time switches of the A/B harness (tools/conv_tune.py builds variant libraries with -D...; the product library takes the
+// defaults — round 3 read these from the environment at run time):
+//   GA_CONV_DMA  1: weights through the LDS-DMA ring (conv3x3_patch_dma_kernel); 0: the register-staged patch kernel
+//   GA_CONV_DEEP 1: the 64 KB weight ring for the weight-bound launches; 0: never
+//   GA_CONV_V1   1: every shape on the per-tap staging kernel
+#ifndef GA_CONV_DMA
+#define GA_CONV_DMA 1
+#endif
+#ifndef GA_CONV_DEEP
+#define GA_CONV_DEEP 1
+#endif
+#ifndef GA_CONV_V1
+#define GA_CONV_V1 0
+#endif
+constexpr bool use_dma() { return GA_CONV_DMA != 0; }
+constexpr bool deep_ring() { return GA_CONV_DEEP != 0; }
+constexpr bool force_v1() { return GA_CONV_V1 != 0; }
 
 template <typename T, int BM, int BN>
 int launch_tile(const T* X, const T* Wp, T* Y, float* ws, unsigned* tickets, const T* bias, const T* residual,

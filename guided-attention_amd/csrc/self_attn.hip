@@ -1360,13 +1360,9 @@ constexpr size_t kLdsLimit = 160 * 1024;
 //             (384 workgroups of 86 KB LDS = two rounds of one per CU), B<=2 CB=1 better
 //   backward  4096x40: B=1 CB=1 236 / CB=2 245
 // Hence CB = 2 from 192 column-block pairs per launch in the forward, from 512 in the backward.
-inline long long env_threshold(const char* name, long long dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoll(v) : dflt;
-}
 template <int NK>
 bool wide_columns(int B, int H, int N, bool backward) {
-  static const long long bwd_min = env_threshold("GA_SA_BWD_WIDE_MIN", 512), fwd_min = env_threshold("GA_SA_FWD_WIDE_MIN", 192);
+  constexpr long long bwd_min = 512, fwd_min = 192;   // (round 3 read these from the environment for the A/B runs: +-0.5 % either way)
   return NK <= 5 && (long long)B * H * ((N + 127) / 128) >= (backward ? bwd_min : fwd_min);
 }
 

@@ -67,6 +67,7 @@ class GuidedAttention:
         # syncs and host I/O; hipGraph replay is bypassed for such a run).  config.diagnostic_level > 0 switches them on
         # as well.  Off by default, never inside a timed benchmark region.
         self.reference_side_effects = False
+        self.library_kernels = frozenset()   # see .to()
         # With hipGraphs, inside the iterative refinement: enqueue an iteration's backward, latent update and the NEXT guidance
         # evaluation before reading the iteration's loss table back.  Nothing is speculative about WHAT runs — the update is
         # unconditional whenever the loss is not exactly 0 (reference :551), and whatever the threshold test says afterwards the
@@ -135,14 +136,15 @@ class GuidedAttention:
             # transposes) and the fused NHWC GroupNorm(+SiLU) HIP kernels in every norm layer
             self.unet.to(memory_format=torch.channels_last)
             self.unet.set_norm_impl(ops.group_norm_act)
-            import os
-            conv = ops.conv3x3 if os.environ.get("GA_LIBRARY_CONV", "0") != "1" else None   # GA_LIBRARY_CONV=1: MIOpen
-            # GA_LIBRARY_LINEAR=1: the transformer blocks' Linear layers stay on hipBLASLt with separate LayerNorm / GEGLU /
-            # add launches (A/B runs); default: ga_linear_fused with those folded in (16-bit dtypes; fp32 keeps the library)
+            # `library_kernels` (A/B runs and the own-vs-library tests set it before .to()): the kinds named there — "conv",
+            # "linear", "cat" — stay on MIOpen / hipBLASLt + the separate LayerNorm, GEGLU and add launches / torch.cat; default:
+            # the package's own kernels for all three (16-bit dtypes; fp32 keeps the library)
             from . import fused_linear
-            linear = fused_linear if os.environ.get("GA_LIBRARY_LINEAR", "0") != "1" else None
+            lib = set(self.library_kernels)
+            conv = None if "conv" in lib else ops.conv3x3
+            linear = None if "linear" in lib else fused_linear
             ops.prepare_device(self.unet.device)   # split-K slabs / tickets exist before any hipGraph capture
-            cat = ops.cat_channels if os.environ.get("GA_LIBRARY_CAT", "0") != "1" else None   # GA_LIBRARY_CAT=1: torch.cat (A/B runs)
+            cat = None if "cat" in lib else ops.cat_channels
             self.unet.set_fused_impl(ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm), conv, linear, cat)
             # MIOpen's exhaustive search (cudnn.benchmark) stays OFF.  It executes every candidate solver once per shape, and a
             # candidate of the backward-data search for conv_in (4 <- 64 channels, 32 x 32, fp16) reads past its operands: a GPU

@@ -9,7 +9,6 @@ Every attention layer dispatches to an *attention processor* with the reference'
 The default processor is the HIP one (no CPU fallback).
 """
 import math
-import os
 from dataclasses import dataclass, field
 from types import SimpleNamespace
 from typing import Optional, Tuple, Union
@@ -128,9 +127,11 @@ class Attention(nn.Module):
         return proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask)
 
 
-# A/B switches for measurements (tools/unet_bench.py): GA_FUSE_UPSAMPLE=0 / GA_GN_ALIAS=0 restore the separate launches
-_FUSE_UPSAMPLE = os.environ.get("GA_FUSE_UPSAMPLE", "1") != "0"
-_GN_ALIAS = os.environ.get("GA_GN_ALIAS", "1") != "0"
+# Measured in round 3 (profiles/r3_*), on since: Upsample2D as one launch (the patch gather reads the half-size map) and the
+# GroupNorm backward adding the skip connection's gradient itself.  Module attributes, not environment switches: an A/B run
+# sets them from its own script (tools/unet_bench.py).
+_FUSE_UPSAMPLE = True
+_GN_ALIAS = True
 
 
 class GroupNormAct(nn.GroupNorm):

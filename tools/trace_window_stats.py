@@ -19,7 +19,7 @@ def cat(n):
     if "conv3x3_patch" in n: return "ga conv3x3 (patch variants)"
     if "conv3x3_kernel" in n: return "ga conv3x3 (per-tap variant)"
     if "conv_pack" in n: return "ga conv weight pack"
-    if "linear_kernel" in n: return "ga Linear (LayerNorm / GEGLU / residual folded in)"
+    if "linear_kernel" in n or "linear_stream_kernel" in n: return "ga Linear (LayerNorm / GEGLU / residual folded in)"
     if n.startswith("Cijk") or n.startswith("Custom_Cijk"): return "hipBLASLt GEMM"
     if "igemm" in n or "ck16tensor" in n or "ck::" in n or "naive_conv" in n or "Conv" in n: return "MIOpen/CK conv"
     if "self_attn" in n: return "ga self-attention"
