@@ -135,6 +135,31 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
   return v;
 }
 
+// Cross-lane sums on the VALU (DPP), not through the LDS crossbar.  `__shfl_xor(x, o, 64)` compiles to ds_bpermute_b32 + a wait:
+// the three-step row sum behind every output vector of linear_kernel's epilogue was 24 dependent LDS round trips per thread (128 x
+// 64 tile with row partial sums: 1.8 us of a 6.4 us workgroup, tools/micro/lin_stamps.py); the same adds as DPP operands cost a
+// few cycles.  group_sum<W>: every lane gets the sum over its aligned group of W adjacent lanes (W = 2 ... 16, inside a row of
+// 16); wave_sum: the sum over the 64 lanes in every lane (rows combined by row_bcast, read back from lane 63).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_src(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
+}
+template <int W>
+__device__ __forceinline__ float group_sum(float x) {
+  static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16, "aligned groups inside a DPP row");
+  if constexpr (W >= 2) x += dpp_src<0xB1>(x);    // quad_perm [1, 0, 3, 2]
+  if constexpr (W >= 4) x += dpp_src<0x4E>(x);    // quad_perm [2, 3, 0, 1]
+  if constexpr (W >= 8) x += dpp_src<0x141>(x);   // row_half_mirror: lane i <- lane 7 - i of its half row (the other quad's sum)
+  if constexpr (W >= 16) x += dpp_src<0x140>(x);  // row_mirror: lane i <- lane 15 - i (the other half row's sum)
+  return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+  x = group_sum<16>(x);
+  x += dpp_src<0x142, 0xa>(x);                     // row_bcast:15 into rows 1 and 3
+  x += dpp_src<0x143, 0xc>(x);                     // row_bcast:31 into rows 2 and 3: row 3 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
 inline int check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? GA_OK : GA_ERR_LAUNCH;

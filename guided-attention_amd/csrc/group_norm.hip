@@ -149,11 +149,8 @@ __device__ __forceinline__ void fold_partials(const float* __restrict__ partial,
       sa += in ? v[i].x : 0.f;
       sc += in ? v[i].y : 0.f;
     }
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-      sa += __shfl_xor(sa, o, 64);
-      sc += __shfl_xor(sc, o, 64);
-    }
+    sa = group_sum<8>(sa);   // (DPP adds: ga_common.h)
+    sc = group_sum<8>(sc);
     if (part == 0 && g < G) {
       float o0, o1;
       if (FWD) {
@@ -696,8 +693,8 @@ constexpr int kSmallIters = 24;
 template <int NT>
 __device__ __forceinline__ void block_sum2(float& a, float& c, float* red) {
   constexpr int NW = NT / 64;
-  a = wave_reduce_sum(a);
-  c = wave_reduce_sum(c);
+  a = wave_sum(a);   // DPP adds (ga_common.h): the six-step shuffle butterflies were twelve dependent LDS-crossbar round trips
+  c = wave_sum(c);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     red[wave] = a;

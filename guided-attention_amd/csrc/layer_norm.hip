@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kThreads) void add_ln_fwd_kernel(const T* __restric
       for (int e = 0; e < N; ++e) f[k][e] = 0.f;
     }
   }
-  const float mean = wave_reduce_sum(sum) / (float)C;
+  const float mean = wave_sum(sum) / (float)C;   // (DPP adds, ga_common.h)
   float sq = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k)
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kThreads) void add_ln_fwd_kernel(const T* __restric
         sq += d * d;
       }
     }
-  const float rstd = rsqrtf(wave_reduce_sum(sq) / (float)C + eps);
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
   if (stats != nullptr && lane == 0) {
     stats[row * 2] = mean;
     stats[row * 2 + 1] = rstd;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void add_ln_bwd_kernel(const T* __restric
       s1 += in ? dh[k][e] * xh[k][e] : 0.f;
     }
   }
-  const float m0 = wave_reduce_sum(s0) / (float)C, m1 = wave_reduce_sum(s1) / (float)C;
+  const float m0 = wave_sum(s0) / (float)C, m1 = wave_sum(s1) / (float)C;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int j = lane + 64 * k;

@@ -314,7 +314,7 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
   constexpr int OUTC = GEGLU ? BN / 2 : BN;       // columns of Y this tile writes
   constexpr int VPR = OUTC / 8;                   // 16-byte vectors per output row
   constexpr int NV = BM * VPR / kThreads;
-  static_assert((VPR & (VPR - 1)) == 0 && VPR <= 64, "the row reduction below shuffles inside a wave");
+  static_assert((VPR & (VPR - 1)) == 0 && VPR <= 16, "the row reduction below adds inside a DPP row");
   const int n_out = GEGLU ? a.F : a.N;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -359,11 +359,8 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
           s2 += x * x;
         }
       }
-#pragma unroll
-      for (int o = VPR >> 1; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
-      }
+      s1 = group_sum<VPR>(s1);   // DPP adds (ga_common.h); the shuffles this replaces were 6 dependent ds_bpermute round trips per vector
+      s2 = group_sum<VPR>(s2);
       if ((v & (VPR - 1)) == 0 && m < a.M)
         *reinterpret_cast<float2*>(p.row_partials_out + ((size_t)m * a.tn + nt) * 2) = float2{s1, s2};
     }
@@ -767,13 +764,6 @@ __device__ __forceinline__ void lds_write64(unsigned byte_address, f32x2 v) {
 #endif
 }
 
-// x + (x of the lanes whose id differs in bit 0, then bit 1): DPP quad permutes, no LDS traffic
-__device__ __forceinline__ float quad_sum(float x) {
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));   // [1,0,3,2]
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));   // [2,3,0,1]
-  return x;
-}
-
 template <typename T>
 __device__ __forceinline__ f32x2 pack4(float a, float b, float c, float d) {   // four results as 8 bytes of T
   typename Traits<T>::frag f;
@@ -904,8 +894,8 @@ __global__ __launch_bounds__(kSThreads, 2) void linear_stream_kernel(
       s1 += (first ? v[u][0] : 0.f) + (in ? v[u][2] : 0.f);
       s2 += (first ? v[u][1] : 0.f) + (in ? v[u][3] : 0.f);
     }
-    s1 = quad_sum(s1);
-    s2 = quad_sum(s2);
+    s1 = group_sum<4>(s1);
+    s2 = group_sum<4>(s2);
     const float mean = s1 * a_in.ln_inv_k;
     const float rstd = rsqrtf(fmaxf(s2 * a_in.ln_inv_k - mean * mean, 0.f) + a_in.ln_eps);
     if (sub == 0) lds_write64(lds0 + kSStatOff + (unsigned)(row * 8), f32x2{mean, rstd});
