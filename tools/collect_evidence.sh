@@ -47,6 +47,19 @@ for m in ("sd21_768", "sdxl"):
         print("   ", m, "failed", e)
 PY
 fi
+if want variants; then
+echo "[5b] W-every-step and the truncated guidance forward"
+python bench.py --workload every-step --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_every_step.json 2> $out/bench_every_step.err || true
+python bench.py --guidance-forward truncated --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_truncated_guidance_forward.json 2> $out/bench_truncated.err || true
+python - <<'PY'
+import json
+for m in ("every_step", "truncated_guidance_forward"):
+    try:
+        d = json.load(open(f"gpurun_out/ev/bench_{m}.json")); print("   ", m, d["value"], d["ms_per_step"], d["unet_calls_per_image"])
+    except Exception as e:
+        print("   ", m, "failed", e)
+PY
+fi
 if want pmc; then
 echo "[6] PMC traffic"; for m in sd15 sd21 sdxl; do python tools/pmc_traffic.py $m > $out/pmc_traffic_$m.log 2>&1 && cp gpurun_out/r4_pmc_traffic_$m.json $out/ || tail -3 $out/pmc_traffic_$m.log; echo "   $m done"; done
 fi
