@@ -270,6 +270,8 @@ def kernel_work(key):
         return "hbm", esz * B * D * (4 if flag else 3)
     if kind == "conv3x3":                            # B, H = Cin, N = H*W, Kt = stride, D = Cout: 2 * M * 9 Cin * Cout
         return "mfma", 2.0 * B * (N // (Kt * Kt)) * 9 * H * D
+    if kind in ("conv3x3_thin_in", "conv3x3_thin_out"):   # conv_in / conv_out: H = Cin, N = H*W, D = Cout: x in, y out
+        return "hbm", esz * B * N * (H + D)
     if kind == "linear":                             # B = M, H = K, D = N (rows of W): 2 M K N whatever is folded in
         return "mfma", 2.0 * B * H * D
     if kind in ("aggregate_maps", "aggregate_loss_fwd"):   # H = head-maps in all, N = pixels, Kt = context tokens: maps in, A out

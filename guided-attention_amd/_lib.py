@@ -13,7 +13,7 @@ import torch
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("GA_HIP_LIB", _HERE / "libga_hip.so"))
 
-GA_VERSION = 150   # the GA_VERSION of include/ga_hip.h these prototypes were written for (tests/test_abi.py compares the two)
+GA_VERSION = 160   # the GA_VERSION of include/ga_hip.h these prototypes were written for (tests/test_abi.py compares the two)
 GA_F16, GA_BF16, GA_F32 = 0, 1, 2
 GA_LINEAR_STREAM = 8   # `stages` of ga_linear_fused: the persistent one-workgroup-per-CU form (include/ga_hip.h)
 GA_TOK_COOR, GA_TOK_BOX = 0, 1
@@ -75,6 +75,11 @@ PROTOTYPES = {
     "ga_bias_residual_add": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "ga_cat_channels": [_vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "ga_conv3x3_packed_elems": [_i, _i],
+    "ga_conv3x3_thin_packed_elems": [_i, _i],
+    "ga_conv3x3_thin_supported": [_i, _i, _i, _i],
+    "ga_conv3x3_thin_pack": [_vp, _vp, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp],
+    "ga_conv3x3_thin_in": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ga_conv3x3_thin_out": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ga_conv3x3_pack_weights": [_vp, _vp, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp],
     "ga_conv3x3_plan": [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i),
                         ctypes.POINTER(ctypes.c_longlong)],
@@ -114,7 +119,7 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name == "ga_strerror" else
-                          ctypes.c_longlong if name in ("ga_splitk_workspace_floats", "ga_conv3x3_packed_elems") else ctypes.c_int)
+                          ctypes.c_longlong if name in ("ga_splitk_workspace_floats", "ga_conv3x3_packed_elems", "ga_conv3x3_thin_packed_elems") else ctypes.c_int)
         _lib = lib
     return _lib
 

@@ -147,6 +147,18 @@ def replay_launch_us(key, iters=100):
             ws, tickets = splitk_workspace(dev, B * ho * wo, cout, bm, bn, splits)   # the scratch of the stream fn runs on
             check(lib.ga_conv3x3_nhwc(_ptr(x), _ptr(wp), _ptr(y), _ptr(ws), _ptr(tickets), _ptr(bias), _ptr(res), B, side_len,
                                       hw // side_len, cin, cout, stride, bm, bn, splits, code, stream_ptr()), "replay conv")
+    elif kind in ("conv3x3_thin_in", "conv3x3_thin_out"):   # key = (kind, B, Cin, H*W, 1, Cout, bias?, dtype)
+        cin, hw, cout = H, N, D
+        side_len = int(round(hw ** 0.5))
+        w = torch.randn(cout, cin, 3, 3, device=dev, dtype=dtype) * (9 * cin) ** -0.5
+        wp = conv3x3_thin_packed_weights(w, False)
+        bias = torch.randn(cout, device=dev, dtype=dtype) if flag else None
+        x = torch.randn(B, cin, side_len, hw // side_len, device=dev, dtype=dtype)
+        if cin != 4:
+            x = x.contiguous(memory_format=torch.channels_last)
+
+        def fn():
+            conv3x3_thin(x, wp, cout, bias)
     elif kind in ("geglu_fwd", "geglu_bwd", "bias_residual_add", "add_layer_norm_fwd", "add_layer_norm_bwd"):
         rows, C = B, D
         code = dtype_code(torch.empty(0, dtype=dtype))
@@ -1261,6 +1273,92 @@ class _Conv3x3Gn(Conv3x3):
 
 conv3x3.supported = conv3x3_supported
 conv3x3.upsample = upsample_conv3x3
+
+
+# --------------------------------------------------------------------------------------- conv_in / conv_out (one side 4 channels)
+_thin_pack_cache = {}
+
+
+def conv3x3_thin_supported(x, weight, stride=1):
+    """The UNet's edge convolutions (csrc/thin_conv.hip): 3x3, stride 1, 4 channels in or 4 channels out, 16-bit, W % 16 == 0."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == x.dtype
+            and tuple(weight.shape[2:]) == (3, 3) and stride == 1 and x.shape[1] == weight.shape[1]):
+        return False
+    cout, cin = weight.shape[0], weight.shape[1]
+    if min(cin, cout) != 4 or max(cin, cout) % 64 != 0:     # both ways round: the backward is the other kernel
+        return False
+    lib = load()
+    return bool(lib.ga_conv3x3_thin_supported(x.shape[2], x.shape[3], cin, cout) and
+                lib.ga_conv3x3_thin_supported(x.shape[2], x.shape[3], cout, cin))
+
+
+def conv3x3_thin_packed_weights(weight, transpose_flip):
+    """ga_conv3x3_thin_pack of a (Cout, Cin, 3, 3) weight, cached per (storage, version) like conv3x3_packed_weights."""
+    key = (weight.data_ptr(), weight._version, weight.dtype, bool(transpose_flip), tuple(weight.stride()), tuple(weight.shape))
+    entry = _thin_pack_cache.get(key)
+    hit = entry[1] if entry is not None and entry[0]() is weight else None
+    if hit is None:
+        require_cuda(weight)
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        hit = torch.empty(int(load().ga_conv3x3_thin_packed_elems(Cout, Cin)), dtype=weight.dtype, device=weight.device)
+        so, si, sy, sx = weight.stride()
+        check(load().ga_conv3x3_thin_pack(_ptr(weight), _ptr(hit), Cout, Cin, so, si, sy, sx, int(bool(transpose_flip)),
+                                          dtype_code(weight), stream_ptr()), "ga_conv3x3_thin_pack")
+        if len(_thin_pack_cache) > 64:   # graphs read the packs by raw pointer: only a dead weight's entry may go
+            for dead in [k for k, (ref, _) in _thin_pack_cache.items() if ref() is None]:
+                del _thin_pack_cache[dead]
+        _thin_pack_cache[key] = (weakref.ref(weight), hit)
+    return keep_alive(hit)
+
+
+def conv3x3_thin(x, wp, cout, bias=None):
+    """x (B, 4, H, W) dense NCHW -> (B, cout, H, W) channels-last, or x (B, C, H, W) channels-last -> (B, 4, H, W) dense NCHW
+    (cout == 4); wp from conv3x3_thin_packed_weights."""
+    require_cuda(x, wp, bias)
+    B, Cin, H, W = x.shape
+    if bias is not None:
+        bias = bias.to(x.dtype).contiguous()
+    if Cin == 4:
+        x = x.contiguous()
+        y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _count(("conv3x3_thin_in", B, 4, H * W, 1, cout, bias is not None, str(x.dtype)))
+        check(load().ga_conv3x3_thin_in(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), B, H, W, cout, dtype_code(x), stream_ptr()),
+              "ga_conv3x3_thin_in")
+        return y
+    if cout != 4:
+        raise GaError(f"conv3x3_thin serves 4 -> C and C -> 4 channels, got {Cin} -> {cout}")
+    x = _nhwc(x)
+    y = torch.empty((B, 4, H, W), dtype=x.dtype, device=x.device)
+    _count(("conv3x3_thin_out", B, Cin, H * W, 1, 4, bias is not None, str(x.dtype)))
+    check(load().ga_conv3x3_thin_out(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), B, H, W, Cin, dtype_code(x), stream_ptr()),
+          "ga_conv3x3_thin_out")
+    return y
+
+
+class Conv3x3Thin(torch.autograd.Function):
+    """y = conv2d(x, weight, bias, padding=1) for the UNet's conv_in / conv_out.  Differentiable w.r.t. x: the adjoint of the
+    4 -> C kernel is the C -> 4 kernel on the transposed, mirrored pack and the other way round; the weights are frozen."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
+            raise GaError("convolution weight gradients are not part of the guided-attention path (frozen UNet)")
+        ctx.weight = weight
+        return conv3x3_thin(x, conv3x3_thin_packed_weights(weight, False), weight.shape[0], bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        weight = ctx.weight
+        return conv3x3_thin(gy, conv3x3_thin_packed_weights(weight, True), weight.shape[1]), None, None
+
+
+def conv3x3_thin_apply(x, weight, bias=None):
+    return Conv3x3Thin.apply(x, weight, bias)
+
+
+conv3x3_thin_apply.supported = conv3x3_thin_supported
 
 
 # --------------------------------------------------------------------------------------- tiled self-attention

@@ -146,16 +146,17 @@ class GuidedAttention:
             ops.prepare_device(self.unet.device)   # split-K slabs / tickets exist before any hipGraph capture
             cat = None if "cat" in lib else ops.cat_channels
             self.unet.set_fused_impl(ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm), conv, linear, cat)
+            # conv_in / conv_out and conv_in's backward to the latents: own kernels (csrc/thin_conv.hip) with the "conv" kind
+            self.unet.edge_conv_impl = (ops.conv3x3_thin_apply if conv is not None and
+                                        self.unet.dtype in (torch.float16, torch.bfloat16) else None)
             # MIOpen's exhaustive search (cudnn.benchmark) stays OFF.  It executes every candidate solver once per shape, and a
             # candidate of the backward-data search for conv_in (4 <- 64 channels, 32 x 32, fp16) reads past its operands: a GPU
             # memory access fault that killed the process whenever the tensors happened to sit at the end of a mapped segment
             # (round 4, deterministic in `pytest tests/test_pipeline_gpu.py`, the worker thread in a native autograd node:
             # profiles/r4_fault_half_precision_graphs_wide.log; round 3 had seen "the fp32 96x96 backward-data search abort
-            # the process once").  Only conv_in / conv_out and the three stride-2 backward convolutions are still on the
-            # library; the search stays on for the two FORWARD ones only, scoped to their calls (unet._edge_conv): with it off
-            # everywhere the bench lost 1 % (522.8 against 517.9 ms per image, same box: profiles/r4_ab_miopen_search.txt).
+            # the process once").  Only the three stride-2 backward convolutions (and the edge convolutions of shapes the own
+            # kernels do not serve) are still on the library.
             torch.backends.cudnn.benchmark = False
-            self.unet.search_edge_convs = self.unet.dtype in (torch.float16, torch.bfloat16)
         return self
 
     @property

@@ -731,16 +731,14 @@ class UNet2DConditionModel(nn.Module):
         x = self._edge_conv(self.conv_out, self.conv_norm_out(x))
         return UNetOutput(sample=x) if return_dict else (x,)
 
-    # conv_in / conv_out (4 channels on one side) are the two FORWARD convolutions left on the library.  True (set by the GPU
-    # pipeline for the 16-bit dtypes): MIOpen times its candidate kernels for these two calls only — the flag is scoped to
-    # the forward call, so the backward-data convolutions (conv_in's, the stride-2 ones) keep the library's default choice:
-    # their search executed a candidate that reads past its operands (pipeline_guided_attention.py:to).
-    search_edge_convs = False
+    # conv_in / conv_out (4 channels on one side): ops.conv3x3_thin_apply (csrc/thin_conv.hip), installed by the GPU pipeline
+    # for the 16-bit dtypes; None, or a shape it does not serve (map width not a multiple of 16): the library convolution.
+    edge_conv_impl = None
 
     def _edge_conv(self, conv, x):
-        if self.search_edge_convs and x.is_cuda:
-            with torch.backends.cudnn.flags(benchmark=True):
-                return conv(x)
+        impl = self.edge_conv_impl
+        if impl is not None and impl.supported(x, conv.weight, conv.stride[0]):
+            return impl(x, conv.weight, conv.bias)
         return conv(x)
 
     # ---- weights

@@ -27,12 +27,14 @@ extern "C" {
  * was written for BEFORE its first call (guided-attention_amd/_lib.py:load does) — a stale binding passes pointers in the
  * wrong positions.  History:
  *   120  0.1.2  strict bbox mode, paint-with-words entry points
+ *   160  0.1.6  new: ga_conv3x3_thin_in, ga_conv3x3_thin_out, ga_conv3x3_thin_pack, ga_conv3x3_thin_packed_elems,
+ *               ga_conv3x3_thin_supported (the UNet's conv_in / conv_out and their adjoints)
  *   150  0.1.5  new: ga_conv3x3_nhwc_gn, ga_conv3x3_gn_blocks, ga_group_norm_apply, ga_group_norm_two_launch
  *   140  0.1.4  ga_linear_fused: stages = GA_LINEAR_STREAM (persistent form); no signature changed
  *   130  0.1.3  (round 3, bumped late) ga_conv3x3_nhwc / ga_gemm_nt gained `tickets` behind `workspace`, ga_group_norm_bwd
  *               gained `g_res` before `dx`; new: ga_aggregate_loss_fwd, ga_linear_fused, ga_linear_workspace,
  *               ga_splitk_workspace_floats, ga_conv3x3_up2x_nhwc, ga_cat_channels, ga_conv3x3_packed_elems */
-#define GA_VERSION 150
+#define GA_VERSION 160
 
 typedef void* ga_stream_t; /* hipStream_t */
 
@@ -317,6 +319,29 @@ int ga_conv3x3_nhwc_gn(const void* X, const void* Wp, void* Y, float* workspace,
 int ga_conv3x3_up2x_nhwc(const void* X, const void* Wp, void* Y, float* workspace, unsigned* tickets, const void* bias,
                          const void* residual, int B, int H, int W, int Cin, int Cout, int bm, int bn, int splits, int dtype,
                          ga_stream_t stream);
+
+/* The UNet's two edge convolutions, 3x3, padding 1, stride 1, one side four channels wide (diffusers 0.12.1
+ * UNet2DConditionModel.conv_in: latents -> block_out_channels[0], conv_out: the reverse; called through the UNet forward from
+ * pipeline_guided_attention.py:647-738; the reference runs them through cuDNN).  Each is the other's adjoint, so the pair also
+ * serves their backward-to-input passes (conv_in's carries the guidance gradient to the latents, pipeline…:_update_latent).
+ * Not matrix-core work: one pass over the wide tensor bounds both (HBM).  16-bit types; W % 16 == 0.
+ *   ga_conv3x3_thin_supported : 1 when (H, W, Cin, Cout) is served: Cin == 4 and Cout % 4 == 0 (64 ... 4096), or Cout == 4 and
+ *                               Cin % 64 == 0 (64 ... 320).
+ *   ga_conv3x3_thin_pack      : W [Cout][Cin][3][3] with the given ELEMENT strides -> pairs of input channels per 32-bit word,
+ *                               [tap][input pair][output] (ga_conv3x3_thin_packed_elems(Cout, Cin) elements of T).
+ *                               transpose_flip = 1: the adjoint's weights (outputs and inputs exchanged, taps mirrored), e.g.
+ *                               conv_in's [320][4][3][3] packed for ga_conv3x3_thin_out computes conv_in's backward to its input.
+ *   ga_conv3x3_thin_in        : X [B][4][H][W] (NCHW, dense: the latents as the pipeline holds them) -> Y [B][H][W][Cout] (+ bias)
+ *   ga_conv3x3_thin_out       : X [B][H][W][Cin] -> Y [B][4][H][W] (NCHW, dense) (+ bias [4] or NULL)
+ */
+long long ga_conv3x3_thin_packed_elems(int Cout, int Cin);
+int ga_conv3x3_thin_supported(int H, int W, int Cin, int Cout);
+int ga_conv3x3_thin_pack(const void* W, void* Wp, int Cout, int Cin, long long stride_o, long long stride_i, long long stride_y,
+                         long long stride_x, int transpose_flip, int dtype, ga_stream_t stream);
+int ga_conv3x3_thin_in(const void* X, const void* Wp, const void* bias, void* Y, int B, int H, int W, int Cout, int dtype,
+                       ga_stream_t stream);
+int ga_conv3x3_thin_out(const void* X, const void* Wp, const void* bias, void* Y, int B, int H, int W, int Cin, int dtype,
+                        ga_stream_t stream);
 
 /* Linear layers / 1x1 convolutions of the UNet (diffusers 0.12.1 CrossAttention.to_q/to_k/to_v/to_out, FeedForward,
  * Transformer2DModel.proj_in/proj_out, ResnetBlock2D.conv_shortcut — called from pipeline_guided_attention.py:647-738

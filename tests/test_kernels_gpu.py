@@ -943,6 +943,62 @@ def test_conv3x3_implicit_gemm(ops, shape, dt):
     assert not ops.conv3x3_supported(x.float(), w.float(), stride)      # fp32 stays on the library path
 
 
+THIN_SHAPES = [   # B, wide channels, H, W: the three configurations' top-level maps at batch 1 / 3, small ragged cases
+    (1, 320, 64, 64), (3, 320, 64, 64), (2, 320, 96, 96), (1, 320, 128, 128), (2, 64, 5, 16), (3, 128, 7, 48), (1, 192, 3, 32),
+    (2, 256, 74, 112),   # 1036 segments: workgroups that take two of them
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", THIN_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_edge_convolutions_thin_kernels(ops, shape, dt):
+    """ga_conv3x3_thin_in / _out (the UNet's conv_in: 4 -> C from dense NCHW latents to channels-last; conv_out: C -> 4 back to
+    dense NCHW) and their autograd wrapper — each kernel is the other's backward — against torch's conv2d in fp64 on the CPU."""
+    B, C, H, W = shape
+    conv = torch.nn.functional.conv2d
+    tol = TOL[dt] * 2
+    # 4 -> C
+    x = dev(hashrand.normalish((B, 4, H, W), 81 + C), DT[dt])
+    w = dev(hashrand.normalish((C, 4, 3, 3), 82) * (1.0 / 6.0), DT[dt])
+    bias = dev(hashrand.normalish((C,), 83) * 0.3, DT[dt])
+    gy = dev(hashrand.normalish((B, C, H, W), 84), DT[dt]).contiguous(memory_format=torch.channels_last)
+    assert ops.conv3x3_thin_supported(x, w)
+    xr = x.double().cpu().requires_grad_(True)
+    yr = conv(xr, w.double().cpu(), bias.double().cpu(), padding=1)
+    yr.backward(gy.double().cpu())
+    xa = x.clone().requires_grad_(True)
+    ops.start_census()
+    y = ops.conv3x3_thin_apply(xa, w.contiguous(memory_format=torch.channels_last), bias)   # the strides the UNet holds
+    y.backward(gy)
+    census = ops.stop_census()
+    assert y.shape == (B, C, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    close(y, yr.detach().numpy(), tol, "4 -> C forward")
+    close(xa.grad, xr.grad.numpy(), tol * 2, "4 -> C backward to the input")
+    assert xa.grad.is_contiguous()
+    assert {k[0]: n for k, n in census.items()} == {"conv3x3_thin_in": 1, "conv3x3_thin_out": 1}
+    close(ops.conv3x3_thin_apply(x, w, None), conv(x.double().cpu(), w.double().cpu(), None, padding=1).numpy(), tol, "no bias")
+    # C -> 4
+    x = dev(hashrand.normalish((B, C, H, W), 85), DT[dt]).contiguous(memory_format=torch.channels_last)
+    w = dev(hashrand.normalish((4, C, 3, 3), 86) * (1.0 / math.sqrt(9 * C)), DT[dt])
+    bias = dev(hashrand.normalish((4,), 87) * 0.3, DT[dt])
+    gy = dev(hashrand.normalish((B, 4, H, W), 88), DT[dt])
+    assert ops.conv3x3_thin_supported(x, w)
+    xr = x.double().cpu().requires_grad_(True)
+    yr = conv(xr, w.double().cpu(), bias.double().cpu(), padding=1)
+    yr.backward(gy.double().cpu())
+    xa = x.clone().requires_grad_(True)
+    y = ops.conv3x3_thin_apply(xa, w.contiguous(memory_format=torch.channels_last), bias)
+    y.backward(gy)
+    assert y.shape == (B, 4, H, W) and y.is_contiguous()
+    close(y, yr.detach().numpy(), tol, "C -> 4 forward")
+    close(xa.grad, xr.grad.numpy(), tol * 2, "C -> 4 backward to the input")
+    # a dense-NCHW 320-channel input is taken as well (one layout copy), fp32 and maps the kernels do not tile stay on the library
+    close(ops.conv3x3_thin_apply(x.contiguous(), w, bias), yr.detach().numpy(), tol, "C -> 4 from NCHW")
+    assert not ops.conv3x3_thin_supported(x.float(), w.float())
+    assert not ops.conv3x3_thin_supported(x[..., :W - 4], w)
+    assert not ops.conv3x3_thin_supported(x, w, 2)
+
+
 GEMM_SHAPES = [(200, 64, 72, 1), (4096, 320, 320, 1), (768, 1280, 640, 4), (130, 192, 264, 3)]   # M, K, N, splits
 
 
