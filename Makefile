@@ -21,14 +21,17 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/ga_hip.h
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--no-undefined -o $@ $(OBJS)
 
-# Diagnostic library (never the product): linear.hip with in-kernel clock stamps at its phase boundaries, the other objects as
-# they are — tools/micro/lin_stamps.py loads it through GA_HIP_LIB.
+# Diagnostic libraries (never the product): linear.hip / conv3x3.hip with in-kernel clock stamps at their phase boundaries, the
+# other objects as they are — tools/micro/lin_stamps.py and conv_stamps.py load them through GA_HIP_LIB.
 STAMPLIB := tools/micro/libga_stamps.so
+CSTAMPLIB := tools/micro/libga_conv_stamps.so
 stamps: $(OBJS)
 	$(HIPCC) $(HIPFLAGS) -DGA_LIN_STAMPS -c $(CSRC)/linear.hip -o tools/micro/linear_stamps.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--no-undefined -o $(STAMPLIB) $(filter-out $(CSRC)/linear.o,$(OBJS)) tools/micro/linear_stamps.o
+	$(HIPCC) $(HIPFLAGS) -DGA_CONV_STAMPS -c $(CSRC)/conv3x3.hip -o tools/micro/conv_stamps.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--no-undefined -o $(CSTAMPLIB) $(filter-out $(CSRC)/conv3x3.o,$(OBJS)) tools/micro/conv_stamps.o
 
 clean:
-	rm -f $(OBJS) $(LIB) $(STAMPLIB) tools/micro/linear_stamps.o
+	rm -f $(OBJS) $(LIB) $(STAMPLIB) $(CSTAMPLIB) tools/micro/linear_stamps.o tools/micro/conv_stamps.o
 
 .PHONY: all clean stamps

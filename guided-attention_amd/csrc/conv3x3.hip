@@ -773,6 +773,49 @@ __global__ __launch_bounds__(kThreads, WIDE && BN > 64 ? 1 : 2) void conv3x3_pat
 //   * every LDS access inside the loop is inline asm: a C++ LDS load or store makes the compiler wait vmcnt(0) first (any
 //     pending LDS-DMA may alias it as far as its wait-count pass can tell) and the ring would drain at every step.
 // The patch staging (registers -> padded rows) and the epilogue are the kernel's above.
+// Diagnostic build only (-DGA_CONV_STAMPS, `make stamps`; tools/micro/conv_stamps.py): wave 0 of every workgroup of
+// conv3x3_patch_dma_kernel reads the shader clock at its phase boundaries and adds up, over its k-steps, the time in front of the
+// step barrier, in the refill issue, in the MFMA body and in the patch hand-over.  The fences forbid overlaps the product has:
+// read shares.
+#if defined(GA_CONV_STAMPS)
+__device__ unsigned long long* g_conv_stamps = nullptr;   // [workgroup][12]
+struct ConvStamps {
+  unsigned long long t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last = 0;
+  __device__ __forceinline__ unsigned long long now() {
+    unsigned long long v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    return v;
+  }
+  __device__ __forceinline__ unsigned long long real() {
+    unsigned long long v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    return v;
+  }
+  __device__ __forceinline__ void at(int i) { t[i] = last = now(); }
+  __device__ __forceinline__ void add(int i) {   // time since the previous stamp goes to sum i
+    const unsigned long long v = now();
+    t[i] += v - last;
+    last = v;
+  }
+  __device__ __forceinline__ void flush() {
+    if (threadIdx.x == 0 && g_conv_stamps != nullptr)
+      for (int i = 0; i < 12; ++i) g_conv_stamps[(size_t)blockIdx.x * 12 + i] = t[i];
+  }
+};
+#define GA_CSTAMP(x) x
+#else
+#define GA_CSTAMP(x) ((void)0)
+#endif
+
 __device__ __forceinline__ void conv_lds_read128(u32x4_t& dst, unsigned byte_address) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(byte_address) : "memory");
@@ -783,6 +826,17 @@ __device__ __forceinline__ void conv_lds_read128(u32x4_t& dst, unsigned byte_add
 __device__ __forceinline__ void conv_lds_write128(unsigned byte_address, u32x4_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("ds_write_b128 %0, %1" ::"v"(byte_address), "v"(v) : "memory");
+#endif
+}
+// The counted vmcnt waits below assume the ISSUE ORDER written in the source: a refill's DMA pieces, THEN the patch loads.  The patch
+// loads are plain (side-effect-free) buffer loads, which the compiler may move: in a variant of this loop (round 4, the step barrier
+// moved in front of the last sub-step) it put them BETWEEN the two DMA pieces of the refill — piece 1 became younger than the patch
+// loads, the wait for "everything but (PD - 1) refills and the patch loads" no longer covered it, and the n half that piece fills
+// was read before it had landed (64 x 64 tile with many k-slices: one launch in two wrong, tools/micro/conv_debug.py).  The
+// shipped loop happened to come out in source order; an empty asm that clobbers memory now pins it.
+__device__ __forceinline__ void conv_order_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::: "memory");
 #endif
 }
 template <int N>
@@ -825,6 +879,11 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+#if defined(GA_CONV_STAMPS)
+  ConvStamps stm;
+  stm.t[8] = stm.real();
+  stm.at(0);
+#endif
   int m0, n0, split;
   conv_args_resident(a);
   tile_of_workgroup<BM, BN>(a, m0, n0, split);
@@ -975,10 +1034,12 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
     // prologue: patch of the first chunk (registers -> LDS), weights of its first PD steps into ring slots 0 .. PD - 1
 #pragma unroll
     for (int t = 0; t < PD; ++t) issue_w(c_begin, t, t);   // first: they need the tile's n0 only
+    conv_order_fence();
     patch_offsets();
     load_patch(c_begin);
     store_patch();                 // the compiler waits for rp[] itself (the youngest loads: the DMAs above have landed by then)
     conv_wait_lgkmcnt<0>();
+    GA_CSTAMP(stm.at(1));
     int s = 0;                     // global step counter of this workgroup: ring slot = s % NW
     for (int c = c_begin; c < c_end; ++c) {
       const int cn = min(c + 1, c_end - 1);   // next chunk (clamped: loaded again and never used after the last one)
@@ -990,24 +1051,40 @@ __global__ __launch_bounds__(kThreads, WIDE || DEEP ? 1 : 2) void conv3x3_patch_
         if (t >= 1 && t <= PD) conv_wait_vmcnt<(PD - 1) * IPW + kPatchInFlight>();
         else conv_wait_vmcnt<(PD - 1) * IPW>();
         __builtin_amdgcn_s_barrier();   // step s's weights (and, at tap 0, the patch) are in LDS for everyone; step s - 1 is read
+        GA_CSTAMP(stm.add(2));
         {  // refill the slot step s - 1 occupied with step s + PD
           const int tt = t + PD;
           if (tt < 9) issue_w(c, tt, (s + PD) % NW);
           else issue_w(cn, tt - 9, (s + PD) % NW);
         }
+        conv_order_fence();
         if (t == 0) load_patch(cn);
+        conv_order_fence();
+        GA_CSTAMP(stm.add(3));
         mma_tap(s % NW, t / 3, t % 3);
+        GA_CSTAMP(stm.add(4));
         ++s;
       }
       // every wave is past tap 8 of this chunk after the barrier: the patch may be replaced
       __builtin_amdgcn_s_barrier();
       store_patch();
       conv_wait_lgkmcnt<0>();
+      GA_CSTAMP(stm.add(5));
     }
+#if defined(GA_CONV_STAMPS)
+    stm.t[6] = (unsigned long long)s;
+#endif
   }
   conv_wait_vmcnt<0>();
   __syncthreads();
+  GA_CSTAMP(stm.at(7));
   conv_epilogue<T, BM, BN, OUT_F32>(acc, lds, Y, part, tickets, bias, residual, a, m0, n0, split);
+#if defined(GA_CONV_STAMPS)
+  conv_wait_vmcnt<0>();
+  stm.at(10);
+  stm.t[9] = stm.real();
+  stm.flush();
+#endif
 }
 
 // pre-pack: W [Cout][Cin][3][3] in whatever strides the framework holds (element strides given) ->
@@ -1395,3 +1472,10 @@ extern "C" int ga_gemm_nt(const void* X, const void* W, void* Y, float* workspac
     default: return GA_ERR_DTYPE;
   }
 }
+
+#if defined(GA_CONV_STAMPS)
+extern "C" int ga_conv_set_stamps(void* buffer) {   // [workgroups of the next launches][12] u64, or NULL
+  unsigned long long* p = static_cast<unsigned long long*>(buffer);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), &p, sizeof(p)) == hipSuccess ? GA_OK : GA_ERR_LAUNCH;
+}
+#endif
