@@ -13,7 +13,7 @@ import torch
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("GA_HIP_LIB", _HERE / "libga_hip.so"))
 
-GA_VERSION = 160   # the GA_VERSION of include/ga_hip.h these prototypes were written for (tests/test_abi.py compares the two)
+GA_VERSION = 170   # the GA_VERSION of include/ga_hip.h these prototypes were written for (tests/test_abi.py compares the two)
 GA_F16, GA_BF16, GA_F32 = 0, 1, 2
 GA_LINEAR_STREAM = 8   # `stages` of ga_linear_fused: the persistent one-workgroup-per-CU form (include/ga_hip.h)
 GA_TOK_COOR, GA_TOK_BOX = 0, 1
@@ -74,6 +74,8 @@ PROTOTYPES = {
     "ga_geglu_bwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "ga_bias_residual_add": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "ga_cat_channels": [_vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "ga_cat_channels_gn_blocks": [_i, _i, _i, _i],
+    "ga_cat_channels_gn": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ga_conv3x3_packed_elems": [_i, _i],
     "ga_conv3x3_thin_packed_elems": [_i, _i],
     "ga_conv3x3_thin_supported": [_i, _i, _i, _i],

@@ -472,6 +472,55 @@ __global__ __launch_bounds__(kThreads) void gn_wide_stats_kernel(const T* __rest
   wide_fold(m, c0, c1, C, G, lds4, partial + ((size_t)b * gridDim.x + nb) * G * 2);
 }
 
+// The statistics pass fused into the PRODUCER of a norm's input where that producer is a concatenation (diffusers 0.12.1
+// UpBlock2D / CrossAttnUpBlock2D: torch.cat([hidden_states, res_hidden_states], dim=1) in front of resnet.norm1): the statistics
+// kernel above, reading its pixels from the two sources and writing the concatenated tensor on the way — ga_cat_channels and
+// gn_wide_stats_kernel as ONE launch.  Same pixel blocks, same fold order: the partial sums are bit-identical to those
+// gn_wide_stats_kernel takes from the concatenated tensor.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gn_wide_cat_stats_kernel(const T* __restrict__ a, const T* __restrict__ b2,
+                                                                     T* __restrict__ out, float* __restrict__ partial, int HW,
+                                                                     int C1, int C2, int G, int PB) {
+  __shared__ float4 lds4[kThreads];
+  const int C = C1 + C2;
+  const WideMap m(C, G);
+  const int b = blockIdx.y, nb = blockIdx.x, p0 = nb * PB, p1 = min(HW, p0 + PB);
+  float c0[8], c1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c0[j] = c1[j] = 0.f;
+  if (m.active) {
+    const int V1 = C1 >> 3, V2 = C2 >> 3;
+    const bool first = m.vec < V1;
+    const Vec8<T>* src = first ? reinterpret_cast<const Vec8<T>*>(a + (size_t)b * HW * C1) + m.vec
+                               : reinterpret_cast<const Vec8<T>*>(b2 + (size_t)b * HW * C2) + (m.vec - V1);
+    const int sv = first ? V1 : V2;
+    Vec8<T>* ob = reinterpret_cast<Vec8<T>*>(out + (size_t)b * HW * C) + m.vec;
+    Vec8<T> v[kUS];
+    int p = p0 + m.pr;
+#pragma unroll
+    for (int u = 0; u < kUS; ++u)
+      if (p + u * m.RP < p1) v[u] = src[(size_t)(p + u * m.RP) * sv];
+    for (; p < p1; p += kUS * m.RP) {
+#pragma unroll
+      for (int u = 0; u < kUS; ++u)
+        if (p + u * m.RP < p1) {
+          ob[(size_t)(p + u * m.RP) * m.VP] = v[u];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float x = Traits<T>::to_f32(v[u].v[j]);
+            c0[j] += x;
+            c1[j] += x * x;
+          }
+        }
+      const int pn = p + kUS * m.RP;
+#pragma unroll
+      for (int u = 0; u < kUS; ++u)
+        if (pn + u * m.RP < p1) v[u] = src[(size_t)(pn + u * m.RP) * sv];
+    }
+  }
+  wide_fold(m, c0, c1, C, G, lds4, partial + ((size_t)b * gridDim.x + nb) * G * 2);
+}
+
 template <typename T, bool ACT>
 __global__ __launch_bounds__(kThreads) void gn_wide_apply_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
                                                                  const T* __restrict__ gamma,
@@ -1159,6 +1208,35 @@ extern "C" int ga_group_norm_apply(const void* x, const void* chan_bias, const v
     return GA_ERR_DTYPE;
   }
 #undef GA_GN_APPLY
+  return check_launch();
+}
+
+extern "C" int ga_cat_channels_gn_blocks(int HW, int C, int G, int dtype) {
+  /* partial blocks per image ga_cat_channels_gn writes for a concatenated width C (0: not served — the consuming norm would be
+   * one launch anyway, or is not on the wide path) */
+  if (dtype == GA_F32 || HW < 1 || C < 1 || G < 1 || C % G != 0) return 0;
+  if (small_path(HW, C, G, sizeof(float)) || !wide_ok(C, G, 2)) return 0;
+  return WideGeom(HW, C).NB;
+}
+
+extern "C" int ga_cat_channels_gn(const void* a, const void* b, void* out, float* partials, int B, int HW, int C1, int C2, int G,
+                                  int dtype, ga_stream_t stream) {
+  if (!a || !b || !out || !partials) return GA_ERR_NULL;
+  if (B < 1 || HW < 1 || C1 < 8 || C2 < 8 || C1 % 8 != 0 || C2 % 8 != 0 || G < 1) return GA_ERR_SHAPE;
+  const int C = C1 + C2;
+  if (C % G != 0 || (long long)B * HW * C >= (1LL << 31)) return GA_ERR_SHAPE;
+  if (ga_cat_channels_gn_blocks(HW, C, G, dtype) == 0) return GA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15u) return GA_ERR_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const WideGeom wg(HW, C);
+  if (dtype == GA_F16)
+    hipLaunchKernelGGL(gn_wide_cat_stats_kernel<_Float16>, dim3(wg.NB, B), dim3(kThreads), 0, s, (const _Float16*)a,
+                       (const _Float16*)b, (_Float16*)out, partials, HW, C1, C2, G, wg.PBs);
+  else if (dtype == GA_BF16)
+    hipLaunchKernelGGL(gn_wide_cat_stats_kernel<bf16_t>, dim3(wg.NB, B), dim3(kThreads), 0, s, (const bf16_t*)a, (const bf16_t*)b,
+                       (bf16_t*)out, partials, HW, C1, C2, G, wg.PBs);
+  else
+    return GA_ERR_DTYPE;
   return check_launch();
 }
 

@@ -925,9 +925,43 @@ class CatChannels(torch.autograd.Function):
         return g[:, :ctx.c1], g[:, ctx.c1:]
 
 
-def cat_channels(a, b):
-    """torch.cat([a, b], dim=1); the HIP launch where cat_channels_supported, the library otherwise (CPU oracle, odd widths)."""
+class _CatChannelsGn(CatChannels):
+    """CatChannels whose launch also takes the consuming GroupNorm's statistics (ga_cat_channels_gn); what it took leaves through
+    `box` (forward-only side data without a gradient, as for _Conv3x3Gn)."""
+
+    @staticmethod
+    def forward(ctx, a, b, groups, box):
+        require_cuda(a, b)
+        a, b = _nhwc(a), _nhwc(b)
+        B, C1, H, W = a.shape
+        C2 = b.shape[1]
+        blocks = int(load().ga_cat_channels_gn_blocks(H * W, C1 + C2, groups, dtype_code(a)))
+        out = torch.empty((B, C1 + C2, H, W), dtype=a.dtype, device=a.device, memory_format=torch.channels_last)
+        partials = torch.empty((B, blocks, groups, 2), dtype=torch.float32, device=a.device)
+        check(load().ga_cat_channels_gn(_ptr(a), _ptr(b), _ptr(out), _ptr(partials), B, H * W, C1, C2, groups, dtype_code(a),
+                                        stream_ptr()), "ga_cat_channels_gn")
+        ctx.c1 = C1
+        box.append((partials, blocks))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.c1], g[:, ctx.c1:], None, None
+
+
+def cat_channels(a, b, gn_for=None):
+    """torch.cat([a, b], dim=1); the HIP launch where cat_channels_supported, the library otherwise (CPU oracle, odd widths).
+    gn_for = the group count of the GroupNorm (no channel bias) that consumes the result: where that norm would take two launches
+    this launch takes its statistics too, and the result carries them (`_ga_gn`, read by group_norm_act)."""
     if cat_channels_supported(a, b):
+        if gn_for is not None and a.dtype in (torch.float16, torch.bfloat16) and (a.shape[1] + b.shape[1]) % gn_for == 0 and \
+                gn_two_launch(a.shape[2] * a.shape[3], a.shape[1] + b.shape[1], gn_for, a.dtype) and \
+                load().ga_cat_channels_gn_blocks(a.shape[2] * a.shape[3], a.shape[1] + b.shape[1], gn_for, dtype_code(a)):
+            box = []
+            y = _CatChannelsGn.apply(a, b, gn_for, box)
+            partials, blocks = box[0]
+            y._ga_gn = {"partials": partials, "blocks": blocks, "groups": gn_for, "chan_bias": None, "shape": tuple(y.shape)}
+            return y
         return CatChannels.apply(a, b)
     return torch.cat([a, b], dim=1)
 

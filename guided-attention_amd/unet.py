@@ -449,7 +449,10 @@ class UpBlock(nn.Module):
             if n_layers is not None and i >= n_layers:
                 return x
             skip = skips.pop()
-            x = resnet(self.cat_impl(x, skip) if self.cat_impl is not None else torch.cat([x, skip], dim=1), temb_act)
+            if self.cat_impl is not None:   # the launch also takes norm1's statistics where that saves norm1 a launch
+                x = resnet(self.cat_impl(x, skip, gn_for=resnet.norm1.num_groups if resnet.norm1.impl is not None else None), temb_act)
+            else:
+                x = resnet(torch.cat([x, skip], dim=1), temb_act)
             if self.has_cross_attention:
                 x = self.attentions[i](x, context)
         if n_layers is None and self.upsamplers is not None:

@@ -27,6 +27,7 @@ extern "C" {
  * was written for BEFORE its first call (guided-attention_amd/_lib.py:load does) — a stale binding passes pointers in the
  * wrong positions.  History:
  *   120  0.1.2  strict bbox mode, paint-with-words entry points
+ *   170  0.1.7  new: ga_cat_channels_gn, ga_cat_channels_gn_blocks
  *   160  0.1.6  new: ga_conv3x3_thin_in, ga_conv3x3_thin_out, ga_conv3x3_thin_pack, ga_conv3x3_thin_packed_elems,
  *               ga_conv3x3_thin_supported (the UNet's conv_in / conv_out and their adjoints)
  *   150  0.1.5  new: ga_conv3x3_nhwc_gn, ga_conv3x3_gn_blocks, ga_group_norm_apply, ga_group_norm_two_launch
@@ -34,7 +35,7 @@ extern "C" {
  *   130  0.1.3  (round 3, bumped late) ga_conv3x3_nhwc / ga_gemm_nt gained `tickets` behind `workspace`, ga_group_norm_bwd
  *               gained `g_res` before `dx`; new: ga_aggregate_loss_fwd, ga_linear_fused, ga_linear_workspace,
  *               ga_splitk_workspace_floats, ga_conv3x3_up2x_nhwc, ga_cat_channels, ga_conv3x3_packed_elems */
-#define GA_VERSION 160
+#define GA_VERSION 170
 
 typedef void* ga_stream_t; /* hipStream_t */
 
@@ -268,6 +269,14 @@ int ga_bias_residual_add(const void* y, const void* bias, const void* residual, 
  * C1, C2 multiples of 16 / elem_bytes; pointers 16-byte aligned; rows * (C1 + C2) * elem_bytes < 32 GiB. */
 int ga_cat_channels(const void* a, const void* b, void* out, int64_t rows, int C1, int C2, int elem_bytes,
                     ga_stream_t stream);
+/* The same concatenation that ALSO leaves the GroupNorm statistics of its result for the norm layer that consumes it (the
+ * UpBlock's resnet.norm1): a [B][HW][C1], b [B][HW][C2] -> out [B][HW][C1 + C2] and per (image, pixel block, group) partial
+ * (sum, sum of squares) [B][blocks][G][2] f32, blocks = ga_cat_channels_gn_blocks(HW, C1 + C2, G, dtype) (0: not served — that
+ * norm is a single launch already, or off the wide path: use ga_cat_channels).  ga_group_norm_apply(x = out, NULL, ...,
+ * partials, blocks) then normalises without the statistics launch.  16-bit types, C1 % 8 == C2 % 8 == 0. */
+int ga_cat_channels_gn_blocks(int HW, int C, int G, int dtype);
+int ga_cat_channels_gn(const void* a, const void* b, void* out, float* partials, int B, int HW, int C1, int C2, int G, int dtype,
+                       ga_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * UNet host helper: 3x3 convolution, pad 1, stride 1 or 2, on channels-last activations as an implicit GEMM on MFMA

@@ -1314,6 +1314,57 @@ def test_linear_stream_form(ops, case, dt):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("case", [(1, 640, 320, 64, 64), (3, 320, 320, 64, 64), (2, 1280, 640, 32, 32), (1, 640, 320, 50, 64),
+                                  (2, 64, 64, 16, 16), (1, 328, 312, 64, 64)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_cat_channels_takes_the_consuming_group_norm_statistics(ops, case, dt):
+    """ga_cat_channels_gn + ga_group_norm_apply: the UpBlock's concatenation writes its result AND the per-(image, pixel block,
+    group) partial sums of it, and resnet.norm1 runs as one launch on them.  The concatenation is bit-exact torch.cat; the partial
+    sums are taken by the statistics kernel's own arithmetic in its own order, so the norm's output is BIT-IDENTICAL to the
+    two-launch ga_group_norm_fwd on the concatenated tensor (and within tolerance of fp64); the autograd wrappers with the launch
+    census and the gradient to both inputs; shapes the pair does not serve (one-launch norms) fall back without a trace."""
+    B, C1, C2, H, W = case
+    T = DT[dt]
+    groups = 32 if (C1 + C2) % 32 == 0 and (C1 + C2) // 32 >= 8 else 8
+    a = dev(hashrand.normalish((B, C1, H, W), 170 + C1), T).contiguous(memory_format=torch.channels_last)
+    b = dev(hashrand.normalish((B, C2, H, W), 171) * 1.7 + 0.4, T).contiguous(memory_format=torch.channels_last)
+    gamma = dev(hashrand.normalish((C1 + C2,), 172) * 0.3 + 1.0, T)
+    beta = dev(hashrand.normalish((C1 + C2,), 173) * 0.2, T)
+    wide = ops.gn_two_launch(H * W, C1 + C2, groups, T)
+    cat = torch.cat([a, b], dim=1)
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(cat.double().cpu(), groups, gamma.double().cpu(),
+                                                                  beta.double().cpu(), 1e-5))
+    two = ops.group_norm_act(cat.contiguous(memory_format=torch.channels_last), gamma, beta, groups, 1e-5, True)
+    aa, ba = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    with ops.census_scope() as cs:
+        y = ops.cat_channels(aa, ba, gn_for=groups)
+        z, alias = ops.group_norm_act(y, gamma, beta, groups, 1e-5, True, None, with_alias=True)
+    kinds = {k[0]: n for k, n in cs.launches.items()}
+    assert torch.equal(y, cat) and y.is_contiguous(memory_format=torch.channels_last)
+    assert (getattr(y, "_ga_gn", None) is not None) == wide
+    assert kinds.get("group_norm_apply", 0) == (1 if wide else 0) and kinds.get("group_norm_fwd", 0) == (0 if wide else 1)
+    close(z, ref.numpy(), TOL[dt] * 2, "one-launch norm on the concatenation's statistics")
+    assert torch.equal(z, two), "the fused statistics differ from the statistics kernel's"
+    if wide:
+        made = y._ga_gn
+        yg = cat.double().cpu().reshape(B, groups, -1)
+        close(made["partials"][..., 0].sum(1), yg.sum(-1).numpy(), 2e-5, "sum")
+        close(made["partials"][..., 1].sum(1), (yg * yg).sum(-1).numpy(), 2e-5, "sum of squares")
+    g = dev(hashrand.normalish((B, C1 + C2, H, W), 174), T).contiguous(memory_format=torch.channels_last)
+    g2 = dev(hashrand.normalish((B, C1 + C2, H, W), 175), T).contiguous(memory_format=torch.channels_last)
+    torch.autograd.backward([z, alias], [g, g2])
+    ab, bb = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    zb, alias_b = ops.group_norm_act(ops.cat_channels(ab, bb), gamma, beta, groups, 1e-5, True, None, with_alias=True)
+    torch.autograd.backward([zb, alias_b], [g, g2])
+    assert torch.equal(aa.grad, ab.grad) and torch.equal(ba.grad, bb.grad)
+    # another group count than the producer was told: the statistics are not used
+    if wide and (C1 + C2) % 16 == 0:
+        with ops.census_scope() as cs:
+            ops.group_norm_act(y, gamma, beta, 16, 1e-5, True)
+        assert not any(k[0] == "group_norm_apply" for k in cs.launches)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("case", [(1, 320, 320, 64, 64, True), (3, 320, 320, 64, 64, False), (2, 640, 320, 64, 64, True),
                                   (1, 960, 320, 64, 64, False), (2, 128, 256, 32, 32, True), (1, 64, 64, 16, 16, False)],
                          ids=lambda c: "x".join(map(str, c[:5])) + ("-cb" if c[5] else ""))

@@ -675,7 +675,7 @@ def test_full_width_unet_own_kernels_match_the_library(full_width, batch):
         y_own, g_own = run_once()
     assert sum(n for k, n in cs.launches.items() if k[0] == "conv3x3") > 80      # the HIP convolution really ran
     assert sum(n for k, n in cs.launches.items() if k[0] == "linear") > 100      # and the fused Linear layers
-    assert sum(n for k, n in cs.launches.items() if k[0].startswith("conv3x3_thin")) == 3   # conv_in, conv_out, conv_in's backward
+    assert sum(n for k, n in cs.launches.items() if k[0].startswith("conv3x3_thin")) == 4   # conv_in, conv_out and the backward of each
     elementwise = (ops.geglu, ops.bias_residual_add, (ops.layer_norm, ops.add_layer_norm))
     pipe.unet.set_fused_impl(*elementwise, None)
     edge, pipe.unet.edge_conv_impl = pipe.unet.edge_conv_impl, None
