@@ -75,6 +75,8 @@ PROTOTYPES = {
     "ga_bias_residual_add": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "ga_cat_channels": [_vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "ga_cat_channels_gn_blocks": [_i, _i, _i, _i],
+    "ga_group_norm_one_launch": [_i, _i, _i, _i],
+    "ga_cat_group_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ga_cat_channels_gn": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ga_conv3x3_packed_elems": [_i, _i],
     "ga_conv3x3_thin_packed_elems": [_i, _i],

@@ -770,31 +770,49 @@ __device__ __forceinline__ void block_sum2(float& a, float& c, float* red) {
 // IT = pieces per thread the launch is built for (the host takes the smallest of 4 / 8 / 12 / 24 that covers the shape): the
 // loads are unconditional with clamped addresses — a load under `if (k < iters)` into a register array came out of the
 // compiler as load, wait, copy, one at a time.
-template <typename T, bool ACT, int NT, int IT>
-__global__ __launch_bounds__(NT) void gn_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ cbias,
+template <typename T, bool ACT, int NT, int IT, bool CAT>
+// (argument order: what the first loads need — sources, sizes — inside the 16 dwords the hardware preloads into SGPRs; statistics,
+// eps and the concatenation's destination, needed behind the reduction, come from the argument segment while the slab loads fly)
+__global__ __launch_bounds__(NT) void gn_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ x2,
+                                                          const T* __restrict__ cbias, int HW, int C, int G, int C1,
                                                           const T* __restrict__ gamma, const T* __restrict__ beta,
-                                                          T* __restrict__ y, float* __restrict__ stats, int HW,
-                                                          int C, int G, float eps) {
+                                                          T* __restrict__ y, float* __restrict__ stats, float eps,
+                                                          T* __restrict__ cat) {
   extern __shared__ __attribute__((aligned(16))) char smem_small[];
   float* red = reinterpret_cast<float*>(smem_small);
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (CAT) {   // the arguments past the 16 preloaded dwords, fetched here in one batch (left alone: one round trip each, where used)
+    asm volatile("" ::"s"(stats), "s"(eps), "s"(cat));
+  }
+#endif
   const int g = blockIdx.x, b = blockIdx.y, Cg = C / G, hp = Cg >> 1;
   const int rows = NT / hp, p0 = threadIdx.x / hp, j = threadIdx.x - p0 * hp;
   const bool active = p0 < rows;
   const int ch = g * Cg + 2 * (active ? j : 0);
   const size_t base = (size_t)b * HW * C + ch;
+  // x2 != nullptr: the norm's input is the CONCATENATION of x [B][HW][C1] and x2 [B][HW][C - C1] along the channels (the UpBlock's
+  // torch.cat in front of resnet.norm1), never written before: this thread's channel pair lives in one of the two (C1 is even),
+  // and `cat` receives the concatenated tensor on the way (the shortcut GEMM and the backward read it) — ga_cat_channels and
+  // this norm as ONE launch
+  // (CAT: a template parameter — the plain norm's instruction stream stays what it was)
+  const bool second = CAT && ch >= C1;
+  const T* src = !CAT ? x + base : (second ? x2 + (size_t)b * HW * (C - C1) + (ch - C1) : x + (size_t)b * HW * C1 + ch);
+  const size_t sstride = !CAT ? (size_t)C : (size_t)(second ? C - C1 : C1);
   // no branch around any of these loads (a conditional load is waited for where it is issued): without a channel bias the
   // bias load reads a stand-in (not gamma: the compiler then re-uses gamma's register behind a wait) and a select drops it
   // the per-channel constants are requested LAST: whatever consumes one waits for everything, and everything is on its way
   Item<T, 2> xv[IT];
 #pragma unroll
-  for (int k = 0; k < IT; ++k) xv[k] = *reinterpret_cast<const Item<T, 2>*>(x + base + (size_t)min(p0 + k * rows, HW - 1) * C);
+  for (int k = 0; k < IT; ++k) xv[k] = *reinterpret_cast<const Item<T, 2>*>(src + (size_t)min(p0 + k * rows, HW - 1) * sstride);
   // gamma / beta (cold weights: the slowest of these loads) go out last and are first needed behind the block reduction, the
   // channel bias (first pass) in front of them: the first pass's wait leaves the two outstanding and the reduction runs
   // under their latency
-  const Item<T, 2> cbv = load_pair<T>(cbias != nullptr ? cbias + (size_t)b * C + ch : x + base);
+  Item<T, 2> cbv = xv[0];
+  if constexpr (!CAT) cbv = load_pair<T>(cbias != nullptr ? cbias + (size_t)b * C + ch : src);   // CAT: no channel bias
   __builtin_amdgcn_sched_barrier(0);   // gamma / beta stay the YOUNGEST loads (the scheduler moved slab loads behind them)
   const Item<T, 2> gmv = load_pair<T>(gamma + ch), btv = load_pair<T>(beta + ch);
-  const float cb0 = cbias != nullptr ? Traits<T>::to_f32(cbv.v[0]) : 0.f, cb1 = cbias != nullptr ? Traits<T>::to_f32(cbv.v[1]) : 0.f;
+  const bool has_cb = !CAT && cbias != nullptr;
+  const float cb0 = has_cb ? Traits<T>::to_f32(cbv.v[0]) : 0.f, cb1 = has_cb ? Traits<T>::to_f32(cbv.v[1]) : 0.f;
   float sa = 0.f, sc = 0.f;
 #pragma unroll
   for (int k = 0; k < IT; ++k)
@@ -828,6 +846,7 @@ __global__ __launch_bounds__(NT) void gn_small_fwd_kernel(const T* __restrict__ 
       o.v[0] = Traits<T>::from_f32(z0);
       o.v[1] = Traits<T>::from_f32(z1);
       *reinterpret_cast<Item<T, 2>*>(y + base + (size_t)p * C) = o;
+      if constexpr (CAT) *reinterpret_cast<Item<T, 2>*>(cat + base + (size_t)p * C) = xv[k];
     }
   }
 }
@@ -930,13 +949,25 @@ __global__ __launch_bounds__(NT) void gn_small_bwd_kernel(const T* __restrict__ 
 constexpr size_t kSmallHeader = 32 * sizeof(float);
 inline bool small_wide(int HW, int C, int G) { return (C / G) / 2 > 256 || HW * ((C / G) / 2) >= 2048; }
 
+struct SmallCat {        // the second source of a concatenated input and where the concatenation goes (all null / 0: plain input)
+  const void* x2 = nullptr;
+  int C1 = 0;
+  void* cat = nullptr;
+};
+
 template <typename T, bool ACT, int NT, int IT>
 int small_fwd_launch_it(const void* x, const void* cb, const void* gamma, const void* beta, void* y, float* stats, int B,
-                        int HW, int C, int G, float eps, hipStream_t s) {
+                        int HW, int C, int G, float eps, hipStream_t s, SmallCat sc) {
   const size_t lds = kSmallHeader;   // the slab stays in registers
-  auto k = gn_small_fwd_kernel<T, ACT, NT, IT>;
-  hipLaunchKernelGGL(k, dim3(G, B), dim3(NT), lds, s, (const T*)x, (const T*)cb, (const T*)gamma, (const T*)beta,
-                     (T*)y, stats, HW, C, G, eps);
+  if (sc.x2 != nullptr) {
+    auto k = gn_small_fwd_kernel<T, ACT, NT, IT, true>;
+    hipLaunchKernelGGL(k, dim3(G, B), dim3(NT), lds, s, (const T*)x, (const T*)sc.x2, (const T*)nullptr, HW, C, G, sc.C1,
+                       (const T*)gamma, (const T*)beta, (T*)y, stats, eps, (T*)sc.cat);
+  } else {
+    auto k = gn_small_fwd_kernel<T, ACT, NT, IT, false>;
+    hipLaunchKernelGGL(k, dim3(G, B), dim3(NT), lds, s, (const T*)x, (const T*)nullptr, (const T*)cb, HW, C, G, 0,
+                       (const T*)gamma, (const T*)beta, (T*)y, stats, eps, (T*)nullptr);
+  }
   return check_launch();
 }
 
@@ -948,23 +979,23 @@ inline int small_iters(int HW, int C, int G, int NT) {
 
 template <typename T, bool ACT, int NT>
 int small_fwd_launch(const void* x, const void* cb, const void* gamma, const void* beta, void* y, float* stats, int B,
-                     int HW, int C, int G, float eps, hipStream_t s) {
+                     int HW, int C, int G, float eps, hipStream_t s, SmallCat sc) {
   const int it = small_iters(HW, C, G, NT);
-  if (it <= 4) return small_fwd_launch_it<T, ACT, NT, 4>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
-  if (it <= 8) return small_fwd_launch_it<T, ACT, NT, 8>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
-  if (it <= 12) return small_fwd_launch_it<T, ACT, NT, 12>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
-  if (it <= kSmallIters) return small_fwd_launch_it<T, ACT, NT, kSmallIters>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
+  if (it <= 4) return small_fwd_launch_it<T, ACT, NT, 4>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s, sc);
+  if (it <= 8) return small_fwd_launch_it<T, ACT, NT, 8>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s, sc);
+  if (it <= 12) return small_fwd_launch_it<T, ACT, NT, 12>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s, sc);
+  if (it <= kSmallIters) return small_fwd_launch_it<T, ACT, NT, kSmallIters>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s, sc);
   return GA_ERR_SHAPE;
 }
 
 template <typename T>
 int small_fwd(const void* x, const void* cb, const void* gamma, const void* beta, void* y, float* stats, int B, int HW,
-              int C, int G, float eps, int act, hipStream_t s) {
+              int C, int G, float eps, int act, hipStream_t s, SmallCat sc = SmallCat{}) {
   if (small_wide(HW, C, G))
-    return act ? small_fwd_launch<T, true, 1024>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s)
-               : small_fwd_launch<T, false, 1024>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
-  return act ? small_fwd_launch<T, true, 256>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s)
-             : small_fwd_launch<T, false, 256>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s);
+    return act ? small_fwd_launch<T, true, 1024>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s, sc)
+               : small_fwd_launch<T, false, 1024>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s, sc);
+  return act ? small_fwd_launch<T, true, 256>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s, sc)
+             : small_fwd_launch<T, false, 256>(x, cb, gamma, beta, y, stats, B, HW, C, G, eps, s, sc);
 }
 
 template <typename T, bool ACT, int NT, int IT>
@@ -1209,6 +1240,36 @@ extern "C" int ga_group_norm_apply(const void* x, const void* chan_bias, const v
   }
 #undef GA_GN_APPLY
   return check_launch();
+}
+
+extern "C" int ga_group_norm_one_launch(int HW, int C, int G, int dtype) {
+  /* 1 when ga_group_norm_fwd runs this shape as ONE launch (a group's slab stays in registers): the norms ga_cat_group_norm_fwd serves */
+  if (HW < 1 || C < 1 || G < 1 || G > 64 || C % G != 0 || dtype < GA_F16 || dtype > GA_F32) return 0;
+  return small_path(HW, C, G, sizeof(float)) ? 1 : 0;
+}
+
+extern "C" int ga_cat_group_norm_fwd(const void* a, const void* b, void* cat, const void* gamma, const void* beta, void* y,
+                                     float* stats, int B, int HW, int C1, int C2, int G, float eps, int act_silu, int dtype,
+                                     ga_stream_t stream) {
+  /* y = [silu](group_norm(cat([a, b], channels))) AND cat itself, one launch, for the norms that are a single launch anyway (a
+   * group's slab of <= 20 480 elements: the 16 x 16 and 8 x 8 levels): GA_ERR_UNSUPPORTED for the others (ga_cat_channels_gn +
+   * ga_group_norm_apply serve those). */
+  if (!a || !b || !cat || !gamma || !beta || !y || !stats) return GA_ERR_NULL;
+  if (C1 < 2 || C2 < 2 || C1 % 2 != 0 || C2 % 2 != 0) return GA_ERR_SHAPE;
+  const int C = C1 + C2;
+  Geom g;
+  int rc = geometry(B, HW, C, G, g);
+  if (rc != GA_OK) return rc;
+  if ((C / G) % 2 != 0) return GA_ERR_SHAPE;
+  if (!small_path(HW, C, G, sizeof(float))) return GA_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const SmallCat sc{b, C1, cat};
+  switch (dtype) {
+    case GA_F16: return small_fwd<_Float16>(a, nullptr, gamma, beta, y, stats, B, HW, C, G, eps, act_silu, s, sc);
+    case GA_BF16: return small_fwd<bf16_t>(a, nullptr, gamma, beta, y, stats, B, HW, C, G, eps, act_silu, s, sc);
+    case GA_F32: return small_fwd<float>(a, nullptr, gamma, beta, y, stats, B, HW, C, G, eps, act_silu, s, sc);
+    default: return GA_ERR_DTYPE;
+  }
 }
 
 extern "C" int ga_cat_channels_gn_blocks(int HW, int C, int G, int dtype) {

@@ -776,6 +776,14 @@ class GroupNormAct(torch.autograd.Function):
             chan_bias = chan_bias.to(x.dtype).contiguous()
             if tuple(chan_bias.shape) != (B, C):
                 raise GaError(f"chan_bias must be (B, C) = {(B, C)}, got {tuple(chan_bias.shape)}")
+        if produced is not None and produced[0] == "done":     # the producing concatenation's launch ran this norm too
+            y, stats = produced[1], produced[2]
+            ctx.save_for_backward(x, weight, bias, stats, chan_bias)
+            ctx.meta = (groups, bool(act))
+            if with_alias:
+                ctx.set_materialize_grads(False)
+                return y, x.view_as(x)
+            return y
         y = torch.empty_like(x, memory_format=torch.channels_last)
         stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
         if produced is not None:
@@ -826,8 +834,17 @@ def group_norm_act(x, weight, bias, groups, eps, act, chan_bias=None, with_alias
     pre = getattr(x, "_ga_gn", None)
     produced = None
     if pre is not None and pre["groups"] == groups and pre["chan_bias"] is chan_bias and pre["shape"] == tuple(x.shape):
-        produced = (pre["partials"], pre["blocks"])
+        if "done" not in pre:
+            produced = (pre["partials"], pre["blocks"])
+        elif pre["weight"] is weight and pre["bias"] is bias and pre["eps"] == float(eps) and pre["act"] == bool(act):
+            produced = ("done",) + pre.pop("done")     # handed out once: a second norm of the same tensor launches its own
     return GroupNormAct.apply(x, weight, bias, groups, eps, act, chan_bias, with_alias, produced)
+
+
+def gn_fused_with_cat(HW, C, groups, dtype):
+    """True when ga_group_norm_fwd is ONE launch for the shape: a concatenation in front of it joins that launch."""
+    code = _lib.DTYPE_CODE.get(dtype)
+    return code is not None and (C // groups) % 2 == 0 and bool(load().ga_group_norm_one_launch(HW, C, groups, code))
 
 
 def gn_two_launch(HW, C, groups, dtype):
@@ -949,10 +966,49 @@ class _CatChannelsGn(CatChannels):
         return g[:, :ctx.c1], g[:, ctx.c1:], None, None
 
 
-def cat_channels(a, b, gn_for=None):
+class _CatGroupNorm(CatChannels):
+    """CatChannels and the GroupNorm(+SiLU) that consumes it as ONE launch (ga_cat_group_norm_fwd: the norms that are a single
+    launch anyway).  The Function's output is the concatenation; the norm's output and statistics leave through `box` and
+    GroupNormAct picks them up instead of launching (it stays the autograd node of the norm)."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, bias, groups, eps, act, box):
+        require_cuda(a, b, weight, bias)
+        a, b = _nhwc(a), _nhwc(b)
+        B, C1, H, W = a.shape
+        C2 = b.shape[1]
+        out = torch.empty((B, C1 + C2, H, W), dtype=a.dtype, device=a.device, memory_format=torch.channels_last)
+        y = torch.empty_like(out, memory_format=torch.channels_last)
+        stats = torch.empty((B, groups, 2), dtype=torch.float32, device=a.device)
+        _count(("group_norm_fwd", B, groups, H * W, 0, C1 + C2, bool(act), str(a.dtype)))
+        check(load().ga_cat_group_norm_fwd(_ptr(a), _ptr(b), _ptr(out), _ptr(weight), _ptr(bias), _ptr(y), _ptr(stats), B, H * W,
+                                           C1, C2, groups, float(eps), int(bool(act)), dtype_code(a), stream_ptr()),
+              "ga_cat_group_norm_fwd")
+        ctx.c1 = C1
+        box.append((y, stats))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.c1], g[:, ctx.c1:], None, None, None, None, None, None
+
+
+def cat_channels(a, b, gn_for=None, norm=None):
     """torch.cat([a, b], dim=1); the HIP launch where cat_channels_supported, the library otherwise (CPU oracle, odd widths).
     gn_for = the group count of the GroupNorm (no channel bias) that consumes the result: where that norm would take two launches
-    this launch takes its statistics too, and the result carries them (`_ga_gn`, read by group_norm_act)."""
+    this launch takes its statistics too, and the result carries them (`_ga_gn`, read by group_norm_act).
+    norm = (weight, bias, eps, act) of that norm: where it is a single launch anyway, concatenation and norm are ONE launch, and
+    the result carries the norm's output (`_ga_gn["done"]`) for group_norm_act to hand out."""
+    if cat_channels_supported(a, b) and gn_for is not None and norm is not None and (a.shape[1] + b.shape[1]) % gn_for == 0 and \
+            a.dtype in (torch.float16, torch.bfloat16) and norm[0].dtype == a.dtype and a.shape[1] % 2 == 0 and \
+            gn_fused_with_cat(a.shape[2] * a.shape[3], a.shape[1] + b.shape[1], gn_for, a.dtype):
+        weight, bias, eps, act = norm
+        box = []
+        y = _CatGroupNorm.apply(a, b, weight, bias, gn_for, eps, act, box)
+        out, stats = box[0]
+        y._ga_gn = {"done": (out, stats), "groups": gn_for, "chan_bias": None, "shape": tuple(y.shape), "weight": weight,
+                    "bias": bias, "eps": float(eps), "act": bool(act)}
+        return y
     if cat_channels_supported(a, b):
         if gn_for is not None and a.dtype in (torch.float16, torch.bfloat16) and (a.shape[1] + b.shape[1]) % gn_for == 0 and \
                 gn_two_launch(a.shape[2] * a.shape[3], a.shape[1] + b.shape[1], gn_for, a.dtype) and \

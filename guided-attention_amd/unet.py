@@ -450,7 +450,12 @@ class UpBlock(nn.Module):
                 return x
             skip = skips.pop()
             if self.cat_impl is not None:   # the launch also takes norm1's statistics where that saves norm1 a launch
-                x = resnet(self.cat_impl(x, skip, gn_for=resnet.norm1.num_groups if resnet.norm1.impl is not None else None), temb_act)
+                n1 = resnet.norm1
+                if n1.impl is not None:
+                    x = self.cat_impl(x, skip, gn_for=n1.num_groups, norm=(n1.weight, n1.bias, n1.eps, n1.act))
+                else:
+                    x = self.cat_impl(x, skip)
+                x = resnet(x, temb_act)
             else:
                 x = resnet(torch.cat([x, skip], dim=1), temb_act)
             if self.has_cross_attention:

@@ -27,7 +27,7 @@ extern "C" {
  * was written for BEFORE its first call (guided-attention_amd/_lib.py:load does) — a stale binding passes pointers in the
  * wrong positions.  History:
  *   120  0.1.2  strict bbox mode, paint-with-words entry points
- *   170  0.1.7  new: ga_cat_channels_gn, ga_cat_channels_gn_blocks
+ *   170  0.1.7  new: ga_cat_channels_gn, ga_cat_channels_gn_blocks, ga_cat_group_norm_fwd, ga_group_norm_one_launch
  *   160  0.1.6  new: ga_conv3x3_thin_in, ga_conv3x3_thin_out, ga_conv3x3_thin_pack, ga_conv3x3_thin_packed_elems,
  *               ga_conv3x3_thin_supported (the UNet's conv_in / conv_out and their adjoints)
  *   150  0.1.5  new: ga_conv3x3_nhwc_gn, ga_conv3x3_gn_blocks, ga_group_norm_apply, ga_group_norm_two_launch
@@ -274,6 +274,13 @@ int ga_cat_channels(const void* a, const void* b, void* out, int64_t rows, int C
  * (sum, sum of squares) [B][blocks][G][2] f32, blocks = ga_cat_channels_gn_blocks(HW, C1 + C2, G, dtype) (0: not served — that
  * norm is a single launch already, or off the wide path: use ga_cat_channels).  ga_group_norm_apply(x = out, NULL, ...,
  * partials, blocks) then normalises without the statistics launch.  16-bit types, C1 % 8 == C2 % 8 == 0. */
+/* For the norms that are ONE launch (ga_group_norm_one_launch: a group's slab of <= 20 480 elements — the 16 x 16 and 8 x 8 levels)
+ * the concatenation and the norm are one launch: y [B][HW][C1 + C2] = [silu](group_norm(cat([a, b]))) and cat [B][HW][C1 + C2]
+ * itself (the ResnetBlock's shortcut GEMM and the backward read it); statistics as ga_group_norm_fwd leaves them.
+ * GA_ERR_UNSUPPORTED for shapes whose norm takes two launches (ga_cat_channels_gn serves those). */
+int ga_group_norm_one_launch(int HW, int C, int G, int dtype);
+int ga_cat_group_norm_fwd(const void* a, const void* b, void* cat, const void* gamma, const void* beta, void* y, float* stats,
+                          int B, int HW, int C1, int C2, int G, float eps, int act_silu, int dtype, ga_stream_t stream);
 int ga_cat_channels_gn_blocks(int HW, int C, int G, int dtype);
 int ga_cat_channels_gn(const void* a, const void* b, void* out, float* partials, int B, int HW, int C1, int C2, int G, int dtype,
                        ga_stream_t stream);

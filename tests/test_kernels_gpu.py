@@ -1315,14 +1315,16 @@ def test_linear_stream_form(ops, case, dt):
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("case", [(1, 640, 320, 64, 64), (3, 320, 320, 64, 64), (2, 1280, 640, 32, 32), (1, 640, 320, 50, 64),
-                                  (2, 64, 64, 16, 16), (1, 328, 312, 64, 64)],
+                                  (2, 64, 64, 16, 16), (1, 328, 312, 64, 64), (1, 1280, 1280, 16, 16), (3, 1280, 640, 16, 16),
+                                  (2, 1280, 1280, 8, 8), (3, 640, 320, 16, 9)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_cat_channels_takes_the_consuming_group_norm_statistics(ops, case, dt):
-    """ga_cat_channels_gn + ga_group_norm_apply: the UpBlock's concatenation writes its result AND the per-(image, pixel block,
-    group) partial sums of it, and resnet.norm1 runs as one launch on them.  The concatenation is bit-exact torch.cat; the partial
-    sums are taken by the statistics kernel's own arithmetic in its own order, so the norm's output is BIT-IDENTICAL to the
-    two-launch ga_group_norm_fwd on the concatenated tensor (and within tolerance of fp64); the autograd wrappers with the launch
-    census and the gradient to both inputs; shapes the pair does not serve (one-launch norms) fall back without a trace."""
+    """The UpBlock's concatenation in front of resnet.norm1, two forms.  Norms that take two launches (64 x 64, 32 x 32 levels):
+    ga_cat_channels_gn writes the concatenation AND the per-(image, pixel block, group) partial sums of it, the norm runs as one
+    launch on them (ga_group_norm_apply).  Norms that are one launch (16 x 16, 8 x 8 levels): ga_cat_group_norm_fwd IS that launch
+    — two sources in, the norm's output and the concatenation out.  Either way the concatenation is bit-exact torch.cat and the
+    norm's output BIT-IDENTICAL to ga_group_norm_fwd on the concatenated tensor (the same arithmetic in the same order; within
+    tolerance of fp64); the autograd wrappers with the launch census and the gradients to both inputs."""
     B, C1, C2, H, W = case
     T = DT[dt]
     groups = 32 if (C1 + C2) % 32 == 0 and (C1 + C2) // 32 >= 8 else 8
@@ -1337,16 +1339,17 @@ def test_cat_channels_takes_the_consuming_group_norm_statistics(ops, case, dt):
     two = ops.group_norm_act(cat.contiguous(memory_format=torch.channels_last), gamma, beta, groups, 1e-5, True)
     aa, ba = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
     with ops.census_scope() as cs:
-        y = ops.cat_channels(aa, ba, gn_for=groups)
+        y = ops.cat_channels(aa, ba, gn_for=groups, norm=(gamma, beta, 1e-5, True))
+        made = dict(getattr(y, "_ga_gn", None) or {})
         z, alias = ops.group_norm_act(y, gamma, beta, groups, 1e-5, True, None, with_alias=True)
     kinds = {k[0]: n for k, n in cs.launches.items()}
     assert torch.equal(y, cat) and y.is_contiguous(memory_format=torch.channels_last)
-    assert (getattr(y, "_ga_gn", None) is not None) == wide
+    assert made and ("done" in made) == (not wide)        # every case here is served by one of the two forms
     assert kinds.get("group_norm_apply", 0) == (1 if wide else 0) and kinds.get("group_norm_fwd", 0) == (0 if wide else 1)
+    assert "done" not in y._ga_gn                          # handed out once
     close(z, ref.numpy(), TOL[dt] * 2, "one-launch norm on the concatenation's statistics")
     assert torch.equal(z, two), "the fused statistics differ from the statistics kernel's"
     if wide:
-        made = y._ga_gn
         yg = cat.double().cpu().reshape(B, groups, -1)
         close(made["partials"][..., 0].sum(1), yg.sum(-1).numpy(), 2e-5, "sum")
         close(made["partials"][..., 1].sum(1), (yg * yg).sum(-1).numpy(), 2e-5, "sum of squares")
@@ -1357,6 +1360,13 @@ def test_cat_channels_takes_the_consuming_group_norm_statistics(ops, case, dt):
     zb, alias_b = ops.group_norm_act(ops.cat_channels(ab, bb), gamma, beta, groups, 1e-5, True, None, with_alias=True)
     torch.autograd.backward([zb, alias_b], [g, g2])
     assert torch.equal(aa.grad, ab.grad) and torch.equal(ba.grad, bb.grad)
+    # a norm with other parameters than the concatenation was told launches its own
+    y2 = ops.cat_channels(a, b, gn_for=groups, norm=(gamma, beta, 1e-5, True))
+    with ops.census_scope() as cs:
+        z2 = ops.group_norm_act(y2, beta, gamma, groups, 1e-5, True)
+    assert {k[0] for k in cs.launches} == {"group_norm_fwd"} or wide
+    close(z2, torch.nn.functional.silu(torch.nn.functional.group_norm(cat.double().cpu(), groups, beta.double().cpu(),
+                                                                      gamma.double().cpu(), 1e-5)).numpy(), TOL[dt] * 2, "other norm")
     # another group count than the producer was told: the statistics are not used
     if wide and (C1 + C2) % 16 == 0:
         with ops.census_scope() as cs:

@@ -3,7 +3,7 @@
 so host launch cost is excluded): guidance forward + loss (B=1, autograd), its backward to the latents, and
 the CFG forward (B=2), the batch-3 joint pass.  usage: unet_bench.py [truncated] [nhwc-off] [benchmark] [only=eval|grad|cfg|joint]
 A/B arms (same box, one call): [no-gn-producer] the convolutions' epilogues leave no GroupNorm statistics (every large-level norm
-takes its own statistics launch, as before round 4); [no-stream] the Linear layers never take the persistent stream form."""
+takes its own statistics launch, as before round 4); [no-cat-norm] the small-map UpBlock concatenations as launches of their own; [no-stream] the Linear layers never take the persistent stream form."""
 import sys
 from pathlib import Path
 
@@ -35,6 +35,8 @@ def main():
     from guided_attention_amd import ops
     if "no-gn-producer" in sys.argv:
         ops.gn_two_launch = lambda *a, **k: False
+    if "no-cat-norm" in sys.argv:    # the 16 x 16 / 8 x 8 UpBlock concatenations as their own launch in front of resnet.norm1
+        ops.gn_fused_with_cat = lambda *a, **k: False
     if "no-stream" in sys.argv:
         ops.linear_stream_serves = lambda *a, **k: False
     if "benchmark" in sys.argv:
