@@ -181,6 +181,34 @@ def test_conv_plan_is_a_host_function(lib):
     assert lib.ga_conv3x3_nhwc(p, p, p, None, None, None, None, 1, 16, 16, 64, 64, 1, 96, 64, 1, 0, None) == -2   # no 96-pixel tile
 
 
+def test_round4_entry_points_validate_on_the_host(lib):
+    """The edge convolutions, the concatenation that takes / runs the consuming GroupNorm and the statistics-from-the-producer
+    pair: which shapes they serve is a host-side answer, and argument errors come back as codes without touching a device."""
+    assert lib.ga_conv3x3_thin_supported(64, 64, 4, 320) == 1 and lib.ga_conv3x3_thin_supported(64, 64, 320, 4) == 1
+    assert lib.ga_conv3x3_thin_supported(96, 96, 4, 320) == 1 and lib.ga_conv3x3_thin_supported(128, 128, 320, 4) == 1
+    assert lib.ga_conv3x3_thin_supported(24, 24, 4, 320) == 0          # map width not a multiple of 16
+    assert lib.ga_conv3x3_thin_supported(64, 64, 8, 320) == 0          # neither side four channels wide
+    assert lib.ga_conv3x3_thin_supported(64, 64, 640, 4) == 0          # more channels than the slices' registers hold
+    assert lib.ga_conv3x3_thin_packed_elems(320, 4) == 36 * 320 and lib.ga_conv3x3_thin_packed_elems(4, 320) == 36 * 320
+    p = ctypes.c_void_p(4096)
+    assert lib.ga_conv3x3_thin_in(None, p, None, p, 1, 64, 64, 320, 0, None) == -1
+    assert lib.ga_conv3x3_thin_in(p, p, None, p, 1, 64, 60, 320, 0, None) == -2
+    assert lib.ga_conv3x3_thin_out(p, p, None, p, 1, 64, 64, 320, 2, None) == -3       # fp32 stays on the library
+    assert lib.ga_conv3x3_thin_out(ctypes.c_void_p(4100), p, None, p, 1, 64, 64, 320, 0, None) == -4
+    assert lib.ga_conv3x3_thin_pack(p, p, 320, 8, 72, 9, 3, 1, 0, 0, None) == -2        # no four-channel side
+    # GroupNorm: which shapes are one launch, which two, and what the concatenation's two forms serve
+    assert lib.ga_group_norm_two_launch(4096, 320, 32, 0) == 1 and lib.ga_group_norm_one_launch(4096, 320, 32, 0) == 0
+    assert lib.ga_group_norm_two_launch(256, 2560, 32, 0) == 0 and lib.ga_group_norm_one_launch(256, 2560, 32, 0) == 1
+    assert lib.ga_cat_channels_gn_blocks(4096, 960, 32, 0) == 128 and lib.ga_cat_channels_gn_blocks(256, 2560, 32, 0) == 0
+    assert lib.ga_cat_channels_gn_blocks(4096, 960, 32, 2) == 0                          # 16-bit types only
+    assert lib.ga_cat_channels_gn(p, p, p, None, 1, 4096, 640, 320, 32, 0, None) == -1
+    assert lib.ga_cat_channels_gn(p, p, p, p, 1, 4096, 644, 316, 32, 0, None) == -2      # not whole 16-byte vectors
+    assert lib.ga_cat_channels_gn(p, p, p, p, 1, 256, 1280, 1280, 32, 0, None) == -6     # that norm is one launch: the other form
+    assert lib.ga_cat_group_norm_fwd(p, p, p, p, p, p, p, 1, 4096, 640, 320, 32, 1e-5, 1, 0, None) == -6
+    assert lib.ga_cat_group_norm_fwd(p, p, None, p, p, p, p, 1, 256, 1280, 1280, 32, 1e-5, 1, 0, None) == -1
+    assert lib.ga_conv3x3_gn_blocks(64, 64, 320, 32, 128, 64) == 64 and lib.ga_conv3x3_gn_blocks(16, 16, 1280, 32, 128, 64) == 4   # 2 slots x 2 m tiles
+
+
 def test_product_refuses_cpu_tensors():
     import torch
     from guided_attention_amd import ops
