@@ -167,20 +167,29 @@ thin_out_kernel(const T* __restrict__ x, const uint32_t* __restrict__ wp, const 
   float bv = 0.f;
   if (bias && sl < 4) bv = Traits<T>::to_f32(bias[sl]);
 
-  const int first = blockIdx.x * segs_per_wg;
-  for (int sg = first; sg < first + segs_per_wg && sg < total_segs; ++sg) {
+  // the patch of a segment: every load requested in one batch; the NEXT segment's batch goes out before this segment's arithmetic
+  // (a workgroup holds 270 registers — one per CU — so nothing else covers that round trip)
+  auto fetch = [&](int sg, uint4 (&val)[kLoads]) {
     const int seg = sg % segs, row = (sg / segs) % H, b = sg / (segs * H);
-    // the patch: every load requested before the first is written to LDS
-    uint4 val[kLoads];
 #pragma unroll
     for (int j = 0; j < kLoads; ++j) {
       const int i = tid + j * kOutThreads;
       const int v = i % kVecPx, c = (i / kVecPx) % kPatchW, r = i / (kVecPx * kPatchW);
       const int yy = row + r - 1, xx = seg * kSeg + c - 1;
-      val[j] = uint4{0u, 0u, 0u, 0u};
-      if (i < kPatchVecs && yy >= 0 && yy < H && xx >= 0 && xx < W)
-        val[j] = reinterpret_cast<const uint4*>(x + (((size_t)b * H + yy) * W + xx) * C)[v];
+      // no branch around the load (a load under `if` into a register array is waited for where it is issued): a halo
+      // position outside the image reads pixel 0 of the image and a select drops it
+      const bool in = i < kPatchVecs && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const size_t pix = in ? ((size_t)b * H + yy) * W + xx : (size_t)b * H * W;
+      const uint4 t = reinterpret_cast<const uint4*>(x + pix * C)[in ? v : 0];
+      val[j] = in ? t : uint4{0u, 0u, 0u, 0u};
     }
+  };
+  const int first = blockIdx.x * segs_per_wg;
+  const int last = min(first + segs_per_wg, total_segs);
+  uint4 val[kLoads];
+  fetch(first, val);
+  for (int sg = first; sg < last; ++sg) {
+    const int seg = sg % segs, row = (sg / segs) % H, b = sg / (segs * H);
     if (sg != first) __syncthreads();   // the previous segment's readers are done with the patch
 #pragma unroll
     for (int j = 0; j < kLoads; ++j) {
@@ -188,6 +197,7 @@ thin_out_kernel(const T* __restrict__ x, const uint32_t* __restrict__ wp, const 
       if (i < kPatchVecs) patch[i] = val[j];
     }
     __syncthreads();
+    if (sg + 1 < last) fetch(sg + 1, val);
 
     const uint32_t* pw = reinterpret_cast<const uint32_t*>(patch);
 #pragma unroll
@@ -246,9 +256,11 @@ int launch_in(const void* x, const void* wp, const void* bias, void* y, int B, i
 template <typename T>
 int launch_out(const void* x, const void* wp, const void* bias, void* y, int B, int H, int W, int C, hipStream_t s) {
   const long long total = (long long)B * H * (W / kSeg);
-  int per;
-  unsigned grid;
-  seg_grid(total, per, grid);
+  // One workgroup per CU is resident (register budget).  Up to 1024 segments (the 64 x 64 maps): 256 workgroups, each streaming
+  // its share with the next patch in flight (batch 3: 17.4 -> 15.1 us, batch 2: 12.0 -> 11.0); the larger maps measured faster
+  // as up to 1024 shorter workgroups (128 x 128 at batch 3: 42 against 50 us) — gpurun_out probes 9 and 18.
+  const int per = total <= 1024 ? (int)((total + 255) / 256) : (int)((total + 1023) / 1024);
+  const unsigned grid = (unsigned)((total + per - 1) / per);
 #define GA_THIN_OUT(P)                                                                                                   \
   case P:                                                                                                                \
     hipLaunchKernelGGL((thin_out_kernel<T, P>), dim3(grid), dim3(kOutThreads), 0, s, (const T*)x, (const uint32_t*)wp,    \
