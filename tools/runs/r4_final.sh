@@ -1,5 +1,5 @@
 #!/bin/bash
-# final tree: plain-GEMM tune (r4_gemm_tune), the full GPU suite, smoke, the default bench line
+# final tree: the full GPU suite, smoke, the default bench line (what the driver runs at the round end)
 out=gpurun_out/r4final
 mkdir -p $out
 fault() { grep -q "Memory access fault" "$1" && { echo "GPU FAULT in $1"; exit 9; }; }
@@ -10,4 +10,4 @@ kill $ticker
 tail -12 $out/gpu_suite.log; fault $out/gpu_suite.log; [ $rc -eq 0 ] || { grep -n "^E " $out/gpu_suite.log | head -20; exit $rc; }
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 || exit 1
 timeout -k 5 400 python3 bench.py > $out/bench.json 2> $out/bench.err; python3 -c "import json; d=json.load(open('$out/bench.json')); print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'])"
-timeout -k 5 500 python3 tools/linear_tune.py 3 --mode plain > $out/gemm_tune.txt 2>&1; tail -5 $out/gemm_tune.txt
+
