@@ -13,7 +13,7 @@ import torch
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("GA_HIP_LIB", _HERE / "libga_hip.so"))
 
-GA_VERSION = 170   # the GA_VERSION of include/ga_hip.h these prototypes were written for (tests/test_abi.py compares the two)
+GA_VERSION = 180   # the GA_VERSION of include/ga_hip.h these prototypes were written for (tests/test_abi.py compares the two)
 GA_F16, GA_BF16, GA_F32 = 0, 1, 2
 GA_LINEAR_STREAM = 8   # `stages` of ga_linear_fused: the persistent one-workgroup-per-CU form (include/ga_hip.h)
 GA_TOK_COOR, GA_TOK_BOX = 0, 1
@@ -41,7 +41,8 @@ class ga_linear_epilogue_t(ctypes.Structure):
                 ("geglu", ctypes.c_int32), ("preact", ctypes.c_void_p), ("ld_pre", ctypes.c_int64),
                 ("ln_partials", ctypes.c_void_p), ("ln_parts", ctypes.c_int32), ("ln_eps", ctypes.c_float),
                 ("ln_colsum", ctypes.c_void_p), ("ln_shift", ctypes.c_void_p), ("ln_stats_out", ctypes.c_void_p),
-                ("row_partials_out", ctypes.c_void_p)]
+                ("row_partials_out", ctypes.c_void_p), ("gn_partials", ctypes.c_void_p), ("gn_groups", ctypes.c_int32),
+                ("gn_hw", ctypes.c_int32)]
 
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
@@ -75,6 +76,7 @@ PROTOTYPES = {
     "ga_bias_residual_add": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "ga_cat_channels": [_vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "ga_cat_channels_gn_blocks": [_i, _i, _i, _i],
+    "ga_linear_gn_blocks": [_i, _i, _i, _i, _i],
     "ga_group_norm_one_launch": [_i, _i, _i, _i],
     "ga_cat_group_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ga_cat_channels_gn": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

@@ -90,6 +90,8 @@ struct LinPtrs {
   float* row_partials_out;   // optional [M][tn][2]
   float* slabs;              // split-K: [splits][tm * tn][BM * BN] f32, thread order
   unsigned* tickets;         // split-K: [tm * tn], zero on entry and on exit
+  float* gn_partials;        // optional: GroupNorm partial sums of the stored result for the consuming norm (see lin_epilogue)
+  int gn_cg, gn_G, gn_hw, gn_tpi;   // channels per group, groups, rows (pixels) per image, m tiles per image
 };
 
 // workgroup -> (m tile, n tile, k slice): an XCD (workgroup ids equal mod 8) owns a contiguous run of the logical order, so
@@ -316,6 +318,11 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
   constexpr int NV = BM * VPR / kThreads;
   static_assert((VPR & (VPR - 1)) == 0 && VPR <= 16, "the row reduction below adds inside a DPP row");
   const int n_out = GEGLU ? a.F : a.N;
+  // GroupNorm statistics for the norm that consumes Y (proj_out + residual in front of a ResnetBlock's norm1): per-thread sums of
+  // the values AS STORED over this thread's rows — its NV vectors share one column run (kThreads % VPR == 0) — folded through
+  // LDS in a fixed order below, exactly as conv_epilogue does (conv3x3.hip)
+  const bool gn = !GEGLU && p.gn_partials != nullptr;
+  float gsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gsq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int v = tid + k * kThreads;
@@ -348,6 +355,16 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
       }
     }
     if (ok) *reinterpret_cast<uint4*>(Y + (size_t)m * a.ldy + n) = val;
+    if constexpr (!GEGLU) {
+      if (gn && ok) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float x = Traits<T>::to_f32(e[q]);
+          gsum[q] += x;
+          gsq[q] += x * x;
+        }
+      }
+    }
     if (p.row_partials_out != nullptr) {
       // (sum, sum of squares) of the values AS STORED over this tile's columns of the row: VPR adjacent lanes hold one row
       float s1 = 0.f, s2 = 0.f;
@@ -363,6 +380,53 @@ __device__ __forceinline__ void lin_epilogue(f32x16 (&acc)[BN / 64][BM / 64], T*
       s2 = group_sum<VPR>(s2);
       if ((v & (VPR - 1)) == 0 && m < a.M)
         *reinterpret_cast<float2*>(p.row_partials_out + ((size_t)m * a.tn + nt) * 2) = float2{s1, s2};
+    }
+  }
+  if constexpr (!GEGLU) {
+    if (gn) {
+      // this thread's 8 channels lie in at most two groups (8 <= channels per group): gA takes the first `split` of them
+      const int cv = (tid & (VPR - 1)) * 8;
+      const int c_abs = n0 + cv, gA = c_abs / p.gn_cg, split = min(8, (gA + 1) * p.gn_cg - c_abs);
+      float4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (q < split) {
+          r.x += gsum[q];
+          r.y += gsq[q];
+        } else {
+          r.z += gsum[q];
+          r.w += gsq[q];
+        }
+      }
+      __syncthreads();                                   // every thread has read its rows of the staging tile
+      float4* lds4 = reinterpret_cast<float4*>(Cs);
+      lds4[tid] = r;
+      __syncthreads();
+      const int n_end = min(n0 + BN, a.N);
+      const int g_first = n0 / p.gn_cg, g_last = (n_end - 1) / p.gn_cg;
+      const int g = g_first + tid;
+      if (g <= g_last) {
+        const int c_lo = max(g * p.gn_cg, n0), c_hi = min((g + 1) * p.gn_cg, n_end);      // this tile's channels of group g
+        float sa = 0.f, sq = 0.f;
+        for (int vv = (c_lo - n0) >> 3; vv <= (c_hi - 1 - n0) >> 3; ++vv) {
+          const bool first = (n0 + 8 * vv) / p.gn_cg == g;   // g is this vector's gA, otherwise its gA + 1
+          for (int pr = 0; pr < kThreads / VPR; ++pr) {       // fixed order: the same bits whoever runs first
+            const float4 e4 = lds4[pr * VPR + vv];
+            sa += first ? e4.x : e4.z;
+            sq += first ? e4.y : e4.w;
+          }
+        }
+        // slot 2 t of m tile t: the n tile a group STARTS in; slot 2 t + 1: the n tile it continues into (zero when it does not)
+        const int b = m0 / p.gn_hw, t = (m0 - b * p.gn_hw) / BM;
+        float2* out = reinterpret_cast<float2*>(p.gn_partials) + ((size_t)b * 2 * p.gn_tpi + 2 * t) * p.gn_G + g;
+        const bool starts = g * p.gn_cg >= n0, ends = (g + 1) * p.gn_cg <= n_end;
+        if (starts) {
+          out[0] = float2{sa, sq};
+          if (ends) out[p.gn_G] = float2{0.f, 0.f};
+        } else {
+          out[p.gn_G] = float2{sa, sq};
+        }
+      }
     }
   }
 }
@@ -1117,6 +1181,17 @@ extern "C" int ga_linear_workspace(int64_t M, int N, int bm, int bn, int splits,
   return GA_OK;
 }
 
+extern "C" int ga_linear_gn_blocks(int hw, int N, int groups, int bm, int bn) {
+  /* partial blocks per image a ga_linear_fused call with gn_partials writes (2 slots per m tile: the n tile a group starts in and
+   * the one it continues into), or 0 when the shape is not served: m tiles must not straddle images, a group's channels must
+   * lie in at most two n tiles and a 16-byte vector in at most two groups */
+  if (hw < 1 || N < 8 || groups < 1 || N % groups != 0 || (bm != 64 && bm != 128) || (bn != 64 && bn != 128)) return 0;
+  const int cg = N / groups;
+  if (hw % bm != 0 || cg < 8 || cg > bn || groups > 64) return 0;
+  const int blocks = 2 * (hw / bm);
+  return blocks <= 128 ? blocks : 0;
+}
+
 extern "C" int ga_linear_fused(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, const ga_linear_epilogue_t* ep,
                                float* slabs, unsigned* tickets, int64_t M, int K, int N, int bm, int bn, int splits,
                                int stages, int dtype, ga_stream_t stream) {
@@ -1153,6 +1228,13 @@ extern "C" int ga_linear_fused(const void* X, int64_t ldx, const void* W, void* 
   p.ln_partials = ep->ln_partials; p.ln_colsum = ep->ln_colsum; p.ln_shift = ep->ln_shift;
   p.ln_stats_out = ep->ln_stats_out; p.row_partials_out = ep->row_partials_out;
   p.slabs = slabs; p.tickets = tickets;
+  p.gn_partials = nullptr; p.gn_cg = p.gn_G = p.gn_hw = p.gn_tpi = 0;
+  if (ep->gn_partials) {
+    if (ep->geglu || stages == GA_LINEAR_STREAM) return GA_ERR_UNSUPPORTED;
+    if (ga_linear_gn_blocks(ep->gn_hw, N, ep->gn_groups, bm, bn) == 0 || M % ep->gn_hw != 0) return GA_ERR_SHAPE;
+    p.gn_partials = ep->gn_partials; p.gn_G = ep->gn_groups; p.gn_cg = N / ep->gn_groups; p.gn_hw = ep->gn_hw;
+    p.gn_tpi = ep->gn_hw / bm;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (stages == GA_LINEAR_STREAM) {
     // the persistent one-workgroup-per-CU form (linear_stream_kernel): what it serves, it serves with the 128 x 128 tile only

@@ -66,10 +66,14 @@ class _Linear(torch.autograd.Function):
     """y = x W^T + b (+ residual) [, row partial sums of y].  Differentiable w.r.t. x and the residual."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, want_partials):
+    def forward(ctx, x, weight, bias, residual, want_partials, gn=None, box=None):
+        """gn = (groups, hw) and a list `box`: the epilogue also takes the GroupNorm statistics of y for the norm that consumes it;
+        what it took ((partials, blocks) or None) leaves through `box` (forward-only side data without a gradient)."""
         if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
             raise GaError("Linear weight gradients are not part of the guided-attention path (frozen UNet)")
-        out = ops.linear_fused(x, weight, bias, residual=residual, want_row_partials=want_partials)
+        out = ops.linear_fused(x, weight, bias, residual=residual, want_row_partials=want_partials, gn=gn)
+        if box is not None:
+            box.append(out["gn"])
         ctx.weight, ctx.has_res = weight, residual is not None
         partials = out["row_partials"]
         if partials is None:
@@ -81,13 +85,21 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _gp):
         if gy is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None, None
         gx = grad_input(gy, ctx.weight) if ctx.needs_input_grad[0] else None
-        return gx, None, None, (gy if ctx.has_res else None), None
+        return gx, None, None, (gy if ctx.has_res else None), None, None, None
 
 
-def linear(x, weight, bias=None, residual=None, want_partials=False):
-    """-> (y, partials or None)"""
+def linear(x, weight, bias=None, residual=None, want_partials=False, gn_for=None):
+    """-> (y, partials or None).  gn_for = (groups, hw) of the GroupNorm (no channel bias) that consumes y viewed as (B, hw, N)
+    images: where that norm would take two launches the epilogue takes its statistics and y carries them (`_ga_gn_tokens`:
+    (partials, blocks, groups) — the caller re-attaches them to the NCHW view it hands to the norm)."""
+    if gn_for is not None and ops.gn_two_launch(gn_for[1], weight.shape[0], gn_for[0], x.dtype):
+        box = []
+        y, partials = _Linear.apply(x, weight, bias, residual, want_partials, gn_for, box)
+        if box and box[0] is not None:
+            y._ga_gn_tokens = (box[0][0], box[0][1], gn_for[0])
+        return y, (partials if want_partials else None)
     y, partials = _Linear.apply(x, weight, bias, residual, want_partials)
     return y, (partials if want_partials else None)
 

@@ -1679,11 +1679,13 @@ def linear_plan(M, K, N, geglu=False, stream_ok=False):
 
 
 def linear_fused(x, weight, bias=None, residual=None, geglu=False, want_preact=False, ln=None, want_ln_stats=False,
-                 want_row_partials=False, plan=None, out=None):
+                 want_row_partials=False, plan=None, out=None, gn=None):
     """Y = epilogue(X W^T) through ga_linear_fused (see include/ga_hip.h).
     x (..., K): rows `x.stride(-2)` elements apart, last dimension contiguous; weight (N, K) contiguous.
     ln = (partials (M, parts, 2) f32, colsum (N,) f32, shift (N,) f32, eps): LayerNorm folded in front (then `weight` is
-    gamma o W and `bias` is ignored).  -> dict(y, preact, ln_stats, row_partials, parts)."""
+    gamma o W and `bias` is ignored).  gn = (groups, hw): the rows are hw pixels per image and the epilogue also leaves the
+    GroupNorm statistics of the stored result for the norm that consumes it ("gn": (partials, blocks), or None where the plan
+    or shape does not serve).  -> dict(y, preact, ln_stats, row_partials, parts, gn)."""
     require_cuda(x, weight, bias, residual)
     if x.stride(-1) != 1 or not weight.is_contiguous():
         raise GaError("linear_fused needs unit-stride feature axes")
@@ -1736,6 +1738,14 @@ def linear_fused(x, weight, bias=None, residual=None, geglu=False, want_preact=F
     if want_row_partials:
         row_partials = torch.empty((M, parts, 2), dtype=torch.float32, device=x.device)
         ep.row_partials_out = row_partials.data_ptr()
+    gn_made = None
+    if gn is not None and not geglu and stages != LINEAR_STREAM:
+        groups, hw = gn
+        blocks = int(load().ga_linear_gn_blocks(hw, N, groups, bm, bn)) if M % hw == 0 else 0
+        if blocks:
+            gn_partials = torch.empty((M // hw, blocks, groups, 2), dtype=torch.float32, device=x.device)
+            ep.gn_partials, ep.gn_groups, ep.gn_hw = gn_partials.data_ptr(), groups, hw
+            gn_made = (gn_partials, blocks)
     slabs = tickets = None
     if splits > 1:
         ws = linear_workspace(x.device)
@@ -1748,4 +1758,4 @@ def linear_fused(x, weight, bias=None, residual=None, geglu=False, want_preact=F
     _check_ticketed(load().ga_linear_fused(_ptr(x), ldx, _ptr(weight), _ptr(y), y.stride(-2) if y.dim() > 1 else n_out,
                                            ctypes.byref(ep), _ptr(slabs), _ptr(tickets), M, K, N, bm, bn, splits, stages,
                                            dtype_code(x), stream_ptr()), "ga_linear_fused", tickets)
-    return {"y": y, "preact": preact, "ln_stats": ln_stats, "row_partials": row_partials, "parts": parts}
+    return {"y": y, "preact": preact, "ln_stats": ln_stats, "row_partials": row_partials, "parts": parts, "gn": gn_made}

@@ -278,6 +278,8 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)
                                                  for _ in range(depth)])
 
+    feeds_norm = False   # set by the block that owns this layer when its result goes straight into a GroupNorm (DownBlock, UNet)
+
     def _proj_weights(self, proj):
         if self.use_linear_projection:
             return proj.weight, proj.bias
@@ -295,8 +297,15 @@ class Transformer2DModel(nn.Module):
             x, xp = lin.linear(x, *self._proj_weights(self.proj_in), want_partials=True)
             for i, blk in enumerate(blocks):
                 x, xp = blk.forward_folded(x, xp, context, want_partials=i + 1 < len(blocks))
-            x, _ = lin.linear(x, *self._proj_weights(self.proj_out), residual=nchw_to_tokens(res))
-            return tokens_to_nchw(x, h, w)
+            # proj_out's epilogue also takes the GroupNorm statistics of the block's result for the norm that consumes it (the
+            # next ResnetBlock's norm1, conv_norm_out: same group count as this block's own norm) where that norm takes two launches
+            x, _ = lin.linear(x, *self._proj_weights(self.proj_out), residual=nchw_to_tokens(res),
+                              gn_for=(self.norm.num_groups, h * w) if self.feeds_norm and self.norm.impl is not None else None)
+            made = getattr(x, "_ga_gn_tokens", None)
+            x = tokens_to_nchw(x, h, w)
+            if made is not None:
+                x._ga_gn = {"partials": made[0], "blocks": made[1], "groups": made[2], "chan_bias": None, "shape": tuple(x.shape)}
+            return x
         x = self.proj_in(x) if self.use_linear_projection else pointwise_conv_tokens(x, self.proj_in)
         for blk in self.transformer_blocks:
             x = blk(x, context)
@@ -394,6 +403,9 @@ class DownBlock(nn.Module):
                                                                 cfg.norm_num_groups, cfg.use_linear_projection, depth)
                                              for _ in range(cfg.layers_per_block)])
         self.downsamplers = nn.ModuleList([Downsample2D(out_c)]) if add_downsample else None
+        if has_attn:
+            for attn in self.attentions[:-1]:   # the next ResnetBlock's norm1 reads this layer's result directly
+                attn.feeds_norm = True
 
     def forward(self, x, temb_act, context):
         outs = []
@@ -416,6 +428,8 @@ class MidBlock(nn.Module):
                                       for _ in range(2)])
         self.attentions = nn.ModuleList([Transformer2DModel(heads, channels // heads, channels, cfg.cross_attention_dim,
                                                             cfg.norm_num_groups, cfg.use_linear_projection, depth)])
+
+        self.attentions[0].feeds_norm = True   # resnets[1].norm1 reads it directly
 
     def forward(self, x, temb_act, context):
         x = self.resnets[0](x, temb_act)
@@ -525,6 +539,9 @@ class UNet2DConditionModel(nn.Module):
         self._added_version = 0
         self.conv_norm_out = GroupNormAct(cfg.norm_num_groups, ch[0], eps=cfg.norm_eps, act=True)
         self.conv_out = nn.Conv2d(ch[0], cfg.out_channels, 3, padding=1)
+        last = self.up_blocks[-1]
+        if getattr(last, "has_cross_attention", False):
+            last.attentions[-1].feeds_norm = True      # conv_norm_out reads it directly
 
     # ---- attention-processor registry (diffusers protocol used by utils/ptp_utils.py:149-175)
     def _attention_modules(self):

@@ -27,6 +27,7 @@ extern "C" {
  * was written for BEFORE its first call (guided-attention_amd/_lib.py:load does) — a stale binding passes pointers in the
  * wrong positions.  History:
  *   120  0.1.2  strict bbox mode, paint-with-words entry points
+ *   180  0.1.8  ga_linear_epilogue_t gained gn_partials / gn_groups / gn_hw at its END; new: ga_linear_gn_blocks
  *   170  0.1.7  new: ga_cat_channels_gn, ga_cat_channels_gn_blocks, ga_cat_group_norm_fwd, ga_group_norm_one_launch
  *   160  0.1.6  new: ga_conv3x3_thin_in, ga_conv3x3_thin_out, ga_conv3x3_thin_pack, ga_conv3x3_thin_packed_elems,
  *               ga_conv3x3_thin_supported (the UNet's conv_in / conv_out and their adjoints)
@@ -35,7 +36,7 @@ extern "C" {
  *   130  0.1.3  (round 3, bumped late) ga_conv3x3_nhwc / ga_gemm_nt gained `tickets` behind `workspace`, ga_group_norm_bwd
  *               gained `g_res` before `dx`; new: ga_aggregate_loss_fwd, ga_linear_fused, ga_linear_workspace,
  *               ga_splitk_workspace_floats, ga_conv3x3_up2x_nhwc, ga_cat_channels, ga_conv3x3_packed_elems */
-#define GA_VERSION 170
+#define GA_VERSION 180
 
 typedef void* ga_stream_t; /* hipStream_t */
 
@@ -413,8 +414,16 @@ typedef struct {
   const float* ln_shift;
   float* ln_stats_out;
   float* row_partials_out;
+  /* GroupNorm statistics of the STORED result for the norm layer that consumes it (the transformer's proj_out + residual in
+   * front of the next ResnetBlock's norm1 / conv_norm_out), as ga_conv3x3_nhwc_gn leaves them: the rows are gn_hw pixels per
+   * image, gn_partials [M / gn_hw][ga_linear_gn_blocks(gn_hw, N, gn_groups, bm, bn)][gn_groups][2] f32.  NULL: none.
+   * Not with geglu; gn_hw % bm == 0, 8 <= N / gn_groups <= bn. */
+  float* gn_partials;
+  int gn_groups;
+  int gn_hw;
 } ga_linear_epilogue_t;
 
+int ga_linear_gn_blocks(int hw, int N, int groups, int bm, int bn);
 int ga_linear_workspace(int64_t M, int N, int bm, int bn, int splits, int geglu, long long* slab_floats, int* tiles);
 int ga_linear_fused(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, const ga_linear_epilogue_t* ep,
                     float* slabs, unsigned* tickets, int64_t M, int K, int N, int bm, int bn, int splits, int stages,

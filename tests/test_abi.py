@@ -111,7 +111,10 @@ def test_struct_layout_matches_header(tmp_path):
     assert ctypes.sizeof(_lib.ga_loss_params_t) == 40
     fields = {"ga_token_t": ["token", "kind", "geom", "weight"],
               "ga_loss_params_t": ["inside_scale", "outside_scale", "center_weight", "sigma", "shrink", "ksize", "smooth",
-                                   "strict"]}
+                                   "strict"],
+              "ga_linear_epilogue_t": ["bias", "residual", "ld_res", "geglu", "preact", "ld_pre", "ln_partials", "ln_parts", "ln_eps",
+                                       "ln_colsum", "ln_shift", "ln_stats_out", "row_partials_out", "gn_partials", "gn_groups",
+                                       "gn_hw"]}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "ga_hip.h"', "int main(void) {"]
     for st, fs in fields.items():
         src.append(f'  printf("{st} %zu\\n", sizeof({st}));')

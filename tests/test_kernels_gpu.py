@@ -1314,6 +1314,54 @@ def test_linear_stream_form(ops, case, dt):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("case", [(1, 4096, 320, 320, 32), (3, 4096, 320, 320, 32), (2, 1024, 640, 640, 32), (1, 4096, 320, 640, 32),
+                                  (2, 256, 128, 192, 8), (1, 1024, 320, 1280, 32)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_linear_epilogue_takes_the_consuming_group_norm_statistics(ops, case, dt):
+    """ga_linear_fused with gn_partials (the transformer's proj_out + residual in front of a ResnetBlock's norm1 / conv_norm_out):
+    the epilogue leaves the per-(image, m tile, group) partial sums of its STORED result, in the layout of the convolution's, and
+    the norm runs as one launch on them (ga_group_norm_apply) — the sums against fp64 of the stored tensor, the norm against fp64
+    and against the two-launch norm, for every tile and with split-K; the result itself is bit-identical with and without."""
+    B, HW, K, N, groups = case
+    T = DT[dt]
+    M = B * HW
+    x = dev(hashrand.normalish((M, K), 180 + K), T)
+    w = dev(hashrand.normalish((N, K), 181) * (1.0 / math.sqrt(K)), T)
+    bias = dev(hashrand.normalish((N,), 182) * 0.3, T)
+    res = dev(hashrand.normalish((M, N), 183) * 1.5 + 0.3, T)
+    gamma = dev(hashrand.normalish((N,), 184) * 0.3 + 1.0, T)
+    beta = dev(hashrand.normalish((N,), 185) * 0.2, T)
+    side = int(round(HW ** 0.5))
+    nchw = lambda t: t.reshape(B, side, HW // side, N).permute(0, 3, 1, 2)      # noqa: E731  channels-last view
+    served = 0
+    for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64)):
+        for splits in (1, 2):
+            plan = (bm, bn, splits, 4 if bm * bn <= 64 * 128 else 2)
+            plain = ops.linear_fused(x, w, bias, residual=res, plan=plan)["y"]
+            out = ops.linear_fused(x, w, bias, residual=res, plan=plan, gn=(groups, HW))
+            assert torch.equal(out["y"], plain)
+            blocks = ops.load().ga_linear_gn_blocks(HW, N, groups, bm, bn)
+            if not blocks:
+                assert out["gn"] is None
+                continue
+            served += 1
+            partials, nb = out["gn"]
+            assert nb == blocks == 2 * (HW // bm) and tuple(partials.shape) == (B, blocks, groups, 2)
+            yg = nchw(plain).double().cpu().reshape(B, groups, -1)
+            close(partials[..., 0].sum(1), yg.sum(-1).numpy(), 2e-5, f"sum {plan}")
+            close(partials[..., 1].sum(1), (yg * yg).sum(-1).numpy(), 2e-5, f"sum of squares {plan}")
+            if ops.gn_two_launch(HW, N, groups, T):
+                y4 = nchw(plain)
+                ref = torch.nn.functional.silu(torch.nn.functional.group_norm(y4.double().cpu(), groups, gamma.double().cpu(),
+                                                                              beta.double().cpu(), 1e-5))
+                z = ops.GroupNormAct.apply(y4, gamma, beta, groups, 1e-5, True, None, False, (partials, nb))
+                close(z, ref.numpy(), TOL[dt] * 2, f"one-launch norm {plan}")
+                close(z, ops.group_norm_act(y4, gamma, beta, groups, 1e-5, True).double().cpu().numpy(), TOL[dt], f"vs two {plan}")
+    assert served >= 2
+    assert int(ops.linear_workspace(x.device)["tickets"].abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("case", [(1, 640, 320, 64, 64), (3, 320, 320, 64, 64), (2, 1280, 640, 32, 32), (1, 640, 320, 50, 64),
                                   (2, 64, 64, 16, 16), (1, 328, 312, 64, 64), (1, 1280, 1280, 16, 16), (3, 1280, 640, 16, 16),
                                   (2, 1280, 1280, 8, 8), (3, 640, 320, 16, 9)],
